@@ -1,0 +1,153 @@
+/*
+ * hiast_hip.h — C ABI of libhiast_hip.so, the MI355X (gfx950) kernels behind HIAST's
+ * self-training hot path.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer into caller-owned memory unless marked "host";
+ *     the library never allocates, frees or keeps a pointer after the call returns;
+ *   - tensors are contiguous NCHW fp32; label maps are uint8 or int64 (is_i64 flag);
+ *   - calls only ENQUEUE work on `stream` (a hipStream_t passed as void*); they never
+ *     synchronise the device, so a caller's DDP/compute overlap is preserved;
+ *   - return value: 0 = ok, <0 = argument error (HIAST_E_*), >0 = a hipError_t;
+ *   - thread-safe for distinct streams; no global state.
+ *
+ * Each entry point cites the reference call it stands in for (paths under
+ * bupt-ai-cz/HIAST `code/`).  The reference has no native code: these replace
+ * torch/cuDNN/numpy calls made from its Python.
+ */
+#ifndef HIAST_HIP_H
+#define HIAST_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIAST_ABI_VERSION 1
+
+#define HIAST_E_ARG   (-1) /* null pointer / non-positive extent */
+#define HIAST_E_RANGE (-2) /* extent outside what the kernels are built for */
+#define HIAST_E_WS    (-3) /* workspace too small */
+
+/* fp16 bit patterns 0x0000..0x3C00 (0.0 .. 1.0): one histogram bin per representable
+ * fp16 confidence value; reproduces `probs.astype(np.float16)` exactly
+ * (workflows/pseudo_label_generator.py:201). */
+#define HIAST_NBINS 15361
+/* Σ max-prob is accumulated exactly as an integer: prob * 2^30 (prob >= 2^-7). */
+#define HIAST_PROB_FX_SHIFT 30
+#define HIAST_MAX_CLASSES 32
+#define HIAST_IGNORE 255
+
+typedef void* hiast_stream_t;
+
+int hiast_version(void);
+/* host: static string for a negative HIAST_E_* code, "hip error" otherwise */
+const char* hiast_error_string(int code);
+
+/* ---- K2: bilinear upsample, align_corners=True ------------------------------------
+ * F.interpolate(logits, size, mode='bilinear', align_corners=True):
+ *   sseg/models/segmentors/self_training_segmentor.py:27, source_only_segmentor.py:19,
+ *   workflows/validator.py:45,52, workflows/trainer/base_trainer.py:169,171.
+ * in [B,C,h,w] -> out [B,C,H,W].  bwd is the exact adjoint (gin overwritten). */
+int hiast_upsample_bilinear_ac_fwd(const float* in, float* out, int B, int C, int h, int w,
+                                   int H, int W, hiast_stream_t stream);
+int hiast_upsample_bilinear_ac_bwd(const float* gout, float* gin, int B, int C, int h, int w,
+                                   int H, int W, hiast_stream_t stream);
+
+/* ---- K3: pseudo-label pass 1 -------------------------------------------------------
+ * F.softmax(logits,1).max(1) on the upsampled logits + the per-class fp16 confidence
+ * lists of workflows/pseudo_label_generator.py:192-201, as one fused kernel:
+ * logits_lr [B,C,h,w] (low-res head output; h==H,w==W accepted) ->
+ *   maxprob f32 [B,H,W], argmax u8 [B,H,W] (first max on ties),
+ *   hist u32 [C,HIAST_NBINS] += count of pixels of class c whose fp16(maxprob) has
+ *   bit pattern `bin` (caller zeroes hist; bins accumulate across calls). */
+int hiast_plabel_pass1(const float* logits_lr, int B, int C, int h, int w, int H, int W,
+                       float* maxprob, uint8_t* argmax, uint32_t* hist,
+                       hiast_stream_t stream);
+
+/* ---- K4: pseudo-label pass 2 -------------------------------------------------------
+ * BasePseudoGenerator.select_and_save_confident_label, pseudo_label_generator.py:67-105:
+ *   plbl = argmax; plbl[maxprob < thr[argmax]] = 255; per-image per-class pixel counts;
+ *   per-class Σ maxprob over kept pixels.
+ * thr_up f32 [C] = smallest float32 >= the float64 threshold (so the fp32 compare equals
+ * the reference's float32<float64 compare); NULL = no threshold ('NT' policy).
+ * count i64 [B,C] and sumprob_fx u64 [C] (Σ prob*2^30, exact) are ACCUMULATED (caller zeroes). */
+int hiast_plabel_pass2(const float* maxprob, const uint8_t* argmax, const float* thr_up,
+                       int B, int C, int64_t HW, uint8_t* plbl, int64_t* count,
+                       uint64_t* sumprob_fx, hiast_stream_t stream);
+
+/* ---- K5-K8: fused self-training loss ------------------------------------------------
+ * SelfTrainingSegmentor.compute_loss, self_training_segmentor.py:30-53 with
+ * losses.py:32-36 (CE), :39-65,75-89 (SoftCE on a region), _kld :153-163, _entropy :140-150,
+ * consuming LOW-RES student logits (and low-res teacher logits; the bilinear upsample of
+ * forward() and the teacher softmax of consistency_self_training_trainer.py:113-119 are
+ * recomputed in-kernel, never materialised).
+ *
+ * sums f64 [8] (overwritten): 0 Σ_conf -logp[y]   1 Σ_conf Σ_c -logp_c/C   2 Σ_ign Σ_c -p_c logp_c
+ *   3 Σ_region Σ_c -q_c logp_c   4 N_conf   5 N_ign   6 #(q_c * -logp_c != 0 in region)   7 unused
+ * The reference's losses are then  w_t*s0/s4, w_k*s1/(C*s4), w_e*s2/(C*s5), w_c*s3/s6
+ * (0/0 = NaN, as in the reference).
+ * region: 0 'ignored' (plbl==255), 1 'confident', 2 'all' (losses.py:77-82).
+ * teacher_lr may be NULL (no consistency term; s3 = s6 = 0).
+ * plbl: uint8 or int64 [B,H,W] (is_i64).
+ * workspace: hiast_st_loss_workspace_bytes(...) bytes of scratch. */
+size_t hiast_st_loss_workspace_bytes(int B, int C, int h, int w, int H, int W);
+int hiast_st_loss_fwd(const float* logits_lr, const float* teacher_lr, const void* plbl,
+                      int plbl_is_i64, int B, int C, int h, int w, int H, int W, int region,
+                      double* sums, void* workspace, size_t workspace_bytes,
+                      hiast_stream_t stream);
+/* d(Σ_i coef_i * loss_i)/d logits_lr, with the loss_i normalised as above.
+ * coef f32 [4] (device) = grad_output_i * weight_i for (CE, KLD, ENT, CST).
+ * dlogits_lr [B,C,h,w] is overwritten. */
+int hiast_st_loss_bwd(const float* logits_lr, const float* teacher_lr, const void* plbl,
+                      int plbl_is_i64, int B, int C, int h, int w, int H, int W, int region,
+                      const double* sums, const float* coef, float* dlogits_lr,
+                      void* workspace, size_t workspace_bytes, hiast_stream_t stream);
+
+/* ---- K1: ASPP head, 4 dilated 3x3 convs summed --------------------------------------
+ * ASPP_V2.forward, sseg/models/modules/seg_models/deeplab_v2.py:20-24 (+ autograd):
+ *   y = Σ_{i<4} conv3x3(x; W_i, b_i, dilation=dil[i], padding=dil[i]).
+ * x [B,Cin,h,w]; W_i [Cout,Cin,3,3]; b_i [Cout]; y [B,Cout,h,w]; Cin % 64 == 0,
+ * Cout <= 32.  wpack: hiast_aspp_wpack_bytes() scratch holding the repacked weights
+ * (written by hiast_aspp_pack_weights, read by fwd / bwd_data).
+ * dil: host int[4]. */
+size_t hiast_aspp_wpack_bytes(int Cin, int Cout);
+int hiast_aspp_pack_weights(const float* w0, const float* w1, const float* w2, const float* w3,
+                            int Cin, int Cout, float* wpack, hiast_stream_t stream);
+int hiast_aspp_fwd(const float* x, const float* wpack, const float* b0, const float* b1,
+                   const float* b2, const float* b3, float* y, int B, int Cin, int h, int w,
+                   int Cout, const int* dil, hiast_stream_t stream);
+/* dx [B,Cin,h,w] overwritten */
+int hiast_aspp_bwd_data(const float* dy, const float* wpack, float* dx, int B, int Cin, int h,
+                        int w, int Cout, const int* dil, hiast_stream_t stream);
+/* dW_i [Cout,Cin,3,3], db_i [Cout] overwritten (i<4) */
+int hiast_aspp_bwd_weight(const float* x, const float* dy, float* dw0, float* dw1, float* dw2,
+                          float* dw3, float* db, int B, int Cin, int h, int w, int Cout,
+                          const int* dil, void* workspace, size_t workspace_bytes,
+                          hiast_stream_t stream);
+size_t hiast_aspp_bwd_weight_workspace_bytes(int B, int Cin, int h, int w, int Cout);
+
+/* ---- K11: EMA teacher update ---------------------------------------------------------
+ * utils/utils.py:115-123 update_ema_model: ema = ema*gamma + p*(1-gamma) over a list of
+ * tensors in ONE launch (gamma, one_minus_gamma: the float32 roundings of the Python
+ * doubles, as torch's tensor*scalar does; mul, mul, add - no fma).  table: device array of n_tensors records
+ * {float* ema; const float* p; int64 n}; chunk_tensor/chunk_start: device int32/int64
+ * arrays of n_chunks entries mapping a 64Ki-element chunk to (tensor, first element). */
+typedef struct { float* ema; const float* p; int64_t n; } hiast_ema_rec;
+int hiast_ema_update(const hiast_ema_rec* table, const int32_t* chunk_tensor,
+                     const int64_t* chunk_start, int n_chunks, float gamma,
+                     float one_minus_gamma, hiast_stream_t stream);
+
+/* ---- K12: IoU histograms --------------------------------------------------------------
+ * utils/metrics.py:6-19 intersectionAndUnionGPU: pred/target int64 [N]; target==255 is
+ * ignored; inter/area_pred/area_tgt i64 [K] ACCUMULATED (caller zeroes). */
+int hiast_confusion_hist(const int64_t* pred, const int64_t* target, int64_t N, int K,
+                         int64_t* inter, int64_t* area_pred, int64_t* area_tgt,
+                         hiast_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIAST_HIP_H */

@@ -1,0 +1,75 @@
+"""Functional torch-CPU fp32 restatement of the reference DeepLab_V2 forward (floating-point oracle).
+
+TEST INFRASTRUCTURE ONLY.  Parity: PINNED by tests/golden/deeplab.npz (outputs of the reference's
+own DeepLab_V2 class on seeded weights).
+
+Follows sseg/models/modules/resnet.py:78-98 (Bottleneck), :176-190 (ResNet.forward) and
+sseg/models/modules/seg_models/deeplab_v2.py:20-24,34-35,42-56,58-64 (output-stride-8 dilation
+surgery, ASPP sum, dead `representation` branch), driven directly by a state dict with the
+reference's key names.
+"""
+import torch
+import torch.nn.functional as F
+
+LAYERS = (3, 4, 23, 3)
+PLANES = (64, 128, 256, 512)
+
+
+def _bn(x, sd, pre, train, eps=1e-5):
+    if train:   # frozen-affine BN still normalises with batch statistics in model.train()
+        return F.batch_norm(x, None, None, sd[pre + ".weight"], sd[pre + ".bias"], True, 0.1, eps)
+    return F.batch_norm(x, sd[pre + ".running_mean"], sd[pre + ".running_var"], sd[pre + ".weight"],
+                        sd[pre + ".bias"], False, 0.1, eps)
+
+
+def conv_geometry(layer, block):
+    """(stride, dilation) of conv2 and stride of the downsample conv after _nostride_dilate
+    (deeplab_v2.py:42-56): layer3/4 lose their stride; block 0 keeps half the dilation."""
+    if layer == 1:
+        return 1, 1
+    if layer == 2:
+        return (2 if block == 0 else 1), 1
+    full = 2 if layer == 3 else 4
+    return 1, (full // 2 if block == 0 else full)
+
+
+def backbone(x, sd, pre="backbone.", train=False):
+    x = F.conv2d(x, sd[pre + "conv1.weight"], None, 2, 3)
+    x = F.relu(_bn(x, sd, pre + "bn1", train))
+    x = F.max_pool2d(x, 3, 2, 1)
+    for li, nblocks in enumerate(LAYERS, start=1):
+        for b in range(nblocks):
+            p = "%slayer%d.%d." % (pre, li, b)
+            stride, dil = conv_geometry(li, b)
+            idt = x
+            o = F.relu(_bn(F.conv2d(x, sd[p + "conv1.weight"]), sd, p + "bn1", train))
+            o = F.conv2d(o, sd[p + "conv2.weight"], None, stride, dil, dil)
+            o = F.relu(_bn(o, sd, p + "bn2", train))
+            o = _bn(F.conv2d(o, sd[p + "conv3.weight"]), sd, p + "bn3", train)
+            if (p + "downsample.0.weight") in sd:
+                idt = _bn(F.conv2d(x, sd[p + "downsample.0.weight"], None, stride), sd,
+                          p + "downsample.1", train)
+            x = F.relu(o + idt)
+    return x
+
+
+def aspp(feat, sd, pre="aspp.conv2d_list.", dil=(6, 12, 18, 24)):
+    out = None
+    for i, d in enumerate(dil):
+        y = F.conv2d(feat, sd["%s%d.weight" % (pre, i)], sd["%s%d.bias" % (pre, i)], 1, d, d)
+        out = y if out is None else out + y
+    return out
+
+
+def deeplab_v2(x, sd, train=False):
+    """-> (prediction [B,C,H/8,W/8], feature [B,2048,H/8,W/8]); `representation` is computed and
+    dropped by the reference (deeplab_v2.py:63), so it is skipped here."""
+    feat = backbone(x, sd, train=train)
+    return aspp(feat, sd), feat
+
+
+def segmentor_logits(x, sd, train=False, prefix="seg_model."):
+    """SelfTrainingSegmentor.forward (self_training_segmentor.py:25-28)."""
+    sub = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)} if prefix else sd
+    pred, feat = deeplab_v2(x, sub, train)
+    return F.interpolate(pred, size=x.shape[2:], mode="bilinear", align_corners=True), pred, feat

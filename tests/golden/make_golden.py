@@ -1,0 +1,380 @@
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE (bupt-ai-cz/HIAST at /root/reference) in the
+build container under torch-CPU / numpy, on seeded synthetic inputs (tests/synth.py).
+
+    python tests/golden/make_golden.py            # regenerate everything
+
+The fixtures hold only inputs' seeds/shapes and the reference's OUTPUTS (data, not source).
+The reference is executed under this container's torch 2.10 (CPU) + numpy 2.2, not its pinned
+torch 1.7.1 / numpy 1.19.2 (unobtainable offline); versions are recorded in each fixture.
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+import ref_import  # noqa: E402
+import synth  # noqa: E402
+
+META = json.dumps({"torch": torch.__version__, "numpy": np.__version__,
+                   "reference": "bupt-ai-cz/HIAST @ /root/reference", "device": "cpu"})
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, meta=np.array(META), **arrays)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+def ns(**kw):
+    return types.SimpleNamespace(**kw)
+
+
+def make_cfg(num_classes=19, kld_w=0.1, ent_w=1.0, cst=True, cst_w=0.5, region='ignored',
+             alpha=0.5, beta=0.9, gamma=8.0, cp_gamma=0.99):
+    return ns(
+        dataset=ns(num_classes=num_classes, source=ns(type='GTAV')),
+        model=ns(seg_model=ns(type='DeepLab_V2', output_dim=256),
+                 predictor=ns(seg_loss=ns(type='CE', source_weight=1.0, target_pseudo_weight=1.0),
+                              kld_loss=ns(weight=kld_w), ent_loss=ns(weight=ent_w))),
+        cst_training=ns(is_enabled=cst, cst_loss=ns(type='SoftCE', weight=cst_w, region=region)),
+        mut_training=ns(is_enabled=False),
+        pseudo_policy=ns(ias=ns(alpha=alpha, beta=beta, gamma=gamma), type='IAS'),
+        preprocessor=ns(copy_paste=ns(gamma=cp_gamma, selected_num_classes=14, mode='original')),
+    )
+
+
+# ---------------------------------------------------------------------------------- G3
+def g_upsample():
+    F = torch.nn.functional
+    out = {}
+    for tag, (B, C, h, w, H, W) in {"a": (1, 5, 6, 9, 41, 70), "b": (1, 4, 8, 16, 64, 128),
+                                    "c": (1, 3, 5, 7, 5, 7)}.items():
+        x = synth.normal_f32(100 + ord(tag), (B, C, h, w), 2.0)
+        t = torch.from_numpy(x).requires_grad_(True)
+        y = F.interpolate(t, size=(H, W), mode='bilinear', align_corners=True)
+        g = synth.normal_f32(200 + ord(tag), (B, C, H, W))
+        y.backward(torch.from_numpy(g))
+        out["shape_" + tag] = np.array([B, C, h, w, H, W])
+        out["y_" + tag] = y.detach().numpy()
+        out["gin_" + tag] = t.grad.numpy()
+    save("upsample", **out)
+
+
+# ---------------------------------------------------------------------------------- G4
+def g_stage_a():
+    """pseudo_label_generator.py:191-195 on the output of SelfTrainingSegmentor.forward's
+    interpolate (self_training_segmentor.py:27): low-res logits -> max-prob, argmax."""
+    F = torch.nn.functional
+    out = {}
+    for tag, (B, C, h, w, H, W, sig) in {"a": (2, 19, 8, 16, 64, 128, 3.0),
+                                         "b": (1, 19, 9, 17, 65, 129, 6.0),
+                                         "c": (1, 9, 6, 6, 48, 48, 1.0)}.items():
+        z = synth.logits_lr(300 + ord(tag), B, C, h, w, sig)
+        if tag == "c":
+            z[:, 1] = z[:, 0]          # exact ties: class 0 must win
+            z[:, 5] = z[:, 0]
+        logits = F.interpolate(torch.from_numpy(z), size=(H, W), mode='bilinear', align_corners=True)
+        probs = F.softmax(logits, dim=1)
+        pp, lp = probs.max(dim=1)
+        out["shape_" + tag] = np.array([B, C, h, w, H, W])
+        out["sigma_" + tag] = np.array(sig)
+        out["maxprob_" + tag] = pp.numpy()
+        out["argmax_" + tag] = lp.numpy().astype(np.uint8)
+    save("stage_a", **out)
+
+
+# ---------------------------------------------------------------------------------- G5
+def _ias_generator(cfg):
+    plg = ref_import.ref("workflows.pseudo_label_generator")
+    gen = object.__new__(plg.IASPseudoGenerator)   # bypass initialize(): needs .cuda() + a dataset
+    C = cfg.dataset.num_classes
+    gen.cfg = cfg
+    gen.statics_class = np.array([0] * C)
+    gen.sample_stats = []
+    gen.samples_class = {i: [] for i in range(C)}
+    gen.class_mean_probs = np.zeros(C)
+    gen.pseudo_label_save_dir = "/nonexistent/pseudo_labels"
+    return gen
+
+
+def _ias_run(gen, batches):
+    """body of IASPseudoGenerator.run (pseudo_label_generator.py:185-211) driven with
+    precomputed (probs_pred, lbls_pred, paths) instead of a model + loader; the calls are
+    the reference's own methods."""
+    cfg = gen.cfg
+    C = cfg.dataset.num_classes
+    gen.class_threshold = 0.9 * np.ones(C)
+    temps, thrs, plbls, means = [], [], [], []
+    for probs_pred, lbls_pred, paths in batches:
+        class_probs_dict = {c: [gen.class_threshold[c]] for c in range(C)}
+        for c in range(C):
+            class_probs_dict[c].extend(probs_pred[lbls_pred == c].astype(np.float16))
+        temp = gen.get_ias_threshold(class_probs_dict, C, cfg.pseudo_policy.ias.alpha,
+                                     gen.class_threshold, cfg.pseudo_policy.ias.gamma)
+        gen.class_threshold = cfg.pseudo_policy.ias.beta * gen.class_threshold + \
+            (1 - cfg.pseudo_policy.ias.beta) * temp
+        gen.class_threshold[gen.class_threshold >= 1] = 0.999
+        ref_import.captured_pngs().clear()
+        gen.select_and_save_confident_label(probs_pred, lbls_pred, paths)
+        pngs = ref_import.captured_pngs()
+        plbls.append(np.stack([pngs[os.path.join(gen.pseudo_label_save_dir,
+                                                 os.path.splitext(os.path.basename(p))[0] +
+                                                 '_pseudo_label.png')] for p in paths]))
+        temps.append(temp.copy())
+        thrs.append(gen.class_threshold.copy())
+        means.append(gen.class_mean_probs.copy())
+    return temps, thrs, plbls, means
+
+
+def g_ias():
+    C, H, W = 19, 64, 128
+    cfg = make_cfg(C)
+    out = {}
+    # (i) Stage B alone: 6 batches of B=2, and the same 12 images as 3 batches of B=4
+    imgs = [synth.probs_and_labels(500 + i, 1, H, W, C) for i in range(12)]
+    paths = ["data/cityscapes/leftImg8bit/train/x/img_%03d_leftImg8bit.png" % i for i in range(12)]
+    for tag, bs in (("b2", 2), ("b4", 4)):
+        gen = _ias_generator(cfg)
+        batches = []
+        for s in range(0, 12, bs):
+            p = np.concatenate([imgs[i][0] for i in range(s, s + bs)])
+            l = np.concatenate([imgs[i][1] for i in range(s, s + bs)])
+            batches.append((p, l, paths[s:s + bs]))
+        temps, thrs, plbls, means = _ias_run(gen, batches)
+        out["temp_" + tag] = np.stack(temps)
+        out["thr_" + tag] = np.stack(thrs)
+        out["plbl_" + tag] = np.concatenate(plbls).astype(np.uint8)
+        out["mean_" + tag] = np.stack(means)
+        out["statics_" + tag] = np.asarray(gen.statics_class, np.int64)
+        out["sample_stats_" + tag] = np.array(json.dumps(gen.sample_stats))
+        out["samples_class_" + tag] = np.array(json.dumps(gen.samples_class))
+    out["shape"] = np.array([12, H, W, C])
+    save("ias_stage_b", **out)
+
+    # (ii) full chain through torch: low-res logits -> interpolate -> softmax -> max -> IAS
+    F = torch.nn.functional
+    h, w = 8, 16
+    gen = _ias_generator(cfg)
+    batches = []
+    for t in range(4):
+        z = synth.smooth_logits_lr(600 + t, 2, C, h, w)
+        logits = F.interpolate(torch.from_numpy(z), size=(H, W), mode='bilinear', align_corners=True)
+        pp, lp = F.softmax(logits, dim=1).max(dim=1)
+        batches.append((pp.numpy(), lp.numpy(), paths[2 * t:2 * t + 2]))
+    temps, thrs, plbls, means = _ias_run(gen, batches)
+    save("ias_chain", shape=np.array([4, 2, C, h, w, H, W]), temp=np.stack(temps), thr=np.stack(thrs),
+         plbl=np.concatenate(plbls).astype(np.uint8), mean=np.stack(means),
+         statics=np.asarray(gen.statics_class, np.int64))
+
+
+# ---------------------------------------------------------------------------------- G6
+def g_losses():
+    """SelfTrainingSegmentor.compute_loss (self_training_segmentor.py:30-53) + backward."""
+    sts = ref_import.ref("sseg.models.segmentors.self_training_segmentor")
+    losses_mod = ref_import.ref("sseg.models.modules.losses")
+    F = torch.nn.functional
+    out = {}
+    cases = {
+        "mix": dict(seed=700, p_ignore=0.4, region='ignored'),
+        "conf": dict(seed=710, p_ignore=0.3, region='confident'),
+        "all": dict(seed=720, p_ignore=0.5, region='all'),
+        "allign": dict(seed=730, p_ignore=1.1, region='ignored'),   # every pixel ignored -> NaNs
+        "noign": dict(seed=740, p_ignore=-1.0, region='ignored'),   # no pixel ignored -> NaNs
+        "zeroq": dict(seed=750, p_ignore=0.4, region='ignored'),    # teacher prob underflows to 0
+    }
+    B, C, h, w, H, W = 2, 19, 5, 9, 33, 65
+    for tag, cs in cases.items():
+        cfg = make_cfg(C, region=cs['region'])
+        seg = object.__new__(sts.SelfTrainingSegmentor)
+        torch.nn.Module.__init__(seg)
+        seg.cfg = cfg
+        seg.seg_loss_fun = losses_mod.LOSS['CE'] if hasattr(losses_mod, 'LOSS') else None
+        seg.kld_loss_fun = sts._kld
+        seg.ent_loss_fun = sts._entropy
+        seg.cst_loss_fun = losses_mod.LOSS['SoftCE']
+        z = synth.logits_lr(cs['seed'], B, C, h, w, 2.5)
+        zt = synth.logits_lr(cs['seed'] + 1, B, C, h, w, 2.5)
+        if tag == "zeroq":
+            zt[:, 3] = -150.0            # softmax underflows to exactly 0 for class 3
+        plbl = synth.pseudo_labels(cs['seed'] + 2, B, H, W, C, cs['p_ignore'], np.int64)
+        zl = torch.from_numpy(z).requires_grad_(True)
+        logits = F.interpolate(zl, size=(H, W), mode='bilinear', align_corners=True)
+        with torch.no_grad():
+            tl = F.interpolate(torch.from_numpy(zt), size=(H, W), mode='bilinear', align_corners=True)
+            q = F.softmax(tl, dim=1)
+        losses = seg.compute_loss(logits, torch.from_numpy(plbl), q)
+        names = ['target_seg_loss', 'kld_confident_loss', 'ent_ignored_loss', 'cst_loss']
+        vals = np.array([losses[n].item() for n in names], np.float64)
+        # gradient of the sum of the finite losses w.r.t. the LOW-RES logits
+        finite = [losses[n] for n in names if torch.isfinite(losses[n])]
+        if finite:
+            sum(finite).backward()
+            g = zl.grad.numpy()
+        else:
+            g = np.zeros_like(z)
+        out["vals_" + tag] = vals
+        out["grad_" + tag] = g
+        out["cfg_" + tag] = np.array(json.dumps(cs))
+    out["shape"] = np.array([B, C, h, w, H, W])
+    save("losses", **out)
+
+
+# ---------------------------------------------------------------------------------- G1
+def g_aspp():
+    """ASPP_V2 (deeplab_v2.py:8-24) forward + autograd on a 2048-channel 9x17 map."""
+    dl = ref_import.ref("sseg.models.modules.seg_models.deeplab_v2")
+    C = 19
+    aspp = dl.ASPP_V2([6, 12, 18, 24], [6, 12, 18, 24], C)
+    h, w = 9, 17
+    x = synth.normal_f32(800, (1, 2048, h, w), 1.0)
+    with torch.no_grad():
+        for i, m in enumerate(aspp.conv2d_list):
+            m.weight.copy_(torch.from_numpy(synth.normal_f32(810 + i, (C, 2048, 3, 3), 0.01)))
+            m.bias.copy_(torch.from_numpy(synth.normal_f32(820 + i, (C,), 0.1)))
+    xt = torch.from_numpy(x).requires_grad_(True)
+    y = aspp(xt)
+    gy = synth.normal_f32(830, (1, C, h, w))
+    y.backward(torch.from_numpy(gy))
+    dws = np.stack([m.weight.grad.numpy() for m in aspp.conv2d_list])       # [4,C,2048,3,3]
+    dbs = np.stack([m.bias.grad.numpy() for m in aspp.conv2d_list])
+    save("aspp", y=y.detach().numpy(), dx_sub=xt.grad.numpy()[:, ::61], dx_sum=np.array(
+        xt.grad.double().sum().item()), dw_sub=dws[:, :, ::97], dw_abs_sum=np.array(
+        np.abs(dws.astype(np.float64)).sum()), db=dbs, shape=np.array([1, 2048, h, w, C]))
+
+
+# ---------------------------------------------------------------------------------- G2
+def seeded_state_dict(model, seed):
+    """deterministic weights for every parameter/buffer of a DeepLab_V2-shaped module"""
+    sd = {}
+    for i, (k, v) in enumerate(model.state_dict().items()):
+        if k.endswith("num_batches_tracked"):
+            sd[k] = torch.zeros_like(v)
+        elif k.endswith("running_var"):
+            sd[k] = torch.from_numpy(0.5 + synth.rng(seed + i).random(v.shape, dtype=np.float32))
+        elif k.endswith("running_mean"):
+            sd[k] = torch.from_numpy(synth.normal_f32(seed + i, tuple(v.shape), 0.1))
+        elif v.dim() == 1 and "bn" in k.split(".")[-2] or (v.dim() == 1 and "downsample.1" in k):
+            base = 1.0 if k.endswith("weight") else 0.0
+            sd[k] = torch.from_numpy(base + synth.normal_f32(seed + i, tuple(v.shape), 0.1))
+        elif v.dim() == 4:
+            fan_out = v.shape[0] * v.shape[2] * v.shape[3]
+            std = 0.01 if "aspp" in k else (2.0 / fan_out) ** 0.5
+            sd[k] = torch.from_numpy(synth.normal_f32(seed + i, tuple(v.shape), std))
+        else:
+            sd[k] = torch.from_numpy(synth.normal_f32(seed + i, tuple(v.shape), 0.05))
+    return sd
+
+
+def g_deeplab():
+    m = ref_import.ref_deeplab_v2(19, 256)
+    m.load_state_dict(seeded_state_dict(m, 9000))
+    m.eval()
+    out = {}
+    for tag, (H, W) in {"a": (65, 129), "b": (128, 256)}.items():
+        x = synth.normal_f32(900 + ord(tag), (1, 3, H, W))
+        with torch.no_grad():
+            pred, feat = m(torch.from_numpy(x))
+        out["pred_" + tag] = pred.numpy()
+        out["feat_sub_" + tag] = feat.numpy()[:, ::64]
+        out["feat_sum_" + tag] = np.array(feat.double().sum().item())
+        out["shape_" + tag] = np.array([1, 3, H, W])
+    # train-mode (batch-stat BN) forward on a batch of 2, as SelfTrainingTrainer.train does
+    m.train()
+    x = synth.normal_f32(950, (2, 3, 65, 129))
+    with torch.no_grad():
+        pred, _ = m(torch.from_numpy(x))
+    out["pred_train"] = pred.numpy()
+    out["keys"] = np.array(json.dumps(list(m.state_dict().keys())))
+    save("deeplab", **out)
+
+
+# ---------------------------------------------------------------------------------- G7
+def g_metrics():
+    met = ref_import.ref("utils.metrics")
+    out = {}
+    for tag, seed in (("a", 1000), ("b", 1001)):
+        g = synth.rng(seed)
+        pred = g.integers(0, 19, size=(2, 40, 60), dtype=np.int64)
+        tgt = g.integers(0, 19, size=(2, 40, 60), dtype=np.int64)
+        tgt[g.random((2, 40, 60)) < 0.2] = 255
+        i, u = met.intersectionAndUnionGPU(torch.from_numpy(pred.copy()), torch.from_numpy(tgt), 19)
+        out["inter_" + tag] = i.numpy()
+        out["union_" + tag] = u.numpy()
+    save("metrics", **out)
+
+
+# ---------------------------------------------------------------------------------- G8
+def g_copy_paste():
+    """CopyPaste.run (sseg/datasets/preprocessor.py:12-122) on an in-memory dataset stub."""
+    pp = ref_import.ref("sseg.datasets.preprocessor")
+    C, H, W, N = 19, 24, 40, 6
+    imgs = synth.images_u8(1100, N, H, W)
+    lbls = np.stack([synth.pseudo_labels(1110 + i, 1, H, W, C, 0.3)[0] for i in range(N)])
+    names = ["img_%d.png" % i for i in range(N)]
+    swc = {c: [names[i] for i in range(N) if (lbls[i] == c).any()] for c in range(C)}
+
+    class DS:
+        def get_samples_with_class(self):
+            return swc
+
+        def get_file_to_idx(self, f):
+            return names.index(f)
+
+        def load_data(self, i):
+            return imgs[i].copy(), lbls[i].copy(), names[i]
+
+    cfg = make_cfg(C)
+    class_value = np.linspace(0.55, 0.97, C)[synth.rng(1120).permutation(C)]
+    cp = pp.CopyPaste(cfg, DS(), class_value.copy())
+    np.random.seed(888)
+    outs = [cp.run(imgs[i].copy(), lbls[i].copy()) for i in range(N)]
+    save("copy_paste", img=np.stack([o[0] for o in outs]), lbl=np.stack([o[1] for o in outs]),
+         mask=np.stack([o[2] for o in outs]), class_value=class_value,
+         hard_classes=np.asarray(cp.hard_classes), class_probs=np.asarray(cp.class_probs),
+         shape=np.array([N, H, W, C]))
+
+
+# ---------------------------------------------------------------------------------- G10
+def g_ema_optim():
+    """update_ema_model (utils/utils.py:115-123), Adam(wd=5e-4) (utils.py:142) and the cosine
+    schedule (modules/schedulers.py:9-10) over 3 steps on a tiny parameter set."""
+    sched = ref_import.ref("sseg.models.modules.schedulers")
+    torch.manual_seed(0)
+    p = [torch.nn.Parameter(torch.from_numpy(synth.normal_f32(1200 + i, s))) for i, s in
+         enumerate([(7, 5), (11,), (3, 2, 3, 3)])]
+    e = [q.detach().clone() for q in p]
+    cfg = ns(train=ns(total_iter=10, lr=3e-6, lr_scheduler=ns(type='Cosine')))
+    opt = torch.optim.Adam([{'params': p[:2], 'lr': 3e-6}, {'params': p[2:], 'lr': 3e-5}],
+                           betas=(0.9, 0.999), weight_decay=0.0005)
+    sc = sched.build_scheduler(cfg, opt)
+    gamma = 0.999
+    traj_p, traj_e, lrs = [], [], []
+    for step in range(3):
+        opt.zero_grad()
+        for i, q in enumerate(p):
+            q.grad = torch.from_numpy(synth.normal_f32(1300 + 10 * step + i, tuple(q.shape)))
+        opt.step()
+        for q, k in zip(p, e):   # utils.py:117-119
+            k.data = k.data.clone() * gamma + q.data.clone() * (1 - gamma)
+        sc.step()
+        traj_p.append(np.concatenate([q.detach().numpy().ravel() for q in p]))
+        traj_e.append(np.concatenate([k.numpy().ravel() for k in e]))
+        lrs.append([g['lr'] for g in opt.param_groups])
+    save("ema_optim", p=np.stack(traj_p), e=np.stack(traj_e), lr=np.array(lrs))
+
+
+ALL = {"upsample": g_upsample, "stage_a": g_stage_a, "ias": g_ias, "losses": g_losses,
+       "aspp": g_aspp, "deeplab": g_deeplab, "metrics": g_metrics, "copy_paste": g_copy_paste,
+       "ema_optim": g_ema_optim}
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or list(ALL)
+    for k in which:
+        ALL[k]()

@@ -1,0 +1,244 @@
+"""Pin the oracle (oracle/) against fixtures produced by the reference itself (tests/golden/)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from oracle import cref, ias_ref, losses_ref, metrics_ref, deeplab_ref, copy_paste_ref
+
+
+def ulp_diff(a, b):
+    ia = a.astype(np.float32).view(np.int32).astype(np.int64)
+    ib = b.astype(np.float32).view(np.int32).astype(np.int64)
+    return np.abs(ia - ib)
+
+
+def test_expf_accuracy():
+    x = -np.abs(synth.normal_f32(1, (20000,), 12.0))
+    x[:4] = [0.0, -1e-8, -86.9, -200.0]
+    got = cref.expf(x)
+    want = np.exp(x.astype(np.float64))
+    ok = want > 1e-37
+    rel = np.abs(got[ok] - want[ok]) / want[ok]
+    assert rel.max() < 1.3e-7          # < ~1 ulp
+    assert got[0] == 1.0 and got[3] == 0.0
+
+
+def test_f16_bits_match_numpy():
+    p = np.concatenate([synth.rng(2).random(50000, dtype=np.float32),
+                        np.array([0, 1, 0.5, 65504, 1e-8, 6e-8, 6.1e-5, 0.99975586, 0.9998], np.float32)])
+    want = p.astype(np.float16).view(np.uint16)
+    got = np.array([cref.lib().orc_f16_bits(float(v)) for v in p], np.uint16)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_upsample_vs_reference(golden, tag):
+    g = golden("upsample")
+    B, C, h, w, H, W = g["shape_" + tag]
+    x = synth.normal_f32(100 + ord(tag), (B, C, h, w), 2.0)
+    y = cref.upsample_bilinear_ac(x, H, W)
+    # F.interpolate agrees to a few ulp of the largest tap (different association of the lerp)
+    assert np.abs(y - g["y_" + tag]).max() <= 2e-6 * np.abs(x).max()
+    go = synth.normal_f32(200 + ord(tag), (B, C, H, W))
+    gin = cref.upsample_bilinear_ac_bwd(go, h, w)
+    assert np.allclose(gin, g["gin_" + tag], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_stage_a_vs_reference(golden, tag):
+    g = golden("stage_a")
+    B, C, h, w, H, W = g["shape_" + tag]
+    z = synth.logits_lr(300 + ord(tag), B, C, h, w, float(g["sigma_" + tag]))
+    if tag == "c":
+        z[:, 1] = z[:, 0]
+        z[:, 5] = z[:, 0]
+    mp, am = cref.plabel_stage_a(z, H, W)
+    # bit-exact argmax label map (north_star), max-prob within a few ulp of torch's softmax
+    assert np.array_equal(am, g["argmax_" + tag])
+    # (the upsampled logits differ by ~1e-6 abs from ATen's association of the lerp, which moves
+    #  a probability by the same RELATIVE amount)
+    assert np.allclose(mp, g["maxprob_" + tag], rtol=4e-6, atol=0)
+
+
+@pytest.mark.parametrize("tag,bs", [("b2", 2), ("b4", 4)])
+def test_ias_stage_b_bit_exact(golden, tag, bs):
+    """thresholds (float64 bit patterns), label maps, counts, JSON stats: exact."""
+    g = golden("ias_stage_b")
+    N, H, W, C = g["shape"]
+    imgs = [synth.probs_and_labels(500 + i, 1, H, W, C) for i in range(N)]
+    paths = ["data/cityscapes/leftImg8bit/train/x/img_%03d_leftImg8bit.png" % i for i in range(N)]
+    st = ias_ref.IASState(C, 0.5, 0.9, 8.0, 0.99)
+    plbls = []
+    for k, s in enumerate(range(0, N, bs)):
+        p = np.concatenate([imgs[i][0] for i in range(s, s + bs)])
+        l = np.concatenate([imgs[i][1] for i in range(s, s + bs)])
+        plbls.append(st.step(p, l, paths[s:s + bs]))
+        assert np.array_equal(st.temp_history[-1].view(np.uint32), g["temp_" + tag][k].view(np.uint32))
+        assert np.array_equal(st.class_threshold.view(np.uint64), g["thr_" + tag][k].view(np.uint64))
+        assert np.allclose(st.class_mean_probs, g["mean_" + tag][k], rtol=1e-6, atol=0)
+    assert np.array_equal(np.concatenate(plbls), g["plbl_" + tag])
+    assert np.array_equal(st.statics_class, g["statics_" + tag])
+    want_stats = json.loads(str(g["sample_stats_" + tag]))
+    got_stats = json.loads(json.dumps(st.sample_stats))
+    assert got_stats == want_stats
+    assert json.loads(json.dumps(st.samples_class)) == json.loads(str(g["samples_class_" + tag]))
+
+
+def test_ias_select_c_matches_numpy(golden):
+    """the C select/count/Σprob routine == the numpy restatement (and the exact integer Σ
+    reproduces np.mean to 1e-6)"""
+    C = 19
+    p, l = synth.probs_and_labels(42, 3, 64, 128, C)
+    thr = np.linspace(0.5, 0.95, C)
+    plbl, count, sfx = cref.plabel_select(p, l.astype(np.uint8), thr, C)
+    want = ias_ref.select_confident(p, l, thr)
+    assert np.array_equal(plbl, want.astype(np.uint8))
+    for c in range(C):
+        assert count[:, c].sum() == np.count_nonzero(want == c)
+        if count[:, c].sum():
+            mean = float(sfx[c]) / 2.0 ** 30 / count[:, c].sum()
+            assert abs(mean - np.mean(p[want == c])) <= 1e-6 * mean
+    hist = cref.plabel_hist(p, l.astype(np.uint8), C)
+    for c in (0, 5, C - 2):
+        bits = p[l == c].astype(np.float16).view(np.uint16)
+        assert np.array_equal(np.bincount(bits, minlength=15361)[:15361], hist[c])
+
+
+def test_ias_chain_vs_reference(golden):
+    """low-res logits -> C oracle stage A -> numpy stage B, against the reference driven through
+    torch's interpolate/softmax: thresholds to 1e-5, label maps equal up to borderline pixels."""
+    g = golden("ias_chain")
+    T, B, C, h, w, H, W = g["shape"]
+    st = ias_ref.IASState(C, 0.5, 0.9, 8.0, 0.99)
+    paths = ["p%d.png" % i for i in range(T * B)]
+    plbls = []
+    for t in range(T):
+        z = synth.smooth_logits_lr(600 + t, B, C, h, w)
+        mp, am = cref.plabel_stage_a(z, H, W)
+        plbls.append(st.step(mp, am.astype(np.int64), paths[B * t:B * t + B]))
+        assert np.allclose(st.class_threshold, g["thr"][t], rtol=1e-5, atol=0)
+    got = np.concatenate(plbls)
+    assert (got != g["plbl"]).mean() <= 1e-4
+    assert np.abs(st.statics_class - g["statics"]).sum() <= 1e-4 * got.size
+
+
+LOSS_CASES = ["mix", "conf", "all", "allign", "noign", "zeroq"]
+
+
+@pytest.mark.parametrize("tag", LOSS_CASES)
+def test_losses_vs_reference(golden, tag):
+    g = golden("losses")
+    B, C, h, w, H, W = g["shape"]
+    cs = json.loads(str(g["cfg_" + tag]))
+    z = synth.logits_lr(cs["seed"], B, C, h, w, 2.5)
+    zt = synth.logits_lr(cs["seed"] + 1, B, C, h, w, 2.5)
+    if tag == "zeroq":
+        zt[:, 3] = -150.0
+    plbl = synth.pseudo_labels(cs["seed"] + 2, B, H, W, C, cs["p_ignore"], np.int64)
+    zl = torch.from_numpy(z).requires_grad_(True)
+    L = losses_ref.st_losses(zl, torch.from_numpy(zt), torch.from_numpy(plbl), (H, W), cs["region"])
+    names = ['target_seg_loss', 'kld_confident_loss', 'ent_ignored_loss', 'cst_loss']
+    got = np.array([L[n].item() for n in names])
+    want = g["vals_" + tag]
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    ok = ~np.isnan(want)
+    assert np.allclose(got[ok], want[ok], rtol=2e-6)
+    fin = [L[n] for n in names if torch.isfinite(L[n])]
+    sum(fin).backward()
+    assert np.allclose(zl.grad.numpy(), g["grad_" + tag], rtol=1e-4, atol=1e-7)
+    if tag == "zeroq":   # value-dependent denominator (losses.py:89): class 3 never counted
+        s = losses_ref.st_loss_sums(torch.from_numpy(z), torch.from_numpy(zt), torch.from_numpy(plbl),
+                                    (H, W), cs["region"])
+        assert s["cst_cnt"].item() == (C - 1) * s["n_ign"].item()
+
+
+def test_aspp_vs_reference(golden):
+    g = golden("aspp")
+    _, Cin, h, w, C = g["shape"]
+    x = synth.normal_f32(800, (1, Cin, h, w), 1.0)
+    ws = [synth.normal_f32(810 + i, (C, Cin, 3, 3), 0.01) for i in range(4)]
+    bs = [synth.normal_f32(820 + i, (C,), 0.1) for i in range(4)]
+    y = cref.aspp_fwd(x, ws, bs, (6, 12, 18, 24))
+    assert np.allclose(y, g["y"], rtol=1e-4, atol=1e-5)
+
+
+def test_metrics_vs_reference(golden):
+    g = golden("metrics")
+    for tag, seed in (("a", 1000), ("b", 1001)):
+        r = synth.rng(seed)
+        pred = r.integers(0, 19, size=(2, 40, 60), dtype=np.int64)
+        tgt = r.integers(0, 19, size=(2, 40, 60), dtype=np.int64)
+        tgt[r.random((2, 40, 60)) < 0.2] = 255
+        i, u = metrics_ref.intersection_and_union(pred, tgt, 19)
+        assert np.array_equal(i, g["inter_" + tag].astype(np.int64))
+        assert np.array_equal(u, g["union_" + tag].astype(np.int64))
+
+
+def test_ema_adam_cosine_vs_reference(golden):
+    g = golden("ema_optim")
+    shapes = [(7, 5), (11,), (3, 2, 3, 3)]
+    p = [synth.normal_f32(1200 + i, s) for i, s in enumerate(shapes)]
+    e = [q.copy() for q in p]
+    m = [np.zeros_like(q) for q in p]
+    v = [np.zeros_like(q) for q in p]
+    base = [3e-6, 3e-6, 3e-5]
+    lr = list(base)
+    for step in range(3):
+        for i in range(3):
+            grad = synth.normal_f32(1300 + 10 * step + i, shapes[i]) + np.float32(0.0005) * p[i]
+            m[i] = np.float32(0.9) * m[i] + np.float32(0.1) * grad
+            v[i] = np.float32(0.999) * v[i] + np.float32(0.001) * grad * grad
+            bc1, bc2 = 1 - 0.9 ** (step + 1), 1 - 0.999 ** (step + 1)
+            denom = np.sqrt(v[i]) / np.float32(np.sqrt(bc2)) + np.float32(1e-8)
+            p[i] = (p[i] - np.float32(lr[i] / bc1) * (m[i] / denom)).astype(np.float32)
+            cref.ema_update(e[i].reshape(-1), p[i].reshape(-1), 0.999)
+        t = step + 1   # CosineAnnealingLR closed form, eta_min = lr*1e-3 of the BACKBONE lr (schedulers.py:10)
+        lr = [3e-9 + (b - 3e-9) * (1 + np.cos(np.pi * t / 10)) / 2 for b in base]
+        assert np.allclose(np.concatenate([q.ravel() for q in p]), g["p"][step], rtol=1e-6, atol=1e-9)
+        assert np.array_equal(np.concatenate([q.ravel() for q in e]), g["e"][step]) or \
+            np.allclose(np.concatenate([q.ravel() for q in e]), g["e"][step], rtol=2e-7, atol=0)
+        assert np.allclose([lr[0], lr[2]], g["lr"][step], rtol=1e-9)
+
+
+def test_deeplab_vs_reference(golden):
+    from make_golden import seeded_state_dict
+    import hiast_amd  # noqa: F401  (only to build an identically-keyed module for the seeded weights)
+    from hiast_amd.sseg.models.modules.seg_models.deeplab_v2 import DeepLab_V2
+    g = golden("deeplab")
+    m = DeepLab_V2(19, 256)
+    assert list(m.state_dict().keys()) == json.loads(str(g["keys"]))
+    sd = seeded_state_dict(m, 9000)
+    torch.set_num_threads(8)
+    for tag, (H, W) in {"a": (65, 129), "b": (128, 256)}.items():
+        x = torch.from_numpy(synth.normal_f32(900 + ord(tag), (1, 3, H, W)))
+        with torch.no_grad():
+            pred, feat = deeplab_ref.deeplab_v2(x, sd)
+        assert np.allclose(pred.numpy(), g["pred_" + tag], rtol=1e-4, atol=1e-4)
+        assert np.allclose(feat.numpy()[:, ::64], g["feat_sub_" + tag], rtol=1e-4, atol=1e-4)
+    x = torch.from_numpy(synth.normal_f32(950, (2, 3, 65, 129)))
+    with torch.no_grad():
+        pred, _ = deeplab_ref.deeplab_v2(x, sd, train=True)
+    assert np.allclose(pred.numpy(), g["pred_train"], rtol=1e-3, atol=1e-3)
+
+
+def test_copy_paste_vs_reference(golden):
+    g = golden("copy_paste")
+    N, H, W, C = g["shape"]
+    imgs = synth.images_u8(1100, N, H, W)
+    lbls = np.stack([synth.pseudo_labels(1110 + i, 1, H, W, C, 0.3)[0] for i in range(N)])
+    names = ["img_%d.png" % i for i in range(N)]
+    swc = {c: [names[i] for i in range(N) if (lbls[i] == c).any()] for c in range(C)}
+    cv = g["class_value"]
+    hard = copy_paste_ref.hard_classes(cv, 14)
+    probs = copy_paste_ref.class_probs(cv)
+    assert np.array_equal(hard, g["hard_classes"])
+    assert np.allclose(probs, g["class_probs"], rtol=1e-12)
+    np.random.seed(888)
+    for i in range(N):
+        im, lb, mk = copy_paste_ref.run(imgs[i].copy(), lbls[i].copy(), hard, g["class_probs"], swc,
+                                        lambda n: (imgs[names.index(n)], lbls[names.index(n)]), C)
+        assert np.array_equal(im, g["img"][i]) and np.array_equal(lb, g["lbl"][i])
+        assert np.array_equal(mk, g["mask"][i])
