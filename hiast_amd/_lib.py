@@ -1,0 +1,76 @@
+"""ctypes binding of libhiast_hip.so (the C ABI of include/hiast_hip.h).
+
+There is NO fallback: if the library is missing or an entry point returns non-zero, the call
+raises.  `import torch` happens first so the library binds to the same libamdhip64 that
+PyTorch-ROCm has loaded (device pointers and streams are shared).
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (loads libamdhip64 before our library is opened)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libhiast_hip.so")
+
+c_int, c_i64, c_f32, c_sz, c_vp = (ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t,
+                                   ctypes.c_void_p)
+
+# name -> (restype, argtypes); mirrors include/hiast_hip.h one to one
+SIGNATURES = {
+    "hiast_version": (c_int, []),
+    "hiast_error_string": (ctypes.c_char_p, [c_int]),
+    "hiast_upsample_bilinear_ac_fwd": (c_int, [c_vp, c_vp] + [c_int] * 6 + [c_vp]),
+    "hiast_upsample_bilinear_ac_bwd": (c_int, [c_vp, c_vp] + [c_int] * 6 + [c_vp]),
+    "hiast_plabel_pass1": (c_int, [c_vp] + [c_int] * 6 + [c_vp, c_vp, c_vp, c_vp]),
+    "hiast_plabel_pass2": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_i64, c_vp, c_vp, c_vp, c_vp]),
+    "hiast_st_loss_workspace_bytes": (c_sz, [c_int] * 6),
+    "hiast_st_loss_fwd": (c_int, [c_vp, c_vp, c_vp] + [c_int] * 8 + [c_vp, c_vp, c_sz, c_vp]),
+    "hiast_st_loss_bwd": (c_int, [c_vp, c_vp, c_vp] + [c_int] * 8 + [c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "hiast_aspp_wpack_bytes": (c_sz, [c_int, c_int]),
+    "hiast_aspp_workspace_bytes": (c_sz, [c_int] * 5),
+    "hiast_aspp_pack_weights": (c_int, [c_vp] * 8 + [c_int, c_int, c_vp, c_vp]),
+    "hiast_aspp_fwd": (c_int, [c_vp, c_vp, c_vp] + [c_int] * 5 + [c_vp, c_vp, c_sz, c_vp]),
+    "hiast_aspp_bwd_data": (c_int, [c_vp, c_vp, c_vp] + [c_int] * 5 + [c_vp, c_vp]),
+    "hiast_aspp_bwd_weight": (c_int, [c_vp] * 7 + [c_int] * 5 + [c_vp, c_vp, c_sz, c_vp]),
+    "hiast_ema_update": (c_int, [c_vp, c_vp, c_vp, c_int, c_f32, c_f32, c_vp]),
+    "hiast_confusion_hist": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp]),
+}
+
+NBINS = 15361
+PROB_FX_SHIFT = 30
+IGNORE = 255
+
+_lib = None
+
+
+class HiastLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Open libhiast_hip.so and type every entry point; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HiastLibraryError(
+            "libhiast_hip.so is not built (%s). Build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C hiast_amd/csrc`; there is no fallback path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HiastLibraryError("libhiast_hip.so does not export %s" % name) from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.hiast_version() != 1:
+        raise HiastLibraryError("libhiast_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().hiast_error_string(int(code)).decode()
+        raise HiastLibraryError("%s failed: %s (code %d)" % (what, msg, code))

@@ -1,0 +1,108 @@
+// Version / error strings, K11 (EMA teacher update) and K12 (IoU area histograms).
+#include "common.h"
+
+namespace hiast {
+
+// utils/utils.py:115-123: ema = ema*gamma + p*(1-gamma) — mul, mul, add (no fma: the library is
+// built with -ffp-contract=off), one launch for the whole parameter list.
+// 64Ki-element chunks; 256 threads x float4 x 64 iterations per chunk.
+__global__ __launch_bounds__(256) void ema_kernel(const hiast_ema_rec* __restrict__ table,
+                                                  const int32_t* __restrict__ chunk_tensor,
+                                                  const int64_t* __restrict__ chunk_start,
+                                                  float gamma, float omg)
+{
+    const hiast_ema_rec r = table[chunk_tensor[blockIdx.x]];
+    const int64_t s = chunk_start[blockIdx.x];
+    const int64_t e = (s + 65536 < r.n) ? s + 65536 : r.n;
+    float* __restrict__ d = r.ema;
+    const float* __restrict__ p = r.p;
+    const bool vec = ((((uintptr_t)d) | ((uintptr_t)p)) & 15) == 0;   // s is a multiple of 64Ki
+    if (vec) {
+        const int64_t nv = (e - s) / 4;
+        float4* d4 = reinterpret_cast<float4*>(d + s);
+        const float4* p4 = reinterpret_cast<const float4*>(p + s);
+        for (int64_t i = threadIdx.x; i < nv; i += 256) {
+            float4 a = d4[i], b = p4[i];
+            a.x = a.x * gamma + b.x * omg;
+            a.y = a.y * gamma + b.y * omg;
+            a.z = a.z * gamma + b.z * omg;
+            a.w = a.w * gamma + b.w * omg;
+            d4[i] = a;
+        }
+        for (int64_t i = s + nv * 4 + threadIdx.x; i < e; i += 256) d[i] = d[i] * gamma + p[i] * omg;
+    } else {
+        for (int64_t i = s + threadIdx.x; i < e; i += 256) d[i] = d[i] * gamma + p[i] * omg;
+    }
+}
+
+// utils/metrics.py:6-19: pred[target==255] = 255; inter = hist(pred[pred==target]);
+// area_pred = hist(pred); area_tgt = hist(target) over K bins.  Per-thread pixels -> LDS integer
+// histograms (3*K counters) -> one global integer atomic per non-empty counter per block.
+__global__ __launch_bounds__(256) void confusion_kernel(const int64_t* __restrict__ pred,
+                                                        const int64_t* __restrict__ target,
+                                                        int64_t N, int K,
+                                                        unsigned long long* __restrict__ inter,
+                                                        unsigned long long* __restrict__ ap,
+                                                        unsigned long long* __restrict__ at)
+{
+    extern __shared__ unsigned s_h[];   // [3][K]
+    for (int i = threadIdx.x; i < 3 * K; i += 256) s_h[i] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)gridDim.x * 256) {
+        const int64_t t = target[i];
+        const int64_t p = (t == HIAST_IGNORE) ? HIAST_IGNORE : pred[i];
+        if (p >= 0 && p < K) atomicAdd(&s_h[K + (int)p], 1u);
+        if (t >= 0 && t < K) atomicAdd(&s_h[2 * K + (int)t], 1u);
+        if (p == t && p >= 0 && p < K) atomicAdd(&s_h[(int)p], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * K; i += 256) {
+        const unsigned v = s_h[i];
+        if (!v) continue;
+        unsigned long long* dst = i < K ? inter + i : (i < 2 * K ? ap + (i - K) : at + (i - 2 * K));
+        atomicAdd(dst, (unsigned long long)v);
+    }
+}
+
+}  // namespace hiast
+
+extern "C" int hiast_version(void) { return HIAST_ABI_VERSION; }
+
+extern "C" const char* hiast_error_string(int code)
+{
+    switch (code) {
+        case 0: return "ok";
+        case HIAST_E_ARG: return "hiast: null pointer or non-positive extent";
+        case HIAST_E_RANGE: return "hiast: extent outside the range the kernels are built for";
+        case HIAST_E_WS: return "hiast: workspace too small";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "hiast: unknown error";
+    }
+}
+
+extern "C" int hiast_ema_update(const hiast_ema_rec* table, const int32_t* chunk_tensor,
+                                const int64_t* chunk_start, int n_chunks, float gamma,
+                                float one_minus_gamma, hiast_stream_t stream)
+{
+    if (!table || !chunk_tensor || !chunk_start) return HIAST_E_ARG;
+    if (n_chunks <= 0) return HIAST_E_ARG;
+    hipLaunchKernelGGL(hiast::ema_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, table,
+                       chunk_tensor, chunk_start, gamma, one_minus_gamma);
+    HIAST_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int hiast_confusion_hist(const int64_t* pred, const int64_t* target, int64_t N, int K,
+                                    int64_t* inter, int64_t* area_pred, int64_t* area_tgt,
+                                    hiast_stream_t stream)
+{
+    if (!pred || !target || !inter || !area_pred || !area_tgt) return HIAST_E_ARG;
+    if (N <= 0 || K <= 0) return HIAST_E_ARG;
+    if (K > 1024) return HIAST_E_RANGE;
+    int64_t nb = (N + 256 * 16 - 1) / (256 * 16);
+    int grid = (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
+    hipLaunchKernelGGL(hiast::confusion_kernel, dim3(grid), dim3(256), 3 * K * sizeof(unsigned),
+                       (hipStream_t)stream, pred, target, N, K, (unsigned long long*)inter,
+                       (unsigned long long*)area_pred, (unsigned long long*)area_tgt);
+    HIAST_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,219 @@
+// K3/K4 — pseudo-label kernels (workflows/pseudo_label_generator.py:192-201 and :67-105 of the
+// reference).  gfx950 only.
+//
+// pass 1: fused bilinear upsample (align_corners) + softmax + max/argmax + per-class fp16-bin
+//         confidence histogram.  Full-resolution logits (39.8 MB/img) never exist: each thread
+//         owns one output column X of one "band" (the 8-9 output rows that share a pair of
+//         low-res source rows), keeps the horizontally-lerped top/bottom row values of all C
+//         classes in registers (2*C VGPRs) and walks down the band.
+//         Histogram: wave-aggregated — lanes holding the same (class, bin) key elect a leader
+//         that issues ONE integer atomic of the popcount.
+// pass 2: threshold select + per-image class counts + exact integer Σ prob.
+#include "common.h"
+
+namespace hiast {
+
+template <int C>
+__global__ __launch_bounds__(256) void plabel_pass1_kernel(
+    const float* __restrict__ logits, int h, int w, int H, int W, float sh, float sw,
+    float* __restrict__ maxprob, uint8_t* __restrict__ argmax, uint32_t* __restrict__ hist)
+{
+    const int b = blockIdx.z;
+    const int j = blockIdx.y;                       // band: source rows (j, j+1)
+    const int X = blockIdx.x * 256 + threadIdx.x;
+    const int Y0 = band_start(sh, j, h, H);
+    const int Y1 = band_start(sh, j + 1, h, H);
+    if (Y0 >= Y1) return;                           // wave-uniform
+    const bool live = X < W;
+    const int Xc = live ? X : W - 1;
+
+    const Src sx = src_of(sw, Xc, w);
+    const int y0 = j, y1 = j + (j < h - 1 ? 1 : 0);
+    const float* base = logits + (size_t)b * C * h * w;
+
+    float top[C], bot[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const float* p = base + (size_t)c * h * w;
+        float a = p[y0 * w + sx.i0], bb = p[y0 * w + sx.i1];
+        float cc = p[y1 * w + sx.i0], d = p[y1 * w + sx.i1];
+        top[c] = lerp_h(a, bb, sx.l0, sx.l1);
+        bot[c] = lerp_h(cc, d, sx.l0, sx.l1);
+    }
+
+    for (int Y = Y0; Y < Y1; ++Y) {
+        const Src sy = src_of(sh, Y, h);
+        float z[C];
+        float m = 0.0f;
+        int am = 0;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            z[c] = lerp_v(top[c], bot[c], sy.l0, sy.l1);
+            if (c == 0 || z[c] > m) { m = z[c]; am = c; }   // first max wins ties
+        }
+        float s = 0.0f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) s = s + a_expf(z[c] - m);
+        const float prob = 1.0f / s;                         // IEEE division
+
+        unsigned key = 0xFFFFFFFFu;
+        if (live) {
+            const size_t o = ((size_t)b * H + Y) * W + X;
+            maxprob[o] = prob;
+            argmax[o] = (uint8_t)am;
+            const unsigned bin = __half_as_ushort(__float2half_rn(prob));
+            if (bin < HIAST_NBINS) key = (unsigned)am * HIAST_NBINS + bin;
+        }
+        // wave-aggregated histogram update
+        unsigned long long todo = __ballot(key != 0xFFFFFFFFu);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const unsigned k = __shfl(key, leader, 64);
+            const unsigned long long same = __ballot(key == k);
+            if (lane_id() == leader) atomicAdd(&hist[k], (unsigned)__popcll(same));
+            todo &= ~same;
+        }
+    }
+}
+
+template <int C>
+static int launch_pass1(const float* logits, int B, int h, int w, int H, int W, float* maxprob,
+                        uint8_t* argmax, uint32_t* hist, hipStream_t st)
+{
+    const float sh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.0f;
+    const float sw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.0f;
+    dim3 grid((W + 255) / 256, h, B);
+    hipLaunchKernelGGL(plabel_pass1_kernel<C>, grid, dim3(256), 0, st, logits, h, w, H, W, sh, sw,
+                       maxprob, argmax, hist);
+    HIAST_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// pass 2: VEC pixels per thread per iteration (VEC=4: float4 + uchar4 when every image row base
+// stays 16-byte aligned; VEC=1 for ragged sizes), class statistics reduced per wave over the
+// distinct labels present, then per block in LDS, then one integer atomic per class.
+template <bool HAS_THR, int VEC>
+__global__ __launch_bounds__(256) void plabel_pass2_kernel(
+    const float* __restrict__ maxprob, const uint8_t* __restrict__ argmax,
+    const float* __restrict__ thr_up, int C, long long HW, uint8_t* __restrict__ plbl,
+    long long* __restrict__ count, unsigned long long* __restrict__ sumprob_fx)
+{
+    __shared__ unsigned s_cnt[HIAST_MAX_CLASSES];
+    __shared__ unsigned long long s_sum[HIAST_MAX_CLASSES];
+    __shared__ float s_thr[HIAST_MAX_CLASSES];
+    const int b = blockIdx.y;
+    if (threadIdx.x < HIAST_MAX_CLASSES) {
+        s_cnt[threadIdx.x] = 0;
+        s_sum[threadIdx.x] = 0;
+        s_thr[threadIdx.x] = (HAS_THR && (int)threadIdx.x < C) ? thr_up[threadIdx.x] : 0.0f;
+    }
+    __syncthreads();
+
+    const float* mp = maxprob + (size_t)b * HW;
+    const uint8_t* am = argmax + (size_t)b * HW;
+    uint8_t* out = plbl + (size_t)b * HW;
+    const long long nvec = HW / VEC;
+    // block-uniform trip count: every lane stays in the loop for the ballots / shuffles
+    for (long long base = (long long)blockIdx.x * 256; base < nvec; base += (long long)gridDim.x * 256) {
+        const long long v = base + threadIdx.x;
+        const bool in = v < nvec;
+        float pv[VEC];
+        uint8_t lv[VEC];
+        if (VEC == 4) {
+            float4 p = make_float4(0, 0, 0, 0);
+            uchar4 l = make_uchar4(255, 255, 255, 255);
+            if (in) {
+                p = reinterpret_cast<const float4*>(mp)[v];
+                l = reinterpret_cast<const uchar4*>(am)[v];
+            }
+            pv[0] = p.x; pv[VEC > 1 ? 1 : 0] = p.y; pv[VEC > 2 ? 2 : 0] = p.z; pv[VEC > 3 ? 3 : 0] = p.w;
+            lv[0] = l.x; lv[VEC > 1 ? 1 : 0] = l.y; lv[VEC > 2 ? 2 : 0] = l.z; lv[VEC > 3 ? 3 : 0] = l.w;
+        } else {
+            pv[0] = in ? mp[v] : 0.0f;
+            lv[0] = in ? am[v] : (uint8_t)255;
+        }
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            uint8_t lab = lv[k];
+            if (in && lab < C) {
+                if (HAS_THR && pv[k] < s_thr[lab]) lab = HIAST_IGNORE;
+            } else {
+                lab = HIAST_IGNORE;
+            }
+            lv[k] = lab;
+            // exact: prob is a multiple of 2^-30 for prob >= 2^-7
+            const unsigned long long fx = (unsigned long long)((double)pv[k] * 1073741824.0);
+            unsigned long long todo = __ballot(lab != HIAST_IGNORE);
+            while (todo) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const int cl = __shfl((int)lab, leader, 64);
+                const unsigned long long same = __ballot((int)lab == cl);
+                const unsigned long long s = wave_sum_u64((int)lab == cl ? fx : 0ull);
+                if (lane_id() == leader) {
+                    atomicAdd(&s_cnt[cl], (unsigned)__popcll(same));
+                    atomicAdd(&s_sum[cl], s);
+                }
+                todo &= ~same;
+            }
+        }
+        if (in) {
+            if (VEC == 4)
+                reinterpret_cast<uchar4*>(out)[v] = make_uchar4(lv[0], lv[VEC > 1 ? 1 : 0],
+                                                                lv[VEC > 2 ? 2 : 0], lv[VEC > 3 ? 3 : 0]);
+            else
+                out[v] = lv[0];
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < C && s_cnt[threadIdx.x]) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(&count[(size_t)b * C + threadIdx.x]),
+                  (unsigned long long)s_cnt[threadIdx.x]);
+        atomicAdd(&sumprob_fx[threadIdx.x], s_sum[threadIdx.x]);
+    }
+}
+
+}  // namespace hiast
+
+extern "C" int hiast_plabel_pass1(const float* logits_lr, int B, int C, int h, int w, int H, int W,
+                                  float* maxprob, uint8_t* argmax, uint32_t* hist,
+                                  hiast_stream_t stream)
+{
+    if (!logits_lr || !maxprob || !argmax || !hist) return HIAST_E_ARG;
+    if (B <= 0 || C <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return HIAST_E_ARG;
+    if (H < h || W < w || B > 65535 || h > 65535) return HIAST_E_RANGE;
+    hipStream_t st = (hipStream_t)stream;
+    switch (C) {
+        case 19: return hiast::launch_pass1<19>(logits_lr, B, h, w, H, W, maxprob, argmax, hist, st);
+        case 16: return hiast::launch_pass1<16>(logits_lr, B, h, w, H, W, maxprob, argmax, hist, st);
+        case 9: return hiast::launch_pass1<9>(logits_lr, B, h, w, H, W, maxprob, argmax, hist, st);
+        case 2: return hiast::launch_pass1<2>(logits_lr, B, h, w, H, W, maxprob, argmax, hist, st);
+        default: return HIAST_E_RANGE;   // class counts of the reference's datasets (19 / 9) + tests
+    }
+}
+
+extern "C" int hiast_plabel_pass2(const float* maxprob, const uint8_t* argmax, const float* thr_up,
+                                  int B, int C, int64_t HW, uint8_t* plbl, int64_t* count,
+                                  uint64_t* sumprob_fx, hiast_stream_t stream)
+{
+    if (!maxprob || !argmax || !plbl || !count || !sumprob_fx) return HIAST_E_ARG;
+    if (B <= 0 || C <= 0 || HW <= 0) return HIAST_E_ARG;
+    if (C > HIAST_MAX_CLASSES || B > 65535) return HIAST_E_RANGE;
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec4 = !(((uintptr_t)maxprob) & 15) && !(((uintptr_t)argmax) & 3) &&
+                      !(((uintptr_t)plbl) & 3) && (HW % 4 == 0);
+    const long long nvec = vec4 ? HW / 4 : HW;
+    int gx = (int)((nvec + 256 * 4 - 1) / (256 * 4));
+    gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
+    dim3 grid(gx, B);
+    long long* cnt = (long long*)count;
+    unsigned long long* sfx = (unsigned long long*)sumprob_fx;
+#define HIAST_P2(T, V)                                                                            \
+    hipLaunchKernelGGL((hiast::plabel_pass2_kernel<T, V>), grid, dim3(256), 0, st, maxprob, argmax, \
+                       thr_up, C, (long long)HW, plbl, cnt, sfx)
+    if (thr_up) { if (vec4) HIAST_P2(true, 4); else HIAST_P2(true, 1); }
+    else        { if (vec4) HIAST_P2(false, 4); else HIAST_P2(false, 1); }
+#undef HIAST_P2
+    HIAST_CHECK_LAUNCH();
+    return 0;
+}

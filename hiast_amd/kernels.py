@@ -1,0 +1,266 @@
+"""Tensor-level entry points of the HIP library: validate shapes/dtypes/devices on the host
+(a kernel that faults can take the whole node down), allocate outputs with torch, and enqueue
+on torch's current HIP stream.  No torch arithmetic happens here and there is no CPU path:
+every function requires CUDA(HIP) tensors and raises otherwise.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import NBINS, check
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _req(t, dtype, ndim=None, name="tensor"):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.HiastLibraryError("%s must be a CUDA(HIP) tensor: the HIP path has no CPU fallback" % name)
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if ndim is not None and t.dim() != ndim:
+        raise ValueError("%s must have %d dims, got %s" % (name, ndim, tuple(t.shape)))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    return t
+
+
+# ------------------------------------------------------------------------------- K2 upsample
+def upsample_bilinear_ac_fwd(x, H, W):
+    _req(x, torch.float32, 4, "x")
+    B, C, h, w = x.shape
+    out = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
+    if out.numel():
+        check(_lib.load().hiast_upsample_bilinear_ac_fwd(_ptr(x), _ptr(out), B, C, h, w, H, W, _stream()),
+              "hiast_upsample_bilinear_ac_fwd")
+    return out
+
+
+def upsample_bilinear_ac_bwd(gout, h, w):
+    _req(gout, torch.float32, 4, "gout")
+    B, C, H, W = gout.shape
+    gin = torch.empty((B, C, h, w), dtype=torch.float32, device=gout.device)
+    if gin.numel():
+        check(_lib.load().hiast_upsample_bilinear_ac_bwd(_ptr(gout), _ptr(gin), B, C, h, w, H, W, _stream()),
+              "hiast_upsample_bilinear_ac_bwd")
+    return gin
+
+
+# ------------------------------------------------------------------------------- K3/K4 pseudo labels
+def plabel_pass1(logits_lr, H, W, hist=None):
+    """-> (maxprob f32 [B,H,W], argmax u8 [B,H,W], hist u32-as-int32 [C,NBINS] (accumulated))"""
+    _req(logits_lr, torch.float32, 4, "logits_lr")
+    B, C, h, w = logits_lr.shape
+    dev = logits_lr.device
+    maxprob = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    argmax = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+    if hist is None:
+        hist = torch.zeros((C, NBINS), dtype=torch.int32, device=dev)
+    else:
+        _req(hist, torch.int32, 2, "hist")
+        assert tuple(hist.shape) == (C, NBINS)
+    if B:
+        check(_lib.load().hiast_plabel_pass1(_ptr(logits_lr), B, C, h, w, H, W, _ptr(maxprob), _ptr(argmax),
+                                             _ptr(hist), _stream()), "hiast_plabel_pass1")
+    return maxprob, argmax, hist
+
+
+def plabel_pass2(maxprob, argmax, thr_up, C, count=None, sumprob_fx=None):
+    """thr_up: f32 [C] device tensor or None.  -> (plbl u8, count i64 [B,C], sumprob_fx i64 [C])"""
+    _req(maxprob, torch.float32, 3, "maxprob")
+    _req(argmax, torch.uint8, 3, "argmax")
+    assert maxprob.shape == argmax.shape
+    B = maxprob.shape[0]
+    HW = maxprob.shape[1] * maxprob.shape[2]
+    dev = maxprob.device
+    if thr_up is not None:
+        _req(thr_up, torch.float32, 1, "thr_up")
+        assert thr_up.numel() == C
+    plbl = torch.empty_like(argmax)
+    if count is None:
+        count = torch.zeros((B, C), dtype=torch.int64, device=dev)
+    if sumprob_fx is None:
+        sumprob_fx = torch.zeros((C,), dtype=torch.int64, device=dev)
+    _req(count, torch.int64, 2, "count")
+    _req(sumprob_fx, torch.int64, 1, "sumprob_fx")
+    assert tuple(count.shape) == (B, C) and sumprob_fx.numel() == C
+    if B and HW:
+        check(_lib.load().hiast_plabel_pass2(_ptr(maxprob), _ptr(argmax), _ptr(thr_up), B, C, HW, _ptr(plbl),
+                                             _ptr(count), _ptr(sumprob_fx), _stream()), "hiast_plabel_pass2")
+    return plbl, count, sumprob_fx
+
+
+# ------------------------------------------------------------------------------- K5-K8 loss
+REGION = {"ignored": 0, "confident": 1, "all": 2}
+
+
+def _loss_args(logits_lr, teacher_lr, plbl, H, W):
+    _req(logits_lr, torch.float32, 4, "logits_lr")
+    B, C, h, w = logits_lr.shape
+    if teacher_lr is not None:
+        _req(teacher_lr, torch.float32, 4, "teacher_lr")
+        assert teacher_lr.shape == logits_lr.shape
+    if plbl.dtype not in (torch.uint8, torch.int64):
+        raise TypeError("plbl must be uint8 or int64")
+    _req(plbl, plbl.dtype, 3, "plbl")
+    assert tuple(plbl.shape) == (B, H, W), (tuple(plbl.shape), (B, H, W))
+    return B, C, h, w
+
+
+def st_loss_workspace(B, C, h, w, H, W, device):
+    n = _lib.load().hiast_st_loss_workspace_bytes(B, C, h, w, H, W)
+    if n == 0:
+        raise _lib.HiastLibraryError("hiast_st_loss: unsupported upsampling geometry %s -> %s" % ((h, w), (H, W)))
+    return torch.empty((n + 7) // 8, dtype=torch.float64, device=device)
+
+
+def st_loss_fwd(logits_lr, teacher_lr, plbl, H, W, region, workspace=None):
+    """-> sums f64 [8] (device), see include/hiast_hip.h"""
+    B, C, h, w = _loss_args(logits_lr, teacher_lr, plbl, H, W)
+    ws = workspace if workspace is not None else st_loss_workspace(B, C, h, w, H, W, logits_lr.device)
+    sums = torch.empty(8, dtype=torch.float64, device=logits_lr.device)
+    check(_lib.load().hiast_st_loss_fwd(_ptr(logits_lr), _ptr(teacher_lr), _ptr(plbl),
+                                        int(plbl.dtype == torch.int64), B, C, h, w, H, W, REGION[region],
+                                        _ptr(sums), _ptr(ws), ws.numel() * 8, _stream()), "hiast_st_loss_fwd")
+    return sums
+
+
+def st_loss_bwd(logits_lr, teacher_lr, plbl, H, W, region, sums, coef, workspace=None):
+    B, C, h, w = _loss_args(logits_lr, teacher_lr, plbl, H, W)
+    _req(sums, torch.float64, 1, "sums")
+    _req(coef, torch.float32, 1, "coef")
+    assert sums.numel() == 8 and coef.numel() == 4
+    ws = workspace if workspace is not None else st_loss_workspace(B, C, h, w, H, W, logits_lr.device)
+    d = torch.empty_like(logits_lr)
+    check(_lib.load().hiast_st_loss_bwd(_ptr(logits_lr), _ptr(teacher_lr), _ptr(plbl),
+                                        int(plbl.dtype == torch.int64), B, C, h, w, H, W, REGION[region],
+                                        _ptr(sums), _ptr(coef), _ptr(d), _ptr(ws), ws.numel() * 8, _stream()),
+          "hiast_st_loss_bwd")
+    return d
+
+
+# ------------------------------------------------------------------------------- K1 ASPP
+def _dil(dil):
+    assert len(dil) == 4
+    return (ctypes.c_int * 4)(*[int(d) for d in dil])
+
+
+def aspp_pack_weights(weights, biases):
+    assert len(weights) == 4 and len(biases) == 4
+    Cout, Cin = weights[0].shape[:2]
+    for wt, b in zip(weights, biases):
+        _req(wt, torch.float32, 4, "aspp weight")
+        _req(b, torch.float32, 1, "aspp bias")
+        assert tuple(wt.shape) == (Cout, Cin, 3, 3) and b.numel() == Cout
+    lib = _lib.load()
+    n = lib.hiast_aspp_wpack_bytes(Cin, Cout)
+    wpack = torch.empty(n // 4, dtype=torch.float32, device=weights[0].device)
+    check(lib.hiast_aspp_pack_weights(*[_ptr(t) for t in weights], *[_ptr(t) for t in biases], Cin, Cout,
+                                      _ptr(wpack), _stream()), "hiast_aspp_pack_weights")
+    return wpack
+
+
+def aspp_workspace(B, Cin, h, w, Cout, device):
+    n = _lib.load().hiast_aspp_workspace_bytes(B, Cin, h, w, Cout)
+    return torch.empty((n + 3) // 4, dtype=torch.float32, device=device)
+
+
+def aspp_fwd(x, wpack, Cout, dil, workspace=None):
+    _req(x, torch.float32, 4, "x")
+    _req(wpack, torch.float32, 1, "wpack")
+    B, Cin, h, w = x.shape
+    lib = _lib.load()
+    assert wpack.numel() * 4 == lib.hiast_aspp_wpack_bytes(Cin, Cout), "wpack does not match (Cin, Cout)"
+    ws = workspace if workspace is not None else aspp_workspace(B, Cin, h, w, Cout, x.device)
+    y = torch.empty((B, Cout, h, w), dtype=torch.float32, device=x.device)
+    check(lib.hiast_aspp_fwd(_ptr(x), _ptr(wpack), _ptr(y), B, Cin, h, w, Cout, _dil(dil), _ptr(ws),
+                             ws.numel() * 4, _stream()), "hiast_aspp_fwd")
+    return y
+
+
+def aspp_bwd_data(dy, wpack, Cin, dil):
+    _req(dy, torch.float32, 4, "dy")
+    _req(wpack, torch.float32, 1, "wpack")
+    B, Cout, h, w = dy.shape
+    lib = _lib.load()
+    assert wpack.numel() * 4 == lib.hiast_aspp_wpack_bytes(Cin, Cout)
+    dx = torch.empty((B, Cin, h, w), dtype=torch.float32, device=dy.device)
+    check(lib.hiast_aspp_bwd_data(_ptr(dy), _ptr(wpack), _ptr(dx), B, Cin, h, w, Cout, _dil(dil), _stream()),
+          "hiast_aspp_bwd_data")
+    return dx
+
+
+def aspp_bwd_weight(x, dy, dil, workspace=None):
+    _req(x, torch.float32, 4, "x")
+    _req(dy, torch.float32, 4, "dy")
+    B, Cin, h, w = x.shape
+    Cout = dy.shape[1]
+    assert tuple(dy.shape) == (B, Cout, h, w)
+    lib = _lib.load()
+    ws = workspace if workspace is not None else aspp_workspace(B, Cin, h, w, Cout, x.device)
+    dws = [torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=x.device) for _ in range(4)]
+    db = torch.empty((Cout,), dtype=torch.float32, device=x.device)
+    check(lib.hiast_aspp_bwd_weight(_ptr(x), _ptr(dy), *[_ptr(t) for t in dws], _ptr(db), B, Cin, h, w, Cout,
+                                    _dil(dil), _ptr(ws), ws.numel() * 4, _stream()), "hiast_aspp_bwd_weight")
+    return dws, db
+
+
+# ------------------------------------------------------------------------------- K11 EMA
+class EmaPlan:
+    """Device tables for one (ema parameters, student parameters) pairing; built once."""
+    CHUNK = 65536
+
+    def __init__(self, ema_tensors, src_tensors):
+        assert len(ema_tensors) == len(src_tensors) and len(ema_tensors) > 0
+        dev = ema_tensors[0].device
+        recs = np.zeros((len(ema_tensors), 3), dtype=np.int64)
+        ct, cs = [], []
+        for i, (e, p) in enumerate(zip(ema_tensors, src_tensors)):
+            _req(e, torch.float32, None, "ema tensor")
+            _req(p, torch.float32, None, "student tensor")
+            assert e.numel() == p.numel()
+            recs[i] = (e.data_ptr(), p.data_ptr(), e.numel())
+            for s in range(0, e.numel(), self.CHUNK):
+                ct.append(i)
+                cs.append(s)
+        self.keep = (list(ema_tensors), list(src_tensors))
+        self.table = torch.from_numpy(recs).to(dev)
+        self.chunk_tensor = torch.tensor(ct, dtype=torch.int32, device=dev)
+        self.chunk_start = torch.tensor(cs, dtype=torch.int64, device=dev)
+        self.n_chunks = len(ct)
+        self.ptrs = recs[:, :2].copy()
+
+    def still_valid(self):
+        return all(e.data_ptr() == a and p.data_ptr() == b
+                   for (e, p, (a, b)) in zip(self.keep[0], self.keep[1], self.ptrs))
+
+
+def ema_update(plan, gamma):
+    """ema = ema*gamma + p*(1-gamma), the scalars rounded to float32 as torch's tensor*float does"""
+    check(_lib.load().hiast_ema_update(_ptr(plan.table), _ptr(plan.chunk_tensor), _ptr(plan.chunk_start),
+                                       plan.n_chunks, float(np.float32(gamma)), float(np.float32(1 - gamma)),
+                                       _stream()), "hiast_ema_update")
+
+
+# ------------------------------------------------------------------------------- K12 IoU
+def confusion_hist(pred, target, K, inter=None, area_pred=None, area_tgt=None):
+    _req(pred, torch.int64, None, "pred")
+    _req(target, torch.int64, None, "target")
+    assert pred.shape == target.shape
+    dev = pred.device
+    if inter is None:
+        inter = torch.zeros(K, dtype=torch.int64, device=dev)
+        area_pred = torch.zeros(K, dtype=torch.int64, device=dev)
+        area_tgt = torch.zeros(K, dtype=torch.int64, device=dev)
+    if pred.numel():
+        check(_lib.load().hiast_confusion_hist(_ptr(pred), _ptr(target), pred.numel(), K, _ptr(inter),
+                                               _ptr(area_pred), _ptr(area_tgt), _stream()),
+              "hiast_confusion_hist")
+    return inter, area_pred, area_tgt

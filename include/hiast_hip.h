@@ -109,25 +109,28 @@ int hiast_st_loss_bwd(const float* logits_lr, const float* teacher_lr, const voi
 /* ---- K1: ASPP head, 4 dilated 3x3 convs summed --------------------------------------
  * ASPP_V2.forward, sseg/models/modules/seg_models/deeplab_v2.py:20-24 (+ autograd):
  *   y = Σ_{i<4} conv3x3(x; W_i, b_i, dilation=dil[i], padding=dil[i]).
- * x [B,Cin,h,w]; W_i [Cout,Cin,3,3]; b_i [Cout]; y [B,Cout,h,w]; Cin % 64 == 0,
- * Cout <= 32.  wpack: hiast_aspp_wpack_bytes() scratch holding the repacked weights
- * (written by hiast_aspp_pack_weights, read by fwd / bwd_data).
- * dil: host int[4]. */
+ * x [B,Cin,h,w]; W_i [Cout,Cin,3,3]; b_i [Cout]; y [B,Cout,h,w]; Cin % 64 == 0, Cout <= 32.
+ * The 36 taps collapse to 33 (the 4 centre taps share one input pixel and are pre-summed).
+ * wpack: hiast_aspp_wpack_bytes() scratch written by hiast_aspp_pack_weights (repacked
+ * [33][Cin][32] weights + summed bias) and read by fwd / bwd_data; dil: host int[4].
+ * workspace: hiast_aspp_workspace_bytes() scratch (split-K partial sums, fixed-order reduce:
+ * results are bitwise reproducible; no float atomics). */
 size_t hiast_aspp_wpack_bytes(int Cin, int Cout);
+size_t hiast_aspp_workspace_bytes(int B, int Cin, int h, int w, int Cout);
 int hiast_aspp_pack_weights(const float* w0, const float* w1, const float* w2, const float* w3,
+                            const float* b0, const float* b1, const float* b2, const float* b3,
                             int Cin, int Cout, float* wpack, hiast_stream_t stream);
-int hiast_aspp_fwd(const float* x, const float* wpack, const float* b0, const float* b1,
-                   const float* b2, const float* b3, float* y, int B, int Cin, int h, int w,
-                   int Cout, const int* dil, hiast_stream_t stream);
+int hiast_aspp_fwd(const float* x, const float* wpack, float* y, int B, int Cin, int h, int w,
+                   int Cout, const int* dil, void* workspace, size_t workspace_bytes,
+                   hiast_stream_t stream);
 /* dx [B,Cin,h,w] overwritten */
 int hiast_aspp_bwd_data(const float* dy, const float* wpack, float* dx, int B, int Cin, int h,
                         int w, int Cout, const int* dil, hiast_stream_t stream);
-/* dW_i [Cout,Cin,3,3], db_i [Cout] overwritten (i<4) */
+/* dW_i [Cout,Cin,3,3] and db [Cout] (the same bias gradient for every branch) overwritten */
 int hiast_aspp_bwd_weight(const float* x, const float* dy, float* dw0, float* dw1, float* dw2,
                           float* dw3, float* db, int B, int Cin, int h, int w, int Cout,
                           const int* dil, void* workspace, size_t workspace_bytes,
                           hiast_stream_t stream);
-size_t hiast_aspp_bwd_weight_workspace_bytes(int B, int Cin, int h, int w, int Cout);
 
 /* ---- K11: EMA teacher update ---------------------------------------------------------
  * utils/utils.py:115-123 update_ema_model: ema = ema*gamma + p*(1-gamma) over a list of

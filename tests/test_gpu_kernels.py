@@ -1,0 +1,280 @@
+"""Parity of the HIP kernels (through the C ABI, via hiast_amd.kernels) against the CPU oracle.
+Integer/byte outputs: bit-exact.  Floating point: tolerance stated per test."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from oracle import cref, ias_ref, losses_ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def K():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from hiast_amd import kernels
+    return kernels
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+SHAPES = [(2, 19, 8, 16, 64, 128), (1, 19, 9, 17, 65, 129), (1, 9, 6, 6, 48, 48), (2, 19, 64, 128, 512, 1024),
+          (1, 19, 5, 7, 5, 7), (1, 2, 3, 4, 100, 301), (1, 16, 33, 65, 257, 513)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_upsample_fwd_bit_exact(K, shape):
+    B, C, h, w, H, W = shape
+    x = synth.normal_f32(11, (B, C, h, w), 2.0)
+    got = K.upsample_bilinear_ac_fwd(dev(x), H, W).cpu().numpy()
+    want = cref.upsample_bilinear_ac(x, H, W)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("shape", SHAPES[:3] + SHAPES[4:6])
+def test_upsample_bwd(K, shape):
+    B, C, h, w, H, W = shape
+    g = synth.normal_f32(12, (B, C, H, W))
+    got = K.upsample_bilinear_ac_bwd(dev(g), h, w).cpu().numpy()
+    want = cref.upsample_bilinear_ac_bwd(g, h, w)          # double accumulation
+    assert np.allclose(got, want, rtol=1e-5, atol=1e-5)
+
+
+def test_upsample_golden(K, golden):
+    g = golden("upsample")
+    for tag in "abc":
+        B, C, h, w, H, W = [int(v) for v in g["shape_" + tag]]
+        x = synth.normal_f32(100 + ord(tag), (B, C, h, w), 2.0)
+        y = K.upsample_bilinear_ac_fwd(dev(x), H, W).cpu().numpy()
+        assert np.abs(y - g["y_" + tag]).max() <= 2e-6 * np.abs(x).max()
+        go = synth.normal_f32(200 + ord(tag), (B, C, H, W))
+        gin = K.upsample_bilinear_ac_bwd(dev(go), h, w).cpu().numpy()
+        assert np.allclose(gin, g["gin_" + tag], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("sigma", [3.0, 8.0])
+def test_plabel_pass1_bit_exact(K, shape, sigma):
+    B, C, h, w, H, W = shape
+    z = synth.logits_lr(21, B, C, h, w, sigma)
+    if C > 5:
+        z[:, 1, : h // 2] = z[:, 0, : h // 2]     # ties: lower index must win
+    mp, am, hist = K.plabel_pass1(dev(z), H, W)
+    mp_o, am_o = cref.plabel_stage_a(z, H, W)
+    assert np.array_equal(am.cpu().numpy(), am_o)
+    assert np.array_equal(mp.cpu().numpy().view(np.uint32), mp_o.view(np.uint32))
+    hist_o = cref.plabel_hist(mp_o, am_o, C)
+    assert np.array_equal(hist.cpu().numpy().view(np.uint32), hist_o)
+    assert int(hist_o.sum()) == B * H * W
+
+
+def test_plabel_pass1_golden(K, golden):
+    g = golden("stage_a")
+    for tag in "abc":
+        B, C, h, w, H, W = [int(v) for v in g["shape_" + tag]]
+        z = synth.logits_lr(300 + ord(tag), B, C, h, w, float(g["sigma_" + tag]))
+        if tag == "c":
+            z[:, 1] = z[:, 0]
+            z[:, 5] = z[:, 0]
+        mp, am, _ = K.plabel_pass1(dev(z), H, W)
+        assert np.array_equal(am.cpu().numpy(), g["argmax_" + tag])     # bit-exact argmax map
+        assert np.allclose(mp.cpu().numpy(), g["maxprob_" + tag], rtol=4e-6, atol=0)
+
+
+@pytest.mark.parametrize("hw", [(64, 128), (65, 129), (512, 1024), (7, 3)])
+@pytest.mark.parametrize("with_thr", [True, False])
+def test_plabel_pass2_bit_exact(K, hw, with_thr):
+    H, W = hw
+    C, B = 19, 3
+    p, l = synth.probs_and_labels(31, B, H, W, C)
+    thr = np.linspace(0.4, 0.97, C) if with_thr else None
+    thr_up = None
+    if with_thr:
+        t32 = thr.astype(np.float32)
+        t32 = np.where(t32.astype(np.float64) < thr, np.nextafter(t32, np.float32(np.inf)), t32)
+        thr_up = dev(t32.astype(np.float32))
+    plbl, count, sfx = K.plabel_pass2(dev(p), dev(l.astype(np.uint8)), thr_up, C)
+    plbl_o, count_o, sfx_o = cref.plabel_select(p, l.astype(np.uint8), thr, C)
+    assert np.array_equal(plbl.cpu().numpy(), plbl_o)
+    assert np.array_equal(count.cpu().numpy(), count_o)
+    assert np.array_equal(sfx.cpu().numpy().view(np.uint64), sfx_o)
+
+
+def _loss_inputs(seed, B, C, h, w, H, W, p_ignore, dtype):
+    z = synth.logits_lr(seed, B, C, h, w, 2.5)
+    zt = synth.logits_lr(seed + 1, B, C, h, w, 2.5)
+    plbl = synth.pseudo_labels(seed + 2, B, H, W, C, p_ignore, dtype)
+    return z, zt, plbl
+
+
+@pytest.mark.parametrize("region", ["ignored", "confident", "all"])
+@pytest.mark.parametrize("shape", [(2, 19, 5, 9, 33, 65), (2, 19, 16, 32, 128, 256), (1, 9, 7, 7, 50, 50)])
+@pytest.mark.parametrize("ldt", [np.uint8, np.int64])
+def test_st_loss_fwd_bwd(K, region, shape, ldt):
+    """4 sums + 3 counts and the gradient vs the torch-CPU oracle in float64; counts exact,
+    sums 2e-5 rel, gradient 1e-4 rel of its max."""
+    B, C, h, w, H, W = shape
+    z, zt, plbl = _loss_inputs(700, B, C, h, w, H, W, 0.4, ldt)
+    sums = K.st_loss_fwd(dev(z), dev(zt), dev(plbl), H, W, region)
+    zl = torch.from_numpy(z).requires_grad_(True)
+    pl = torch.from_numpy(plbl.astype(np.int64))
+    s = losses_ref.st_loss_sums(zl, torch.from_numpy(zt), pl, (H, W), region)
+    got = sums.cpu().numpy()
+    want = np.array([s[k].item() for k in ("ce", "kld", "ent", "cst", "n_conf", "n_ign", "cst_cnt")])
+    assert np.array_equal(got[4:7], want[4:7])
+    assert np.allclose(got[:4], want[:4], rtol=2e-5)
+    # gradient of  1.0*CE + 0.1*KLD + 1.0*ENT + 0.5*CST  with upstream grads (2, 3, 0.5, 1)
+    L = losses_ref.st_losses(zl, torch.from_numpy(zt), pl, (H, W), region)
+    up = [2.0, 3.0, 0.5, 1.0]
+    names = ['target_seg_loss', 'kld_confident_loss', 'ent_ignored_loss', 'cst_loss']
+    sum(u * L[n] for u, n in zip(up, names)).backward()
+    coef = torch.tensor([up[0] * 1.0, up[1] * 0.1, up[2] * 1.0, up[3] * 0.5], dtype=torch.float32).cuda()
+    d = K.st_loss_bwd(dev(z), dev(zt), dev(plbl), H, W, region, sums, coef).cpu().numpy()
+    gref = zl.grad.numpy()
+    assert np.abs(d - gref).max() <= 1e-4 * np.abs(gref).max()
+
+
+def test_st_loss_golden_reference(K, golden):
+    """against the reference's own compute_loss outputs (tests/golden/losses.npz)"""
+    g = golden("losses")
+    B, C, h, w, H, W = [int(v) for v in g["shape"]]
+    for tag in ["mix", "conf", "all", "allign", "noign", "zeroq"]:
+        cs = json.loads(str(g["cfg_" + tag]))
+        z, zt, plbl = _loss_inputs(cs["seed"], B, C, h, w, H, W, cs["p_ignore"], np.int64)
+        if tag == "zeroq":
+            zt[:, 3] = -150.0
+        sums = K.st_loss_fwd(dev(z), dev(zt), dev(plbl), H, W, cs["region"]).cpu().numpy()
+        with np.errstate(invalid="ignore", divide="ignore"):
+            vals = np.array([1.0 * sums[0] / sums[4], 0.1 * sums[1] / (C * sums[4]),
+                             1.0 * sums[2] / (C * sums[5]), 0.5 * sums[3] / sums[6]])
+        want = g["vals_" + tag]
+        assert np.array_equal(np.isnan(vals), np.isnan(want)), tag
+        ok = ~np.isnan(want)
+        assert np.allclose(vals[ok], want[ok], rtol=2e-5), tag
+        coef = torch.tensor([1.0 if ok[0] else 0, 0.1 if ok[1] else 0, 1.0 if ok[2] else 0, 0.5 if ok[3] else 0],
+                            dtype=torch.float32).cuda()
+        d = K.st_loss_bwd(dev(z), dev(zt), dev(plbl), H, W, cs["region"], dev(sums), coef).cpu().numpy()
+        gr = g["grad_" + tag]
+        assert np.abs(d - gr).max() <= 2e-4 * max(np.abs(gr).max(), 1e-12), tag
+
+
+def test_st_loss_no_teacher(K):
+    B, C, h, w, H, W = 2, 19, 8, 16, 64, 128
+    z, _, plbl = _loss_inputs(900, B, C, h, w, H, W, 0.4, np.uint8)
+    sums = K.st_loss_fwd(dev(z), None, dev(plbl), H, W, "ignored").cpu().numpy()
+    s = losses_ref.st_loss_sums(torch.from_numpy(z), None, torch.from_numpy(plbl.astype(np.int64)), (H, W))
+    assert np.allclose(sums[:3], [s["ce"].item(), s["kld"].item(), s["ent"].item()], rtol=2e-5)
+    assert sums[3] == 0 and sums[6] == 0
+
+
+def test_st_loss_deterministic(K):
+    B, C, h, w, H, W = 2, 19, 16, 32, 128, 256
+    z, zt, plbl = _loss_inputs(910, B, C, h, w, H, W, 0.4, np.uint8)
+    a, b, c = dev(z), dev(zt), dev(plbl)
+    coef = torch.tensor([1, .1, 1, .5], dtype=torch.float32).cuda()
+    s1 = K.st_loss_fwd(a, b, c, H, W, "ignored")
+    d1 = K.st_loss_bwd(a, b, c, H, W, "ignored", s1, coef)
+    for _ in range(3):
+        s2 = K.st_loss_fwd(a, b, c, H, W, "ignored")
+        d2 = K.st_loss_bwd(a, b, c, H, W, "ignored", s2, coef)
+        assert torch.equal(s1, s2) and torch.equal(d1, d2)
+
+
+ASPP_SHAPES = [(1, 64, 9, 17, 19), (2, 128, 16, 32, 19), (1, 2048, 9, 17, 19), (3, 256, 30, 41, 9)]
+
+
+def _aspp_inputs(seed, B, Cin, h, w, C):
+    x = synth.normal_f32(seed, (B, Cin, h, w), 1.0)
+    ws = [synth.normal_f32(seed + 1 + i, (C, Cin, 3, 3), 0.05) for i in range(4)]
+    bs = [synth.normal_f32(seed + 11 + i, (C,), 0.1) for i in range(4)]
+    return x, ws, bs
+
+
+@pytest.mark.parametrize("shape", ASPP_SHAPES)
+@pytest.mark.parametrize("dil", [(6, 12, 18, 24), (1, 2, 3, 5)])
+def test_aspp_fwd(K, shape, dil):
+    """fp32 MFMA vs the C oracle (double accumulation): |err| <= 1e-5 * Σ|w x| scale."""
+    B, Cin, h, w, C = shape
+    x, ws, bs = _aspp_inputs(40, B, Cin, h, w, C)
+    wpack = K.aspp_pack_weights([dev(t) for t in ws], [dev(t) for t in bs])
+    y = K.aspp_fwd(dev(x), wpack, C, dil).cpu().numpy()
+    want = cref.aspp_fwd(x, ws, bs, dil)
+    assert np.abs(y - want).max() <= 2e-5 * max(1.0, np.abs(want).max())
+
+
+def test_aspp_fwd_golden(K, golden):
+    g = golden("aspp")
+    _, Cin, h, w, C = [int(v) for v in g["shape"]]
+    x = synth.normal_f32(800, (1, Cin, h, w), 1.0)
+    ws = [synth.normal_f32(810 + i, (C, Cin, 3, 3), 0.01) for i in range(4)]
+    bs = [synth.normal_f32(820 + i, (C,), 0.1) for i in range(4)]
+    wpack = K.aspp_pack_weights([dev(t) for t in ws], [dev(t) for t in bs])
+    y = K.aspp_fwd(dev(x), wpack, C, (6, 12, 18, 24))
+    assert np.allclose(y.cpu().numpy(), g["y"], rtol=1e-4, atol=1e-5)       # logits <= 1e-3 rel contract
+    gy = synth.normal_f32(830, (1, C, h, w))
+    dx = K.aspp_bwd_data(dev(gy), wpack, Cin, (6, 12, 18, 24)).cpu().numpy() if Cin % 256 == 0 else None
+    assert np.allclose(dx[:, ::61], g["dx_sub"], rtol=1e-4, atol=1e-6)
+    assert abs(dx.astype(np.float64).sum() - float(g["dx_sum"])) <= 1e-3 * np.abs(dx).sum() ** 0.5 + 1e-3
+    dws, db = K.aspp_bwd_weight(dev(x), dev(gy), (6, 12, 18, 24))
+    dws = np.stack([t.cpu().numpy() for t in dws])
+    assert np.allclose(dws[:, :, ::97], g["dw_sub"], rtol=1e-4, atol=1e-5)
+    assert np.allclose(db.cpu().numpy(), g["db"][0], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("shape", [(2, 256, 16, 32, 19), (1, 512, 9, 17, 19), (2, 256, 20, 70, 9)])
+def test_aspp_bwd_vs_torch(K, shape):
+    """dgrad / wgrad vs autograd of torch-CPU float64 convs (the oracle for a float kernel)."""
+    B, Cin, h, w, C = shape
+    dil = (6, 12, 18, 24)
+    x, ws, bs = _aspp_inputs(50, B, Cin, h, w, C)
+    gy = synth.normal_f32(60, (B, C, h, w))
+    xt = torch.from_numpy(x).double().requires_grad_(True)
+    wt = [torch.from_numpy(t).double().requires_grad_(True) for t in ws]
+    bt = [torch.from_numpy(t).double().requires_grad_(True) for t in bs]
+    y = sum(torch.nn.functional.conv2d(xt, wt[i], bt[i], 1, dil[i], dil[i]) for i in range(4))
+    y.backward(torch.from_numpy(gy).double())
+    wpack = K.aspp_pack_weights([dev(t) for t in ws], [dev(t) for t in bs])
+    dx = K.aspp_bwd_data(dev(gy), wpack, Cin, dil).cpu().numpy()
+    assert np.abs(dx - xt.grad.numpy()).max() <= 2e-5 * np.abs(xt.grad.numpy()).max()
+    dws, db = K.aspp_bwd_weight(dev(x), dev(gy), dil)
+    for i in range(4):
+        ref = wt[i].grad.numpy()
+        assert np.abs(dws[i].cpu().numpy() - ref).max() <= 2e-5 * np.abs(ref).max(), i
+    assert np.allclose(db.cpu().numpy(), bt[0].grad.numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_ema_bit_exact(K):
+    shapes = [(7, 5), (70001,), (3, 2, 3, 3), (64, 2048, 1, 1)]
+    e = [synth.normal_f32(70 + i, s) for i, s in enumerate(shapes)]
+    p = [synth.normal_f32(80 + i, s) for i, s in enumerate(shapes)]
+    et = [dev(a) for a in e]
+    pt = [dev(a) for a in p]
+    plan = K.EmaPlan(et, pt)
+    for _ in range(2):
+        K.ema_update(plan, 0.999)
+        for a, b in zip(e, p):
+            cref.ema_update(a.reshape(-1), b.reshape(-1), 0.999)
+    for a, t in zip(e, et):
+        assert np.array_equal(a.view(np.uint32), t.cpu().numpy().view(np.uint32))
+
+
+def test_confusion_hist_exact(K):
+    g = synth.rng(90)
+    pred = g.integers(0, 19, size=(2, 300, 400), dtype=np.int64)
+    tgt = g.integers(0, 19, size=(2, 300, 400), dtype=np.int64)
+    tgt[g.random((2, 300, 400)) < 0.2] = 255
+    i, ap, at = K.confusion_hist(dev(pred), dev(tgt), 19)
+    io, apo, ato = cref.confusion_hist(pred, tgt, 19)
+    assert np.array_equal(i.cpu().numpy(), io) and np.array_equal(ap.cpu().numpy(), apo)
+    assert np.array_equal(at.cpu().numpy(), ato)
+
+
+def test_no_cpu_fallback(K):
+    from hiast_amd._lib import HiastLibraryError
+    with pytest.raises(HiastLibraryError):
+        K.upsample_bilinear_ac_fwd(torch.zeros(1, 1, 2, 2), 4, 4)
