@@ -1,0 +1,316 @@
+"""bench.py — HIAST self-training hot path on N MI355X of one node.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: under torch.distributed.run)
+
+One STEP = one pass of the hot path over one batch of B synthetic 1024x512 (W x H) images per GPU,
+resident in HBM before the timed region:
+  A. pseudo-label pass  (BASELINE configs[1]): eval forward in fp32 -> fused upsample/softmax/argmax/
+     histogram kernel -> (N>1: RCCL all-reduce of the 19x15361 histogram) -> IAS thresholds -> select kernel
+     -> (N>1: all-reduce of the class sums);
+  B. self-training step (BASELINE configs[2], HIAST setting): EMA-teacher forward (no grad) + student
+     forward/backward under bf16 autocast (the reference trains under apex O1), fused 4-term
+     region-adaptive loss on the labels of A, Adam step (N>1: DDP/RCCL gradient all-reduce overlapped with
+     backward, SyncBN), EMA update.
+value = N * B * K / max-over-ranks(time of K steps)  [images/s].
+
+Prints ONE JSON line (contract in the task statement) with `roofline` (dominant hand-written kernel,
+timed live with HIP events on the launch stream) and `cpu_baseline` (the CPU oracle on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+H, W, C = 512, 1024, 19
+ASPP_FLOP_PER_IMG = 2.0 * (H // 8) * (W // 8) * C * 2048 * 36        # 22.95 GFLOP
+PEAK_FP32_MFMA = 157.3                                                # TFLOP/s, MI355X_MICROARCH.md
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=6)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--batch", type=int, default=8, help="images per GPU per step")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-size", type=int, nargs=2, default=[H // 2, W // 2],
+                   help="H W of the CPU-baseline sample image (time is scaled to 512x1024 by the pixel ratio)")
+    p.add_argument("--cpu-threads", type=int, default=32)
+    p.add_argument("--trainer", default="ConsistencySelfTrainingTrainer",
+                   choices=["ConsistencySelfTrainingTrainer", "SelfTrainingTrainer"])
+    return p.parse_args()
+
+
+def make_cfg(world, trainer):
+    from hiast_amd.utils.default_config import get_default_cfg
+    c = get_default_cfg()
+    c.trainer = trainer
+    c.model.type = "SelfTrainingSegmentor"
+    c.model.predictor.kld_loss.weight = 0.1        # configs/sl_1.yaml
+    c.model.predictor.ent_loss.weight = 1.0
+    c.pseudo_policy.type = "IAS"
+    c.pseudo_policy.ias.alpha, c.pseudo_policy.ias.beta, c.pseudo_policy.ias.gamma = 0.5, 0.9, 8.0
+    c.train.lr, c.train.optimizer, c.train.total_iter = 3e-6, "Adam", 8000
+    c.train.gpu_num = world
+    if trainer == "ConsistencySelfTrainingTrainer":  # configs/hiast_setting.yaml
+        c.cst_training.is_enabled = True
+        c.cst_training.cst_loss.weight = 0.5
+        c.cst_training.cst_loss.region = "ignored"
+    return c
+
+
+class AsppTimer:
+    """HIP-event timing of hiast_aspp_fwd launches on torch's current stream (the stream the kernel is
+    enqueued on)."""
+
+    def __init__(self):
+        self.pairs = []
+        self.on = False
+
+    def install(self):
+        from hiast_amd import kernels as K
+        orig = K.aspp_fwd
+        timer = self
+
+        def timed(x, wpack, Cout, dil, workspace=None):
+            if not timer.on:
+                return orig(x, wpack, Cout, dil, workspace)
+            ws = workspace if workspace is not None else K.aspp_workspace(x.shape[0], x.shape[1], x.shape[2],
+                                                                          x.shape[3], Cout, x.device)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            y = orig(x, wpack, Cout, dil, ws)
+            b.record()
+            timer.pairs.append((a, b, x.shape[0]))
+            return y
+        K.aspp_fwd = timed
+
+    def summary(self):
+        if not self.pairs:
+            return None
+        ms = [a.elapsed_time(b) for a, b, _ in self.pairs]
+        imgs = self.pairs[0][2]
+        avg = float(np.mean(ms))
+        return avg, imgs, len(ms)
+
+
+class HotPath:
+    def __init__(self, cfg, device, rank, world, B):
+        from hiast_amd.utils import utils
+        from hiast_amd.utils.registry import register  # noqa: F401
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        from hiast_amd.workflows.trainer.base_trainer import _Bare, autocast_dtype
+        self.cfg, self.device, self.rank, self.world, self.B = cfg, device, rank, world, B
+        utils.seed_everything(cfg.train.random_seed)
+        model = utils.init_model(cfg).to(device)
+        self.opt, _ = utils.init_optimizers(cfg, model)
+        self.sched = utils.init_schedulers(cfg, self.opt)
+        self.amp = autocast_dtype(cfg)
+        self.model = (DDP(model, device_ids=[device.index], gradient_as_bucket_view=True, bucket_cap_mb=32,
+                          broadcast_buffers=False) if world > 1 else _Bare(model))
+        self.teacher = cfg.cst_training.is_enabled
+        if self.teacher:
+            self.ema = utils.init_model(cfg, student_model=self.model).to(device)
+            for p in self.ema.parameters():
+                p.requires_grad = False
+            self.ema_updater = utils.EmaUpdater()
+        # synthetic batch, resident on the device (normalised float images: what Dataset.transform emits)
+        g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+        self.weak = torch.randn(B, 3, H, W, generator=g).to(device)
+        self.strong = (self.weak * 1.05 + 0.02).contiguous() if self.teacher else self.weak
+        self.thr = 0.9 * np.ones(C)
+        self.class_mean_probs = np.zeros(C)
+
+    def _allreduce(self, t):
+        if self.world > 1:
+            dist.all_reduce(t)
+        return t
+
+    def plabel_pass(self):
+        from hiast_amd import kernels as K
+        from hiast_amd.workflows import ias_math
+        net = self.ema if self.teacher else self.model.module     # train.sh generates with the EMA model
+        net.eval()
+        with torch.no_grad():
+            out = net(self.weak, lowres=True)                     # fp32, like the reference generator
+            mp, am, hist = K.plabel_pass1(out["logits_lowres"].contiguous(), H, W)
+            hist = self._allreduce(hist)
+            ias = self.cfg.pseudo_policy.ias
+            _, self.thr = ias_math.ias_update(hist.cpu().numpy().view(np.uint32), self.thr, ias.alpha, ias.beta,
+                                              ias.gamma)
+            thr_up = torch.from_numpy(ias_math.roundup_f32(self.thr)).to(self.device)
+            plbl, count, sfx = K.plabel_pass2(mp, am, thr_up, C)
+            cnt = self._allreduce(count.sum(0))
+            sfx = self._allreduce(sfx)
+        self._stats = (cnt, sfx)
+        return plbl
+
+    def train_step(self, plbl):
+        self.model.train()
+        teacher_lr = None
+        if self.teacher:
+            self.ema.eval()
+            with torch.no_grad(), torch.autocast("cuda", dtype=self.amp, enabled=self.amp is not None):
+                teacher_lr = self.ema(self.weak, lowres=True)["logits_lowres"].float()
+        with torch.autocast("cuda", dtype=self.amp, enabled=self.amp is not None):
+            out = self.model(self.strong, lowres=True)
+        losses = self.model.module.compute_loss_lowres(out["logits_lowres"], plbl, out["size"], teacher_lr)
+        g_loss = sum(torch.mean(v) for v in losses.values())
+        self.opt.zero_grad(set_to_none=True)
+        g_loss.backward()
+        self.opt.step()
+        if self.teacher:
+            self.ema_updater(self.ema, self.model, self.cfg.cst_training.ema_model.gamma)
+        for s in self.sched:
+            s.step()
+        return losses
+
+    def step(self):
+        plbl = self.plabel_pass()
+        return self.train_step(plbl), plbl
+
+
+def cpu_baseline(cfg, size, threads):
+    """The reference's CPU path, restated (oracle/): eval forward + list/np.quantile IAS post-processing +
+    one training step (teacher fwd, student fwd, 4-term loss, backward, Adam) on ONE image."""
+    from oracle import deeplab_ref, ias_ref, losses_ref
+    from hiast_amd.utils.registry.registries import MODEL
+    h, w = size
+    cores = max(1, min(threads, os.cpu_count()))
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    sd = {k: v.detach().clone() for k, v in MODEL[cfg.model.type](cfg).state_dict().items()}
+    x = torch.randn(1, 3, h, w)
+    t0 = time.time()
+    with torch.no_grad():
+        logits, _, _ = deeplab_ref.segmentor_logits(x, sd)
+        pp, lp = torch.softmax(logits, 1).max(1)
+    st = ias_ref.IASState(C, 0.5, 0.9, 8.0)
+    plbl = st.step(pp.numpy(), lp.numpy(), ["a.png"])
+    # reference's per-pixel threshold map (np.apply_along_axis over rows, pseudo_label_generator.py:74)
+    np.apply_along_axis(lambda r: [st.class_threshold[e] for e in r], 1, lp.numpy()[0])
+    t_gen = time.time() - t0
+    t0 = time.time()
+    params = {k: v.requires_grad_(v.dtype.is_floating_point and ".bn" not in k and "downsample.1" not in k)
+              for k, v in sd.items()}
+    with torch.no_grad():
+        zt = deeplab_ref.segmentor_logits(x, sd)[1]
+    _, zs, _ = deeplab_ref.segmentor_logits(x, params, train=True)
+    L = losses_ref.st_losses(zs, zt, torch.from_numpy(plbl.astype(np.int64)), (h, w), "ignored",
+                             dtype=torch.float32)
+    sum(v for v in L.values() if torch.isfinite(v)).backward()
+    opt = torch.optim.Adam([p for p in params.values() if p.requires_grad and p.grad is not None], lr=3e-6,
+                           weight_decay=0.0005)
+    opt.step()
+    t_train = time.time() - t0
+    scale = (H * W) / float(h * w)
+    total = (t_gen + t_train) * scale
+    return {"value": 1.0 / total, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "1 image %dx%d (scaled x%.1f to 1024x512): eval fwd + IAS list/np.quantile post-processing "
+                      "%.1fs, teacher fwd + student fwd/bwd + 4-term loss + Adam %.1fs; torch %d threads"
+                      % (w, h, scale, t_gen, t_train, cores)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world)
+    import __graft_entry__ as ge
+    if rank == 0 and not os.path.exists(os.path.join(ROOT, "hiast_amd", "csrc", "libhiast_hip.so")):
+        ge.build()
+    assert torch.cuda.is_available(), "bench.py needs the MI355X; there is no CPU fallback"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=device)
+    torch.backends.cudnn.benchmark = bool(int(os.environ.get("HIAST_MIOPEN_FIND", "0")))
+
+    cfg = make_cfg(world, args.trainer)
+    hp = HotPath(cfg, device, rank, world, args.batch)
+    timer = AsppTimer()
+    timer.install()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        hp.step()
+    sync()
+
+    def marker():
+        """a uniquely named tiny kernel (hiast::confusion_kernel) that brackets the timed region in a
+        rocprofv3 kernel trace; tools/trace_summary.py keeps only what lies between two markers"""
+        from hiast_amd import kernels as K
+        z = torch.zeros(64, dtype=torch.int64, device=device)
+        K.confusion_hist(z, z, 2)
+        torch.cuda.synchronize()
+    marker()
+    timer.on = True
+    t_pl = t_tr = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        a = time.perf_counter()
+        plbl = hp.plabel_pass()
+        torch.cuda.synchronize()
+        b = time.perf_counter()
+        hp.train_step(plbl)
+        torch.cuda.synchronize()
+        t_pl += b - a
+        t_tr += time.perf_counter() - b
+    sync()
+    elapsed = time.perf_counter() - t0
+    timer.on = False
+    marker()
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        imgs = world * args.batch * args.steps
+        out = {
+            "metric": "self-training images/sec (fwd+bwd+pseudo-label) at 1024x512",
+            "value": imgs / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16 (train fwd/bwd) + f32 (pseudo-label fwd, ASPP, losses)",
+            "data": "synthetic",
+            "config": {"workload": "configs[2] self-training round (%s, region-adaptive reg on) bs=%d/GPU @1024x512 "
+                                   "+ configs[1] IAS pseudo-label pass on the same batch" % (args.trainer, args.batch),
+                       "images_per_gpu_per_step": args.batch, "num_classes": C,
+                       "parallelism": "dp%d" % world if world > 1 else "single"},
+            "phases_ms": {"pseudo_label": 1e3 * t_pl / args.steps, "train_step": 1e3 * t_tr / args.steps},
+        }
+        s = timer.summary()
+        if s is not None:
+            avg_ms, nimg, n = s
+            ach = ASPP_FLOP_PER_IMG * nimg / (avg_ms * 1e-3) / 1e12
+            out["roofline"] = {"kernel": "hiast::aspp_fwd_kernel<2>", "bound": "mfma", "achieved": ach,
+                               "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA,
+                               "traffic": None, "avg_launch_ms": avg_ms, "launches": n,
+                               "note": "fp32 MFMA peak; algorithmic 22.95 GFLOP/img x %d img per launch" % nimg}
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(cfg, tuple(args.cpu_size), args.cpu_threads)
+            except Exception as e:      # the baseline must never take the measurement down
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -14,6 +14,8 @@
 // Loop order is channel-chunk OUTER / tap INNER so the 33 shifted re-reads of a channel plane hit
 // L2 while it is resident.  Split-K over channel ranges fills the chip at small batch; partials
 // are reduced in a fixed order (bitwise reproducible).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace hiast {
@@ -124,36 +126,51 @@ __global__ __launch_bounds__(256) void aspp_fwd_kernel(const float* __restrict__
     }
     __syncthreads();
 
-    for (int it = 0; it < niter; ++it) {
+    // B operand: the 16 k-steps x MT pixel tiles of one (chunk, tap) are fetched as ONE batch of
+    // unconditional loads (addresses of out-of-image lanes are redirected to a valid element and the
+    // value is zeroed by a select afterwards: a conditional load would be lowered to a branch plus
+    // s_waitcnt vmcnt(0) per element), one iteration AHEAD of the MFMAs that consume them.
+    auto tap_setup = [&](int it, const float* (&xp)[MT], bool (&ok)[MT]) {
         const int chunk = it / NTAP, tap = it - chunk * NTAP;
         const int cib = ci0 + chunk * KC;
-        const int buf = it & 1;
-        // prefetch next (chunk, tap) weights into registers
-        float4 nxt = make_float4(0, 0, 0, 0);
-        if (it + 1 < niter) {
-            const int chunk2 = (it + 1) / NTAP, tap2 = (it + 1) - chunk2 * NTAP;
-            nxt = reinterpret_cast<const float4*>(wpack + ((size_t)tap2 * Cin + ci0 + chunk2 * KC) * COP)[threadIdx.x];
-        }
         const int dy = taps.dy[tap], dx = taps.dx[tap];
-        const float* xp[MT];
-        bool ok[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int yy = py[m] + dy, xx = px[m] + dx;
             ok[m] = pix[m] < hw && yy >= 0 && yy < h && xx >= 0 && xx < w;
             xp[m] = xn + (size_t)(cib + ksub) * hw + (ok[m] ? yy * w + xx : 0);
         }
+    };
+    // One batch of KC/2 x MT unconditional loads per (chunk, tap); the MFMAs start as the first
+    // values land (counted vmcnt).  Latency is hidden across the 4-5 waves per SIMD that the register
+    // budget admits (the host picks the split-K factor so that the grid provides them).
+    for (int it = 0; it < niter; ++it) {
+        const int buf = it & 1;
+        const bool more = it + 1 < niter;
+        float4 nxt = make_float4(0, 0, 0, 0);
+        if (more) {
+            const int chunk2 = (it + 1) / NTAP, tap2 = (it + 1) - chunk2 * NTAP;
+            nxt = reinterpret_cast<const float4*>(wpack + ((size_t)tap2 * Cin + ci0 + chunk2 * KC) * COP)[threadIdx.x];
+        }
+        const float* xp[MT];
+        bool ok[MT];
+        tap_setup(it, xp, ok);
+        float bs[MT][KC / 2];
+#pragma unroll
+        for (int ks = 0; ks < KC / 2; ++ks)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) bs[m][ks] = xp[m][(size_t)ks * 2 * hw];
         const float* sw = s_w[buf] + ksub * COP + col;
-#pragma unroll 8
+#pragma unroll
         for (int ks = 0; ks < KC / 2; ++ks) {
             const float a = sw[ks * 2 * COP];
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                const float bv = ok[m] ? xp[m][(size_t)ks * 2 * hw] : 0.f;
+                const float bv = ok[m] ? bs[m][ks] : 0.f;
                 acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[m], 0, 0, 0);
             }
         }
-        if (it + 1 < niter) reinterpret_cast<float4*>(s_w[buf ^ 1])[threadIdx.x] = nxt;
+        if (more) reinterpret_cast<float4*>(s_w[buf ^ 1])[threadIdx.x] = nxt;
         __syncthreads();
     }
     (void)ci1;
@@ -261,9 +278,13 @@ __global__ __launch_bounds__(256) void aspp_bwd_data_kernel(const float* __restr
             const int co = 2 * ks + ksub;
             const float a0 = sa[co * DG_CI];
             const float a1 = sa[co * DG_CI + 32];
+            const int coc = co < Cout ? co : Cout - 1;          // keep the address inside dY
             float b[2];
 #pragma unroll
-            for (int m = 0; m < 2; ++m) b[m] = (ok[m] && co < Cout) ? bp[m][(size_t)co * hw] : 0.f;
+            for (int m = 0; m < 2; ++m) {
+                const float v = bp[m][(size_t)coc * hw];            // unconditional load, select after
+                b[m] = (ok[m] && co < Cout) ? v : 0.f;
+            }
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[m], acc[0][m], 0, 0, 0);
@@ -444,8 +465,15 @@ __global__ __launch_bounds__(256) void aspp_db_kernel(const float* __restrict__ 
 static int pick_splitk(int B, int hw, int Cin, int MT)
 {
     const int blocks = ((hw + 128 * MT - 1) / (128 * MT)) * B;
+    const char* env = getenv("HIAST_ASPP_SPLITK");          // tuning override
+    if (env && atoi(env) > 0) {
+        int s = atoi(env);
+        while (s > 1 && ((Cin / s) % KC != 0 || Cin % s != 0)) s >>= 1;
+        return s > 8 ? 8 : s;
+    }
+    // >= 4 blocks (16 waves) per CU so that other waves' MFMAs cover a wave's load latency
     int s = 1;
-    while (blocks * s < 256 && s < 8 && (Cin / (s * 2)) % KC == 0 && Cin / (s * 2) >= 64) s *= 2;
+    while (blocks * s < 1024 && s < 8 && (Cin / (s * 2)) % KC == 0 && Cin / (s * 2) >= 64) s *= 2;
     return s;
 }
 

@@ -1,0 +1,108 @@
+"""torch.autograd bindings of the HIP kernels (one C-ABI call per forward / backward).
+
+CUDA(HIP) tensors only.  Autocast: inputs are taken in fp32 (the reference's losses and the
+pseudo-label path are fp32 even under apex O1; the ASPP head is computed in exact fp32 MFMA).
+"""
+import torch
+
+from . import kernels as K
+
+ASPP_DILATIONS = (6, 12, 18, 24)
+
+
+class _AsppFn(torch.autograd.Function):
+    """y = Σ_i conv3x3(x; W_i, b_i, dilation=d_i, padding=d_i) — ASPP_V2.forward (deeplab_v2.py:20-24)"""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, w0, w1, w2, w3, b0, b1, b2, b3, dil):
+        x = x.contiguous()
+        ws = [w.contiguous() for w in (w0, w1, w2, w3)]
+        bs = [b.contiguous() for b in (b0, b1, b2, b3)]
+        wpack = K.aspp_pack_weights(ws, bs)
+        Cout = ws[0].shape[0]
+        y = K.aspp_fwd(x, wpack, Cout, dil)
+        ctx.save_for_backward(x, wpack)
+        ctx.dil = dil
+        ctx.cin = x.shape[1]
+        return y
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, gy):
+        x, wpack = ctx.saved_tensors
+        gy = gy.contiguous().float()
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = K.aspp_bwd_data(gy, wpack, ctx.cin, ctx.dil)
+        gws, gb = [None] * 4, None
+        if any(ctx.needs_input_grad[1:9]):
+            gws, gb = K.aspp_bwd_weight(x, gy, ctx.dil)
+        return (gx, gws[0], gws[1], gws[2], gws[3], gb, gb, gb, gb, None)
+
+
+def aspp(x, weights, biases, dil=ASPP_DILATIONS):
+    return _AsppFn.apply(x, *weights, *biases, tuple(dil))
+
+
+class _UpsampleFn(torch.autograd.Function):
+    """F.interpolate(x, size, mode='bilinear', align_corners=True) (self_training_segmentor.py:27)"""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, H, W):
+        ctx.hw = x.shape[2:]
+        return K.upsample_bilinear_ac_fwd(x.contiguous(), H, W)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        return K.upsample_bilinear_ac_bwd(g.contiguous().float(), ctx.hw[0], ctx.hw[1]), None, None
+
+
+def upsample_bilinear_ac(x, size):
+    return _UpsampleFn.apply(x, int(size[0]), int(size[1]))
+
+
+class _StLossFn(torch.autograd.Function):
+    """The four self-training losses from LOW-RES logits in one kernel pass (K5-K8).
+    Returns the raw sums (f64 [8]) as a non-differentiable side output and the four weighted
+    losses; backward is one kernel producing d(low-res logits)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, logits_lr, teacher_lr, plbl, H, W, region, w_t, w_k, w_e, w_c):
+        logits_lr = logits_lr.contiguous()
+        if teacher_lr is not None:
+            teacher_lr = teacher_lr.contiguous()
+        plbl = plbl.contiguous()
+        B, C, h, w = logits_lr.shape
+        ws = K.st_loss_workspace(B, C, h, w, H, W, logits_lr.device)
+        sums = K.st_loss_fwd(logits_lr, teacher_lr, plbl, H, W, region, ws)
+        ctx.save_for_backward(logits_lr, teacher_lr, plbl, sums)
+        ctx.ws = ws
+        ctx.args = (H, W, region, w_t, w_k, w_e, w_c)
+        s = sums.float()      # 0/0 -> NaN exactly like the reference's tensor divisions
+        ce = w_t * s[0] / s[4]
+        kld = w_k * s[1] / (C * s[4])
+        ent = w_e * s[2] / (C * s[5])
+        cst = w_c * s[3] / s[6]
+        ctx.mark_non_differentiable(sums)
+        return ce, kld, ent, cst, sums
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g_ce, g_kld, g_ent, g_cst, _g_sums):
+        logits_lr, teacher_lr, plbl, sums = ctx.saved_tensors
+        H, W, region, w_t, w_k, w_e, w_c = ctx.args
+        coef = torch.stack([g_ce * w_t, g_kld * w_k, g_ent * w_e, g_cst * w_c]).float().contiguous()
+        d = K.st_loss_bwd(logits_lr, teacher_lr, plbl, H, W, region, sums, coef, ctx.ws)
+        return (d,) + (None,) * 9
+
+
+def st_loss(logits_lr, teacher_lr, plbl, size, region="ignored", w_t=1.0, w_k=0.1, w_e=1.0, w_c=0.5):
+    """-> (ce, kld, ent, cst) 0-dim tensors, already multiplied by their weights.
+    `teacher_lr` are the teacher's LOW-RES logits (or None); plbl uint8/int64 [B,H,W]."""
+    ce, kld, ent, cst, _ = _StLossFn.apply(logits_lr, teacher_lr, plbl, int(size[0]), int(size[1]), region,
+                                            float(w_t), float(w_k), float(w_e), float(w_c))
+    return ce, kld, ent, cst

@@ -1,0 +1,80 @@
+"""PREPROCESSOR['CopyPaste'] — HIAST's hard-aware pseudo-label augmentation
+(reference: sseg/datasets/preprocessor.py:12-122).
+
+Hard classes = the `selected_num_classes` classes with the lowest mean confidence (from
+class_mean_probabilities.npy written by the generator); a class is drawn with probability
+∝ (1 - value)^2, one pseudo-labelled image containing it is drawn, and every hard-class pixel of that
+image is pasted (image bytes + label) onto the current sample.  Runs on the host inside DataLoader
+workers on uint8 arrays (byte copies; nothing for a GPU to win).  The np.random call sequence is the
+reference's, so a seeded run reproduces its outputs (tests/golden/copy_paste.npz).
+
+Deviation (documented in DESIGN.md): for SYNTHIA the reference sets the three absent classes'
+value to inf, which turns the sampling probabilities into NaN and makes np.random.choice raise
+(preprocessor.py:18-19,31-40); here those classes get probability 0 instead."""
+import numpy as np
+from PIL import Image
+
+from hiast_amd.utils.registry.registries import PREPROCESSOR
+
+
+@PREPROCESSOR.register("CopyPaste")
+class CopyPaste:
+
+    def __init__(self, cfg, dataset_copy_from, init_class_value):
+        self.cfg = cfg
+        self.dataset_copy_from = dataset_copy_from
+        self.ignored_classes = [9, 14, 16] if cfg.dataset.source.type == "SYNTHIA" else None
+        print("%% Init copy paste with class_value: {}".format(init_class_value))
+        self.class_value, self.hard_classes = self.get_hard_classes(np.array(init_class_value, dtype=np.float64))
+        self.samples_with_class = self.dataset_copy_from.get_samples_with_class()
+        self.class_probs = self.calculate_class_probs()
+
+    def calculate_class_probs(self):
+        v = np.asarray(self.class_value, np.float64)
+        p = np.where(np.isinf(v), 0.0, (1 - np.where(np.isinf(v), 1.0, v)) ** 2)
+        return p / p.sum()
+
+    def get_hard_classes(self, class_value):
+        if self.ignored_classes is not None:
+            for c in self.ignored_classes:
+                class_value[c] = np.inf
+        hard = np.argsort(class_value)[:self.cfg.preprocessor.copy_paste.selected_num_classes]
+        return class_value, hard
+
+    @staticmethod
+    def resize(img, lbl, shape):
+        h, w = shape[0], shape[1]
+        img = np.asarray(Image.fromarray(img).resize((w, h), Image.BILINEAR))
+        lbl = np.asarray(Image.fromarray(lbl).resize((w, h), Image.NEAREST))
+        return img, lbl
+
+    def run(self, img, lbl):
+        if self.cfg.preprocessor.copy_paste.mode != "original":
+            raise NotImplementedError("copy_paste.mode %r" % self.cfg.preprocessor.copy_paste.mode)
+        return self.run_original(img, lbl)
+
+    def random_select(self, selected_classes):
+        ids = [i for i in range(self.cfg.dataset.num_classes)]
+        while True:
+            c = np.random.choice(ids, size=1, replace=False, p=self.class_probs)[0]
+            if c in selected_classes:
+                return c
+
+    def run_original(self, img, lbl):
+        """Returns (img, lbl, copy_paste_mask).  The reference's retry loop (up to 3 source images)
+        always ends after the first paste, because the first pass marks every hard class as
+        present (preprocessor.py:104-118); one paste is therefore the whole behaviour."""
+        mask = np.full(lbl.shape, 255, dtype=np.uint8)
+        c = self.random_select(self.hard_classes)
+        name = np.random.choice(self.samples_with_class[c])
+        img_, lbl_, _ = self.dataset_copy_from.load_data(self.dataset_copy_from.get_file_to_idx(name))
+        if img.shape != img_.shape:
+            img_, lbl_ = self.resize(img_, lbl_, lbl.shape)
+        sel = np.zeros(lbl.shape, dtype=bool)
+        for h in self.hard_classes:
+            hit = lbl_ == h
+            sel[hit] = True
+            mask[hit] = h
+        img[sel] = img_[sel]
+        lbl[sel] = lbl_[sel]
+        return img, lbl, mask

@@ -1,0 +1,52 @@
+"""DeepLab-V2 / ResNet-101 (reference: sseg/models/modules/seg_models/deeplab_v2.py:8-69).
+
+Same sub-module and state-dict names (backbone.*, aspp.conv2d_list.{0..3}.{weight,bias},
+representation.0.{weight,bias}), same forward signature `(prediction, feature)` and LR groups.
+The ASPP head runs as ONE hand-written gfx950 kernel over the four dilations on HIP tensors
+(hiast_aspp_fwd / _bwd_data / _bwd_weight); on CPU tensors (config 1: CPU-only validate) the
+Conv2d holders run as plain torch convs.  `representation` keeps its parameters for checkpoint
+compatibility but is not computed: the reference computes it and drops the result (:63)."""
+import torch.nn as nn
+
+from hiast_amd import functional as HF
+from hiast_amd.sseg.models.modules.resnet import build_resnet101
+from hiast_amd.utils.registry.registries import SEG_MODEL
+
+
+class ASPP_V2(nn.Module):
+
+    def __init__(self, dilation_series, padding_series, num_classes):
+        super().__init__()
+        assert list(dilation_series) == list(padding_series)
+        self.dilations = tuple(int(d) for d in dilation_series)
+        self.conv2d_list = nn.ModuleList(
+            nn.Conv2d(2048, num_classes, 3, stride=1, padding=d, dilation=d, bias=True) for d in self.dilations)
+        for m in self.conv2d_list:
+            m.weight.data.normal_(0, 0.01)      # deeplab_v2.py:17-18
+
+    def forward(self, x):
+        if x.is_cuda:
+            return HF.aspp(x, [m.weight for m in self.conv2d_list], [m.bias for m in self.conv2d_list], self.dilations)
+        out = self.conv2d_list[0](x)
+        for m in self.conv2d_list[1:]:
+            out = out + m(x)
+        return out
+
+
+@SEG_MODEL.register("DeepLab_V2")
+class DeepLab_V2(nn.Module):
+
+    def __init__(self, num_classes=19, output_dim=256):
+        super().__init__()
+        self.backbone = build_resnet101(pretrained=False, output_stride=8)
+        self.aspp = ASPP_V2([6, 12, 18, 24], [6, 12, 18, 24], num_classes)
+        self.representation = nn.Sequential(nn.Conv2d(2048, output_dim, 1))
+
+    def forward(self, x):
+        feat = self.backbone(x)            # [B, 2048, H/8, W/8]
+        return self.aspp(feat), feat       # [B, C, H/8, W/8]
+
+    def get_optimizer_params(self, lr):
+        return [{"params": self.backbone.parameters(), "lr": lr},
+                {"params": self.aspp.parameters(), "lr": lr * 10},
+                {"params": self.representation.parameters(), "lr": lr * 10}]

@@ -1,0 +1,85 @@
+"""MODEL['SelfTrainingSegmentor'] (reference: sseg/models/segmentors/self_training_segmentor.py:9-53).
+
+Reference-compatible surface: `.seg_model`, `forward(t_img) -> {'logits' [B,C,H,W], 'backbone'}`,
+`compute_loss(t_logits, t_plbl, t_cst_lbl=None, s_logits=None, s_lbl=None) -> dict`.
+Fast path used by this package's trainers / generator: `forward(t_img, lowres=True)` returns the
+head's LOW-RES logits and `compute_loss_lowres` consumes them (+ the teacher's low-res logits)
+through one fused kernel, so the 39.8 MB/img full-resolution logits tensor is never built."""
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from hiast_amd import functional as HF
+from hiast_amd.sseg.models.modules.seg_models import build_seg_model
+from hiast_amd.utils.registry.registries import LOSS, MODEL
+
+
+def upsample_logits(logits, size):
+    if logits.is_cuda:
+        return HF.upsample_bilinear_ac(logits, size)
+    return F.interpolate(logits, size=size, mode="bilinear", align_corners=True)   # CPU-only plumbing (config 1)
+
+
+@MODEL.register("SelfTrainingSegmentor")
+class SelfTrainingSegmentor(nn.Module):
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.seg_model = build_seg_model(cfg)
+        self.seg_loss_fun = LOSS[cfg.model.predictor.seg_loss.type]
+        if cfg.cst_training.is_enabled:
+            self.cst_loss_fun = LOSS[cfg.cst_training.cst_loss.type]
+
+    def forward(self, t_img, lowres=False):
+        t_logits, backbone = self.seg_model(t_img)
+        if lowres:
+            return {"logits_lowres": t_logits, "backbone": backbone, "size": tuple(t_img.shape[2:])}
+        return {"logits": upsample_logits(t_logits, t_img.shape[2:]), "backbone": backbone}
+
+    # ---- fused path ---------------------------------------------------------------------------
+    def _weights(self, with_cst):
+        p = self.cfg.model.predictor
+        cst = self.cfg.cst_training
+        if p.seg_loss.type != "CE":
+            raise NotImplementedError("the fused loss implements seg_loss.type == 'CE'")
+        use_cst = with_cst and cst.is_enabled and cst.cst_loss.weight > 0
+        if use_cst and cst.cst_loss.type != "SoftCE":
+            raise NotImplementedError("the fused loss implements cst_loss.type == 'SoftCE'")
+        return (p.seg_loss.target_pseudo_weight, max(p.kld_loss.weight, 0.0), max(p.ent_loss.weight, 0.0),
+                cst.cst_loss.weight if use_cst else 0.0, use_cst)
+
+    def compute_loss_lowres(self, t_logits_lr, t_plbl, size, teacher_logits_lr=None):
+        """Same dict as compute_loss, from low-res student logits and (optionally) the teacher's
+        low-res logits; upsample + teacher softmax are recomputed inside the kernel."""
+        w_t, w_k, w_e, w_c, use_cst = self._weights(teacher_logits_lr is not None)
+        region = self.cfg.cst_training.cst_loss.region
+        ce, kld, ent, cst = HF.st_loss(t_logits_lr, teacher_logits_lr if use_cst else None, t_plbl, size,
+                                       region, w_t, w_k, w_e, w_c)
+        return self._pack(ce, kld, ent, cst, use_cst)
+
+    def _pack(self, ce, kld, ent, cst, use_cst):
+        p = self.cfg.model.predictor
+        losses = {"target_seg_loss": ce}
+        if p.kld_loss.weight > 0:
+            losses["kld_confident_loss"] = kld
+        if p.ent_loss.weight > 0:
+            losses["ent_ignored_loss"] = ent
+        if use_cst:
+            losses["cst_loss"] = cst
+        return losses
+
+    # ---- reference-compatible path ---------------------------------------------------------------
+    def compute_loss(self, t_logits, t_plbl, t_cst_lbl=None, s_logits=None, s_lbl=None):
+        """t_logits full-res [B,C,H,W]; t_cst_lbl = teacher PROBABILITIES [B,C,H,W] (as
+        consistency_self_training_trainer.py:119 builds them)."""
+        losses = {}
+        if s_lbl is not None:
+            losses["source_seg_loss"] = self.seg_loss_fun(s_logits, s_lbl)
+        w_t, w_k, w_e, w_c, use_cst = self._weights(t_cst_lbl is not None)
+        H, W = t_logits.shape[2:]
+        teacher = torch.log(t_cst_lbl) if use_cst else None
+        ce, kld, ent, cst = HF.st_loss(t_logits, teacher, t_plbl, (H, W), self.cfg.cst_training.cst_loss.region,
+                                       w_t, w_k, w_e, w_c)
+        losses.update(self._pack(ce, kld, ent, cst, use_cst))
+        return losses

@@ -1,0 +1,158 @@
+"""Model / optimiser / distributed helpers (reference: utils/utils.py:19-170), without apex:
+torch SyncBatchNorm + DistributedDataParallel over RCCL, torch.autocast instead of amp O1, and the
+EMA teacher update as one multi-tensor HIP launch."""
+import logging
+import os
+import random
+import socket
+import warnings
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from hiast_amd.sseg.models.modules.schedulers import build_scheduler
+from hiast_amd.utils.registry.registries import MODEL
+
+
+def seed_everything(seed=888):
+    random.seed(seed)
+    os.environ["PYTHONHASHSEED"] = str(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed(seed)
+
+
+def create_dir(path):
+    if os.path.exists(path):
+        warnings.warn("%s has existed" % path)
+    else:
+        os.makedirs(path)
+
+
+def is_port_used(port, host="127.0.0.1"):
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.settimeout(1)
+        return s.connect_ex((host, int(port))) == 0
+
+
+def get_device(index=None):
+    if torch.cuda.is_available():
+        return torch.device("cuda", torch.cuda.current_device() if index is None else index)
+    return torch.device("cpu")
+
+
+def freeze_bn(model):
+    """requires_grad=False on every norm layer's affine parameters (utils.py:60-65); the layers
+    still normalise with batch statistics in train() mode, exactly like the reference."""
+    for m in model.modules():
+        if isinstance(m, (nn.BatchNorm2d, nn.GroupNorm, nn.SyncBatchNorm)):
+            for p in m.parameters():
+                p.requires_grad = False
+
+
+def _unwrap(model):
+    return model.module if hasattr(model, "module") else model
+
+
+def load_model(cfg, resume_from=None, student_model=None):
+    """utils.py:68-89: build MODEL[cfg.model.type]; copy a (DDP-wrapped) student, or partially load a
+    checkpoint (keys saved under DDP lose their 7-char 'module.' prefix)."""
+    assert not (resume_from is not None and student_model is not None)
+    model = MODEL[cfg.model.type](cfg)
+    if student_model is not None:
+        model.load_state_dict(_unwrap(student_model).state_dict())
+        print("%% load model from student model")
+    elif resume_from is not None:
+        own = model.state_dict()
+        saved = torch.load(resume_from, map_location="cpu")
+        strip = len("module.") if "module" in next(iter(saved.keys())) else 0
+        own.update({k[strip:]: v for k, v in saved.items() if k[strip:] in own})
+        model.load_state_dict(own)
+        print("%% load model from {}".format(resume_from))
+    else:
+        warnings.warn("not load model")
+    return model
+
+
+def init_model(cfg, resume_from=None, student_model=None):
+    """utils.py:92-112 — SyncBN when more than one GPU takes part, then the BN freeze."""
+    model = load_model(cfg, resume_from=resume_from, student_model=student_model)
+    if cfg.train.gpu_num > 1:
+        model = nn.SyncBatchNorm.convert_sync_batchnorm(model)
+        print("%% convert BN to SyncBN")
+    if cfg.model.is_freeze_bn:
+        freeze_bn(model)
+        print("%% freeze all BN layers")
+    return model
+
+
+class EmaUpdater:
+    """update_ema_model (utils.py:115-123): parameters ema = ema*g + p*(1-g) in one HIP launch,
+    buffers copied (one foreach copy)."""
+
+    def __init__(self):
+        self._plan = None
+
+    def __call__(self, ema_model, model, gamma):
+        from hiast_amd import kernels as K
+        src = _unwrap(model)
+        ep = [p.data for p in ema_model.parameters()]
+        sp = [p.data for p in src.parameters()]
+        if not ep[0].is_cuda:
+            raise RuntimeError("EMA update runs on the HIP device only")
+        if self._plan is None or not self._plan.still_valid() or len(self._plan.keep[0]) != len(ep):
+            self._plan = K.EmaPlan(ep, sp)
+        K.ema_update(self._plan, gamma)
+        eb = [b for b in ema_model.buffers()]
+        sb = [b for b in src.buffers()]
+        if eb:
+            torch._foreach_copy_(eb, sb)
+        return ema_model
+
+
+_default_ema = EmaUpdater()
+
+
+def update_ema_model(ema_model, model, gamma):
+    return _default_ema(ema_model, model, gamma)
+
+
+def init_optimizers(cfg, model):
+    """utils.py:135-154 (generator optimiser only: no discriminator in the self-training stage)"""
+    groups = _unwrap(model).seg_model.get_optimizer_params(cfg.train.lr)
+    groups = [{"params": [p for p in g["params"] if p.requires_grad], "lr": g["lr"]} for g in groups]
+    kind = cfg.train.optimizer
+    if kind == "SGD":
+        opt = torch.optim.SGD(groups, momentum=0.9, weight_decay=0.0005)
+    elif kind == "Adam":
+        opt = torch.optim.Adam(groups, betas=(0.9, 0.999), weight_decay=0.0005)
+    elif kind == "AdamW":
+        opt = torch.optim.AdamW(groups, betas=(0.9, 0.999), weight_decay=0.0005)
+    else:
+        raise ValueError("%s is not a valid optimizer" % kind)
+    if cfg.model.discriminator.is_enabled:
+        raise NotImplementedError("adversarial warm-up (discriminator) is outside the self-training hot path")
+    return opt, None
+
+
+def init_schedulers(cfg, g_optimizer, d_optimizer=None):
+    return [build_scheduler(cfg, o) for o in (g_optimizer, d_optimizer) if o is not None]
+
+
+def all_reduce_average(tensor, world_size):
+    if dist.is_available() and dist.is_initialized() and world_size > 1:
+        dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
+        tensor /= world_size
+    return tensor
+
+
+def init_logger(log_path):
+    logging.basicConfig(format="[%(asctime)s-%(levelname)s]: %(message)s", filename=log_path, filemode="a",
+                        level=logging.INFO)
+    logger = logging.getLogger("UDA.trainer")
+    if not logger.handlers:
+        logger.addHandler(logging.StreamHandler())
+    return logger

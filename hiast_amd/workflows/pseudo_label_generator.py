@@ -1,0 +1,272 @@
+"""PSEUDO_POLICY registry: 'IAS' (instance-adaptive selector), 'CT', 'NT', 'CBST'
+(reference: workflows/pseudo_label_generator.py:14-213).
+
+What changed under the same interface (`PSEUDO_POLICY[type](cfg).run()`, same artefacts on disk):
+  * the model hands over LOW-RES logits; upsample + softmax + max/argmax + the per-class fp16
+    confidence multiset (as a 19 x 15361 integer histogram) is one HIP kernel (pass 1); nothing of
+    size B x C x H x W is built and nothing but the histogram (1.2 MB) and the final uint8 label maps
+    crosses PCIe;
+  * thresholds come from the histogram on the host (hiast_amd/workflows/ias_math.py) — bit-identical
+    to the reference's list + np.quantile formulation;
+  * select / count / Σprob is a second HIP kernel (pass 2);
+  * with torch.distributed initialised, images of a global batch are split over ranks and the
+    histograms / class sums are all-reduced (RCCL): the result equals the single-process run with
+    batch_size = world * local_batch on the same image order.
+"""
+import json
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from PIL import Image
+from torch.utils.data import DataLoader, Sampler
+
+from hiast_amd.utils import utils
+from hiast_amd.utils.registry.registries import DATASET, PSEUDO_POLICY
+from hiast_amd.workflows import ias_math
+
+
+class ShardedBatchSampler(Sampler):
+    """Global batches of `world * batch_size` consecutive positions of a seeded permutation; rank r
+    takes the r-th `batch_size` slice of each (possibly empty at the tail)."""
+
+    def __init__(self, n, batch_size, rank, world, shuffle=True, seed=888):
+        self.n, self.bs, self.rank, self.world = n, batch_size, rank, world
+        if shuffle:
+            g = torch.Generator()
+            g.manual_seed(seed)
+            self.order = torch.randperm(n, generator=g).tolist()
+        else:
+            self.order = list(range(n))
+
+    def __len__(self):
+        gb = self.bs * self.world
+        return (self.n + gb - 1) // gb
+
+    def __iter__(self):
+        gb = self.bs * self.world
+        for s in range(0, self.n, gb):
+            yield self.order[s + self.rank * self.bs: min(s + (self.rank + 1) * self.bs, s + gb, self.n)]
+
+
+class HipPlabelEngine:
+    """Device side of one generator step (the HIP kernels); no CPU path."""
+
+    def __init__(self, model, device, num_classes):
+        self.model, self.device, self.C = model, device, num_classes
+
+    @torch.no_grad()
+    def pass1(self, imgs):
+        from hiast_amd import kernels as K
+        C = self.C
+        if imgs is None or imgs.shape[0] == 0:
+            self._mp = self._am = None
+            return torch.zeros((C, ias_math.NBINS), dtype=torch.int32, device=self.device)
+        imgs = imgs.to(self.device, non_blocking=True)
+        out = self.model(imgs, lowres=True)
+        H, W = out["size"]
+        self._mp, self._am, hist = K.plabel_pass1(out["logits_lowres"].float().contiguous(), H, W)
+        return hist
+
+    @torch.no_grad()
+    def pass2(self, thr64):
+        """-> (plbl uint8 numpy [b,H,W] or None, count i64 tensor [b,C], sumprob_fx i64 tensor [C])"""
+        from hiast_amd import kernels as K
+        C = self.C
+        if self._mp is None:
+            z = torch.zeros((C,), dtype=torch.int64, device=self.device)
+            return None, torch.zeros((0, C), dtype=torch.int64, device=self.device), z
+        thr_up = None if thr64 is None else torch.from_numpy(ias_math.roundup_f32(thr64)).to(self.device)
+        plbl, count, sfx = K.plabel_pass2(self._mp, self._am, thr_up, C)
+        return plbl, count, sfx
+
+
+class BasePseudoGenerator:
+
+    def __init__(self, cfg, engine=None, dataset=None):
+        self.cfg = cfg
+        C = cfg.dataset.num_classes
+        self.statics_class = np.zeros(C, dtype=np.int64)
+        self.sample_stats = []
+        self.samples_class = {i: [] for i in range(C)}
+        self.class_mean_probs = np.zeros(C)
+        self.class_threshold = None
+        self.rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self._io = ThreadPoolExecutor(max_workers=max(2, cfg.dataset.num_workers))
+        self._pending = []
+        self.initialize(engine, dataset)
+
+    # -- setup -------------------------------------------------------------------------------
+    def initialize(self, engine=None, dataset=None):
+        pp = self.cfg.pseudo_policy
+        if engine is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("pseudo-label generation runs on the HIP device; no GPU is visible "
+                                   "and there is no CPU fallback")
+            device = utils.get_device()
+            model = utils.load_model(self.cfg, resume_from=pp.resume_from).to(device).eval()
+            engine = HipPlabelEngine(model, device, self.cfg.dataset.num_classes)
+        self.engine = engine
+        if dataset is None:
+            aug_type = ["PRS-{}-{}".format(pp.resize_size[0], pp.resize_size[1])]
+            tgt = self.cfg.dataset.target
+            dataset = DATASET[tgt.type](self.cfg, tgt.json_path, tgt.image_dir, aug_type=aug_type,
+                                        num_classes=self.cfg.dataset.num_classes)
+        self.t_dataset = dataset
+        sampler = ShardedBatchSampler(len(dataset), pp.batch_size, self.rank, self.world, shuffle=True,
+                                      seed=self.cfg.train.random_seed)
+        self.t_loader = DataLoader(dataset, batch_sampler=sampler, num_workers=self.cfg.dataset.num_workers,
+                                   pin_memory=torch.cuda.is_available(), collate_fn=_collate)
+        self.pseudo_label_save_dir = pp.save_dir
+        assert self.pseudo_label_save_dir is not None and (
+            not os.path.exists(self.pseudo_label_save_dir) or len(os.listdir(self.pseudo_label_save_dir)) == 0
+            or self.rank != 0)
+        if self.rank == 0:
+            os.makedirs(self.pseudo_label_save_dir, exist_ok=True)
+        if self.world > 1:
+            dist.barrier()
+
+    # -- artefacts ---------------------------------------------------------------------------
+    def save_pseudo_label(self, plbl, img_path):
+        name = os.path.splitext(os.path.basename(img_path))[0]
+        path = os.path.join(self.pseudo_label_save_dir, "{}_pseudo_label.png".format(name))
+        self._pending.append(self._io.submit(lambda a=np.ascontiguousarray(plbl, dtype=np.uint8), p=path:
+                                             Image.fromarray(a, mode="L").save(p, compress_level=1)))
+
+    def save_data(self):
+        for f in self._pending:
+            f.result()
+        self._pending = []
+        if self.world > 1:   # per-image records live on their owner rank: gather them on rank 0
+            parts = [None] * self.world
+            dist.all_gather_object(parts, (self.sample_stats, self.samples_class))
+            self.sample_stats = [s for p in parts for s in p[0]]
+            merged = {i: [] for i in range(self.cfg.dataset.num_classes)}
+            for p in parts:
+                for k, v in p[1].items():
+                    merged[int(k)].extend(v)
+            self.samples_class = merged
+        if self.rank != 0:
+            return
+        root = os.path.join(self.pseudo_label_save_dir, "..")
+        if self.class_threshold is not None:
+            print("class threshold: {}".format(self.class_threshold))
+            np.save(os.path.join(root, "class_threshold.npy"), self.class_threshold)
+        print("class statics number: {}".format(self.statics_class))
+        np.save(os.path.join(root, "statics_class.npy"), self.statics_class)
+        print("class mean probabilities: {}".format(self.class_mean_probs))
+        np.save(os.path.join(root, "class_mean_probabilities.npy"), self.class_mean_probs)
+        with open(os.path.join(root, "sample_class_stats.json"), "a") as f:   # append mode, as the reference
+            f.write(json.dumps(self.sample_stats))
+        with open(os.path.join(root, "samples_with_class.json"), "a") as f:
+            f.write(json.dumps(self.samples_class))
+
+    # -- one batch ---------------------------------------------------------------------------
+    def _allreduce(self, t):
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t
+
+    def select_and_save_confident_label(self, img_paths):
+        """pass 2 + statistics of select_and_save_confident_label (pseudo_label_generator.py:67-105)."""
+        plbl, count, sfx = self.engine.pass2(self.class_threshold)
+        count_c = self._allreduce(count.sum(0) if count.shape[0] else torch.zeros_like(sfx))
+        sfx = self._allreduce(sfx)
+        count_h = count.cpu().numpy()
+        plbl_h = plbl.cpu().numpy() if plbl is not None else None
+        C = self.cfg.dataset.num_classes
+        for b, path in enumerate(img_paths):
+            stats = {}
+            for i in range(C):
+                n = int(count_h[b, i])
+                if n != 0:
+                    stats[i] = n
+                    self.samples_class[i].append([path, n])
+            stats["file"] = path
+            self.sample_stats.append(stats)
+            self.save_pseudo_label(plbl_h[b], path)
+        count_c = count_c.cpu().numpy()
+        self.statics_class += count_c
+        ias_math.update_class_mean_probs(self.class_mean_probs, count_c, sfx.cpu().numpy(),
+                                         self.cfg.preprocessor.copy_paste.gamma)
+        return plbl_h
+
+    def _batches(self):
+        for data in self.t_loader:
+            if data is None:
+                yield None, []
+            else:
+                yield data["images"], list(data["image_paths"])
+
+    def _exists(self):
+        if self.rank == 0 and len(os.listdir(self.pseudo_label_save_dir)) >= len(self.t_dataset):
+            print("%% pseudo labels have existed")
+            return True
+        return False
+
+    def run(self):
+        raise NotImplementedError
+
+
+def _collate(items):
+    if len(items) == 0:
+        return None
+    return {"images": torch.stack([it["images"] for it in items]),
+            "image_paths": [it["image_paths"] for it in items]}
+
+
+@PSEUDO_POLICY.register("CT")
+class ConstantThresholdPseudoGenerator(BasePseudoGenerator):
+
+    def get_constant_threshold(self):
+        return self.cfg.pseudo_policy.ct.threshold * np.ones(self.cfg.dataset.num_classes)
+
+    def run(self):
+        if self._exists():
+            return
+        self.class_threshold = self.get_constant_threshold()
+        for imgs, paths in self._batches():
+            self.engine.pass1(imgs)
+            self.select_and_save_confident_label(paths)
+        self.save_data()
+
+
+@PSEUDO_POLICY.register("NT")
+class NoThresholdPseudoGenerator(ConstantThresholdPseudoGenerator):
+
+    def get_constant_threshold(self):
+        return None
+
+
+@PSEUDO_POLICY.register("CBST")
+class CBSTPseudoGenerator(ConstantThresholdPseudoGenerator):
+    """Global per-class quantile over the whole target set (pseudo_label_generator.py:142-165).
+    The reference subsamples every `sample_interval`-th value to bound host memory; the histogram
+    has no such limit, so every pixel is counted (sample_interval is ignored — documented)."""
+
+    def get_constant_threshold(self):
+        C = self.cfg.dataset.num_classes
+        total = torch.zeros((C, ias_math.NBINS), dtype=torch.int64, device=self.engine.device)
+        for imgs, _ in self._batches():
+            total += self.engine.pass1(imgs).long()
+        total = self._allreduce(total)
+        return ias_math.cbst_threshold(total.cpu().numpy(), self.cfg.pseudo_policy.cbst.p)
+
+
+@PSEUDO_POLICY.register("IAS")
+class IASPseudoGenerator(BasePseudoGenerator):
+
+    def run(self):
+        if self._exists():
+            return
+        ias = self.cfg.pseudo_policy.ias
+        self.class_threshold = 0.9 * np.ones(self.cfg.dataset.num_classes)     # :185
+        for imgs, paths in self._batches():
+            hist = self._allreduce(self.engine.pass1(imgs))
+            _, self.class_threshold = ias_math.ias_update(hist.cpu().numpy().view(np.uint32), self.class_threshold,
+                                                          ias.alpha, ias.beta, ias.gamma)
+            self.select_and_save_confident_label(paths)
+        self.save_data()

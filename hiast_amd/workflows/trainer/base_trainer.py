@@ -1,0 +1,209 @@
+"""BaseTrainer (reference: workflows/trainer/base_trainer.py:15-197) on PyTorch-ROCm without apex:
+one process per GPU, torch.distributed 'nccl' (= RCCL over xGMI) with the reference's
+tcp://127.0.0.1:port rendezvous (or the torchrun environment when present), torch DDP with bucketed
+gradient all-reduce overlapped with backward (the reference's apex DDP delays it to the end),
+torch SyncBatchNorm, torch.autocast(bf16) standing in for amp O1."""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch.nn.parallel import DistributedDataParallel as DDP
+from torch.utils.data import DataLoader, DistributedSampler
+
+from hiast_amd.utils import metrics, utils
+from hiast_amd.utils.registry.registries import DATASET
+from hiast_amd.utils.result_recorder import ResultRecorder
+
+
+def autocast_dtype(cfg):
+    """apex opt levels -> autocast: O0 = fp32; O1/O2/O3 = reduced-precision convs (bf16 on MI355X)"""
+    return None if cfg.train.apex_opt == "O0" else torch.bfloat16
+
+
+class _Bare(torch.nn.Module):
+    """`.module` indirection for a single process, so trainers can write model.module.* like under DDP"""
+
+    def __init__(self, m):
+        super().__init__()
+        self.module = m
+
+    def forward(self, *a, **k):
+        return self.module(*a, **k)
+
+    def state_dict(self, *a, **k):
+        return self.module.state_dict(*a, **k)
+
+
+class BaseTrainer:
+
+    def __init__(self, cfg, gpu_index):
+        self.cfg = cfg
+        self.gpu_index = gpu_index
+        self.assert_cfg()
+        self.initialize()
+        self.build_all_model()
+        self.build_train_data_reader()
+        self.build_val_data_reader()
+
+    def assert_cfg(self):
+        pass
+
+    # ---------------------------------------------------------------- setup
+    def initialize(self):
+        utils.seed_everything(self.cfg.train.random_seed)
+        self.world = self.cfg.train.gpu_num
+        self.logger = None
+        if self.gpu_index == 0:
+            os.makedirs(self.cfg.work_dir, exist_ok=True)
+            self.logger = utils.init_logger(os.path.join(self.cfg.work_dir, "train.log"))
+            self.checkpoint_dir_path = os.path.join(self.cfg.work_dir, "checkpoints")
+            os.makedirs(self.checkpoint_dir_path, exist_ok=True)
+        use_cuda = torch.cuda.is_available()
+        if self.world > 1 and not dist.is_initialized():
+            if "MASTER_ADDR" in os.environ and "RANK" in os.environ:
+                dist.init_process_group(backend="nccl" if use_cuda else "gloo")
+            else:
+                dist.init_process_group(backend="nccl" if use_cuda else "gloo",
+                                        init_method="tcp://127.0.0.1:{}".format(self.cfg.train.port),
+                                        world_size=self.world, rank=self.gpu_index)
+        if use_cuda:
+            torch.cuda.set_device(self.gpu_index)
+            self.device = torch.device("cuda", self.gpu_index)
+        else:
+            raise RuntimeError("training runs on the HIP device; no GPU is visible and there is no CPU fallback")
+
+    def _wrap(self, model):
+        if self.world > 1:
+            return DDP(model, device_ids=[self.gpu_index], gradient_as_bucket_view=True, bucket_cap_mb=32,
+                       broadcast_buffers=False)
+        return _Bare(model)
+
+    def build_all_model(self):
+        print("%% initialize main model")
+        model = utils.init_model(self.cfg, resume_from=self.cfg.train.resume_from).to(self.device)
+        self.g_optimizer, self.d_optimizer = utils.init_optimizers(self.cfg, model)
+        self.schedulers = utils.init_schedulers(self.cfg, self.g_optimizer, self.d_optimizer)
+        self.amp_dtype = autocast_dtype(self.cfg)
+        self.model = self._wrap(model)
+        self.model_recorder = ResultRecorder(self.cfg, self.gpu_index, self.g_optimizer, self.d_optimizer, "model",
+                                             self.logger)
+
+    def _loader(self, ds, batch_size, shuffle, drop_last):
+        sampler = DistributedSampler(ds, num_replicas=self.world, rank=self.gpu_index, shuffle=shuffle)
+        return sampler, DataLoader(ds, batch_size, sampler=sampler, num_workers=self.cfg.dataset.num_workers,
+                                   pin_memory=True, drop_last=drop_last,
+                                   persistent_workers=self.cfg.dataset.num_workers > 0)
+
+    def build_train_data_reader(self):
+        t = self.cfg.dataset.target
+        if t.type is not None and t.json_path and t.image_dir is not None:
+            self.t_dataset = DATASET[t.type](self.cfg, t.json_path, t.image_dir, pseudo_dir=t.pseudo_dir,
+                                             aug_type=t.aug_type, num_classes=self.cfg.dataset.num_classes)
+            self.t_sampler, self.t_loader = self._loader(self.t_dataset, self.cfg.train.batch_size, True, True)
+            self.t_iter = iter(self.t_loader)
+
+    def build_val_data_reader(self):
+        v = self.cfg.dataset.val
+        self.v_loader = None
+        if v.type is not None and v.json_path and v.image_dir is not None:
+            ds = DATASET[v.type](self.cfg, v.json_path, v.image_dir, num_classes=self.cfg.dataset.num_classes)
+            _, self.v_loader = self._loader(ds, self.cfg.train.batch_size, False, False)
+
+    def next_target_batch(self):
+        try:
+            return next(self.t_iter)
+        except StopIteration:
+            self.t_sampler.set_epoch(self.t_sampler.epoch + 1)
+            self.t_iter = iter(self.t_loader)
+            return next(self.t_iter)
+
+    # ---------------------------------------------------------------- loop
+    def run(self):
+        if self.gpu_index == 0:
+            self.logger.info("=" * 100)
+            self.logger.info(self.cfg)
+            self.logger.info("=" * 100)
+        self.model_recorder.reset_time_and_losses()
+        for current_iter in range(1, self.cfg.train.total_iter + 1):
+            self.step(current_iter)
+        self.model_recorder.report_end_info()
+
+    def step(self, current_iter):
+        losses = self.train()
+        self.update_model(self.g_optimizer, self.d_optimizer, losses)
+        self.after_update(current_iter)
+        for s in self.schedulers:
+            s.step()
+        self.model_recorder.record_losses(losses)
+        if current_iter % self.cfg.train.iter_report == 0:
+            self.model_recorder.report_losses(current_iter)
+        if current_iter % self.cfg.train.iter_val == 0 and self.v_loader is not None:
+            self.validate_all(current_iter)
+
+    def after_update(self, current_iter):
+        pass
+
+    def validate_all(self, current_iter):
+        self.validate(self.model, self.model_recorder, current_iter)
+
+    def update_model(self, g_optimizer, d_optimizer, losses):
+        """base_trainer.py:127-141: g_loss = Σ mean(loss_i); bf16 autocast needs no loss scaling"""
+        g_loss = sum(torch.mean(v) for k, v in losses.items() if "D_" not in k)
+        g_optimizer.zero_grad(set_to_none=True)
+        g_loss.backward()
+        g_optimizer.step()
+
+    def train(self):
+        raise NotImplementedError
+
+    # ---------------------------------------------------------------- validation / checkpoints
+    def validate(self, model, recorder, current_iter, is_ema=False):
+        iou, miou = self.get_validate_result(model)
+        recorder.record_and_report_metrics(miou, iou, current_iter)
+        if self.gpu_index == 0:
+            if not is_ema:
+                self.save_checkpoint(model, current_iter, recorder.model_name, miou == recorder.best_miou)
+            else:
+                torch.save(model.state_dict(), os.path.join(self.checkpoint_dir_path,
+                                                            "{}_last.pth".format(recorder.model_name)))
+
+    @torch.no_grad()
+    def get_validate_result(self, model):
+        """base_trainer.py:160-186: image -> val.resize_size, logits -> label size, argmax, I/U;
+        the two bilinear resamplings of the logits are kept (low-res -> input size -> label size); the
+        second one is fused with the argmax (pass-1 kernel) so label-size logits are never stored."""
+        from hiast_amd import functional as HF, kernels as K
+        net = model.module if hasattr(model, "module") else model
+        net.eval()
+        C = self.cfg.dataset.num_classes
+        acc = torch.zeros(2, C, dtype=torch.int64, device=self.device)
+        for data in self.v_loader:
+            img = data["images"].to(self.device, non_blocking=True)
+            lbl = data["labels"].to(self.device, non_blocking=True)
+            size = self.cfg.dataset.val.resize_size or tuple(img.shape[2:])
+            img = HF.upsample_bilinear_ac(img, size) if tuple(size) != tuple(img.shape[2:]) else img
+            with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
+                out = net(img, lowres=True)
+            logits = HF.upsample_bilinear_ac(out["logits_lowres"].float(), size)
+            _, pred, _ = K.plabel_pass1(logits.contiguous(), lbl.shape[1], lbl.shape[2])
+            inter, union = metrics.intersection_union_counts(pred.long(), lbl, C)
+            acc[0] += inter
+            acc[1] += union
+        if self.world > 1:
+            dist.all_reduce(acc)       # one 38-element all-reduce instead of two
+        acc = acc.cpu().numpy().astype(np.float64)
+        iou = acc[0] / (acc[1] + 1e-10)
+        return iou, float(np.mean(iou))
+
+    def save_checkpoint(self, model, it, model_name, is_best=False):
+        ckpt = model.module.state_dict()
+        d = self.checkpoint_dir_path
+        if self.cfg.train.is_save_all:
+            torch.save(ckpt, os.path.join(d, "{}_iter_{}.pth".format(model_name, it)))
+        torch.save(ckpt, os.path.join(d, "{}_last.pth".format(model_name)))
+        if is_best:
+            torch.save(ckpt, os.path.join(d, "{}_best.pth".format(model_name)))
+        mid = os.path.join(d, "{}_mid.pth".format(model_name))
+        if it >= self.cfg.train.total_iter // 2 and not os.path.exists(mid):
+            torch.save(ckpt, mid)

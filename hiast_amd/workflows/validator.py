@@ -1,0 +1,114 @@
+"""Validator (reference: workflows/validator.py:13-115): multi-scale / flip softmax-sum test-time
+evaluation, argmax, IoU accumulation, SYNTHIA 16/13-class rescale.  The device is a parameter
+(`device=`) instead of the reference's hard-coded .cuda(), so BASELINE config 1 (CPU-only plumbing
+run) works; on the HIP device the resamplings and the IoU histogram are the library's kernels."""
+import os
+
+import numpy as np
+import torch
+import tqdm
+from PIL import Image
+from torch.nn import functional as F
+from torch.utils.data import DataLoader
+
+from hiast_amd.utils import metrics, utils
+from hiast_amd.utils.registry.registries import DATASET
+
+PALETTE_19 = [128, 64, 128, 244, 35, 232, 70, 70, 70, 102, 102, 156, 190, 153, 153, 153, 153, 153, 250, 170, 30,
+              220, 220, 0, 107, 142, 35, 152, 251, 152, 70, 130, 180, 220, 20, 60, 255, 0, 0, 0, 0, 142, 0, 0, 70,
+              0, 60, 100, 0, 80, 100, 0, 0, 230, 119, 11, 32]
+PALETTE_9 = [70, 130, 180, 220, 20, 60, 119, 11, 32, 0, 0, 142, 220, 220, 0, 250, 170, 30, 70, 70, 70, 244, 35, 232,
+             128, 64, 128]
+
+
+def _resample(x, size):
+    if tuple(x.shape[2:]) == tuple(size):
+        return x
+    if x.is_cuda:
+        from hiast_amd import functional as HF
+        return HF.upsample_bilinear_ac(x.float(), size)
+    return F.interpolate(x, size, mode="bilinear", align_corners=True)
+
+
+class Validator:
+
+    def __init__(self, cfg, device=None):
+        self.cfg = cfg
+        self.device = device if device is not None else utils.get_device()
+        self.initialize()
+
+    def initialize(self):
+        self.model = utils.load_model(self.cfg, resume_from=self.cfg.validate.resume_from).to(self.device)
+        v = self.cfg.dataset.val
+        ds = DATASET[v.type](self.cfg, v.json_path, v.image_dir, num_classes=self.cfg.dataset.num_classes)
+        self.v_loader = DataLoader(ds, self.cfg.validate.batch_size, num_workers=self.cfg.dataset.num_workers,
+                                   pin_memory=self.device.type == "cuda")
+        d = self.cfg.validate.color_mask_dir_path
+        if d is not None:
+            assert not os.path.exists(d) or len(os.listdir(d)) == 0
+            os.makedirs(d, exist_ok=True)
+
+    def get_multi_scale_and_flip_logits(self, imgs, is_softmax=True):
+        """validator.py:34-55: Σ over scales of softmax(model(resized)) (+ flipped), each resampled
+        back to the native size"""
+        def pred(x):
+            y = self.model(x)["logits"]
+            return F.softmax(y, dim=1) if is_softmax else y
+        total = None
+        for size in self.cfg.validate.resize_sizes:
+            assert len(size) == 2 and size[0] <= size[1], \
+                "each resize_size is [height, width] with height <= width, such as [512, 1024]"
+            x = _resample(imgs, size)
+            r = pred(x)
+            if self.cfg.validate.is_flip:
+                r = r + torch.flip(pred(torch.flip(x, dims=[3])), dims=[3])
+            r = _resample(r, imgs.shape[2:])
+            total = r if total is None else total + r
+        return total
+
+    def colorize_mask(self, mask):
+        C = self.cfg.dataset.num_classes
+        if C not in (19, 9):
+            raise NotImplementedError
+        m = Image.fromarray(mask.astype(np.uint8)).convert("P")
+        m.putpalette(PALETTE_19 if C == 19 else PALETTE_9)
+        return m
+
+    def save_color_mask(self, lbls_pred, img_paths):
+        for l, p in zip(lbls_pred, img_paths):
+            self.colorize_mask(l).save(os.path.join(self.cfg.validate.color_mask_dir_path, os.path.basename(p)))
+
+    @torch.no_grad()
+    def run(self):
+        v = self.cfg.validate
+        print("%% batch_size: {}".format(v.batch_size))
+        print("%% num_classes: {}".format(self.cfg.dataset.num_classes))
+        print("%% resize_sizes: {}".format(v.resize_sizes))
+        print("%% is_flip: {}".format(v.is_flip))
+        C = self.cfg.dataset.num_classes
+        acc = torch.zeros(2, C, dtype=torch.int64, device=self.device)
+        self.model.eval()
+        for data in tqdm.tqdm(self.v_loader, desc="Validation", ncols=100):
+            imgs = data["images"].to(self.device)
+            lbls = data["labels"].to(self.device)
+            pred = self.get_multi_scale_and_flip_logits(imgs).argmax(dim=1)
+            inter, union = metrics.intersection_union_counts(pred, lbls, C)
+            acc[0] += inter
+            acc[1] += union
+            if v.color_mask_dir_path is not None:
+                self.save_color_mask(pred.cpu().numpy(), data["image_paths"])
+        acc = acc.cpu().numpy().astype(np.float64)
+        iou = acc[0] / (acc[1] + 1e-10)
+        miou = float(np.mean(iou))
+        self.iou, self.miou, self.miou_13 = iou, miou, None
+        if "SYNTHIA" in str(self.cfg.dataset.source.type):     # validator.py:108-113
+            miou *= 19 / 16
+            iu13 = iou.copy()
+            iu13[3:6] = 0
+            self.miou_13 = float(np.mean(iu13)) * 19 / 13
+            self.miou = miou
+            print("miou_16: {:.4f}, miou_13: {:.4f}, iou: {}".format(miou, self.miou_13,
+                                                                   {c: round(float(x), 4) for c, x in enumerate(iou)}))
+        else:
+            print("miou: {:.4f}, iou: {}".format(miou, {c: round(float(x), 4) for c, x in enumerate(iou)}))
+        return self.miou

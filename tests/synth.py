@@ -32,7 +32,7 @@ def smooth_logits_lr(seed, B, C, h, w, sigma=4.0):
     d = coarse[:, :, y0 + 1][:, :, :, x0 + 1]
     out = (a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy
     out += g.standard_normal((B, C, h, w)).astype(np.float32) * 0.3
-    return out.astype(np.float32)
+    return np.ascontiguousarray(out, dtype=np.float32)
 
 
 def probs_and_labels(seed, B, H, W, C):

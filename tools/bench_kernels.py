@@ -1,0 +1,94 @@
+"""Per-kernel timing of the HIP library on the MI355X (HIP events on torch's current stream, inputs of the
+bench workload: B images of 1024x512 -> 64x128 head maps).  Usage: python tools/bench_kernels.py [B]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from hiast_amd import kernels as K  # noqa: E402
+
+
+def timeit(fn, n=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    ms = sorted(a.elapsed_time(b) for a, b in ev)
+    return ms[len(ms) // 2], ms[0]
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    which = sys.argv[2].split(",") if len(sys.argv) > 2 else ["aspp", "plabel", "loss", "upsample", "ema"]
+    dev = torch.device("cuda")
+    C, Cin, h, w, H, W = 19, 2048, 64, 128, 512, 1024
+    dil = (6, 12, 18, 24)
+    torch.manual_seed(0)
+    if "aspp" in which:
+        x = torch.randn(B, Cin, h, w, device=dev)
+        ws = [torch.randn(C, Cin, 3, 3, device=dev) * 0.01 for _ in range(4)]
+        bs = [torch.randn(C, device=dev) * 0.1 for _ in range(4)]
+        dy = torch.randn(B, C, h, w, device=dev)
+        wpack = K.aspp_pack_weights(ws, bs)
+        wsp = K.aspp_workspace(B, Cin, h, w, C, dev)
+        gf = 2.0 * h * w * C * Cin * 36 * B / 1e9
+        for name, fn in (("aspp_pack", lambda: K.aspp_pack_weights(ws, bs)),
+                         ("aspp_fwd", lambda: K.aspp_fwd(x, wpack, C, dil, wsp)),
+                         ("aspp_bwd_data", lambda: K.aspp_bwd_data(dy, wpack, Cin, dil)),
+                         ("aspp_bwd_weight", lambda: K.aspp_bwd_weight(x, dy, dil, wsp))):
+            med, best = timeit(fn)
+            print("%-18s B=%d  median %8.3f ms  best %8.3f ms  %7.2f TFLOP/s (algorithmic, fp32)" %
+                  (name, B, med, best, gf / med if "pack" not in name else 0))
+        del x, dy
+    if "plabel" in which:
+        z = torch.randn(B, C, h, w, device=dev) * 3
+        med, best = timeit(lambda: K.plabel_pass1(z, H, W))
+        mp, am, hist = K.plabel_pass1(z, H, W)
+        byt = B * (C * h * w * 4 + H * W * 5) / 1e9
+        print("%-18s B=%d  median %8.3f ms  best %8.3f ms  %7.1f GB/s (logits in + prob/label out)" % ("plabel_pass1", B, med, best, byt / med * 1e3))
+        thr = torch.full((C,), 0.9, device=dev)
+        med, best = timeit(lambda: K.plabel_pass2(mp, am, thr, C))
+        byt = B * H * W * 6 / 1e9
+        print("%-18s B=%d  median %8.3f ms  best %8.3f ms  %7.1f GB/s" % ("plabel_pass2", B, med, best, byt / med * 1e3))
+    if "loss" in which:
+        z = torch.randn(B, C, h, w, device=dev) * 3
+        zt = torch.randn(B, C, h, w, device=dev) * 3
+        pl = torch.randint(0, C, (B, H, W), device=dev, dtype=torch.uint8)
+        pl[torch.rand(B, H, W, device=dev) < 0.4] = 255
+        ws_ = K.st_loss_workspace(B, C, h, w, H, W, dev)
+        coef = torch.tensor([1, .1, 1, .5], device=dev)
+        med, best = timeit(lambda: K.st_loss_fwd(z, zt, pl, H, W, "ignored", ws_))
+        byt = B * (2 * C * h * w * 4 + H * W) / 1e9
+        print("%-18s B=%d  median %8.3f ms  best %8.3f ms  %7.1f GB/s (algorithmic)" % ("st_loss_fwd", B, med, best, byt / med * 1e3))
+        sums = K.st_loss_fwd(z, zt, pl, H, W, "ignored", ws_)
+        med, best = timeit(lambda: K.st_loss_bwd(z, zt, pl, H, W, "ignored", sums, coef, ws_))
+        byt = B * (3 * C * h * w * 4 + H * W) / 1e9
+        print("%-18s B=%d  median %8.3f ms  best %8.3f ms  %7.1f GB/s (algorithmic)" % ("st_loss_bwd", B, med, best, byt / med * 1e3))
+    if "upsample" in which:
+        z = torch.randn(B, C, h, w, device=dev)
+        med, best = timeit(lambda: K.upsample_bilinear_ac_fwd(z, H, W))
+        byt = B * C * (h * w + H * W) * 4 / 1e9
+        print("%-18s B=%d  median %8.3f ms  best %8.3f ms  %7.1f GB/s" % ("upsample_fwd", B, med, best, byt / med * 1e3))
+        g = torch.randn(B, C, H, W, device=dev)
+        med, best = timeit(lambda: K.upsample_bilinear_ac_bwd(g, h, w))
+        print("%-18s B=%d  median %8.3f ms  best %8.3f ms  %7.1f GB/s" % ("upsample_bwd", B, med, best, byt / med * 1e3))
+    if "ema" in which:
+        n = 44_000_000
+        e = [torch.randn(n, device=dev)]
+        p = [torch.randn(n, device=dev)]
+        plan = K.EmaPlan(e, p)
+        med, best = timeit(lambda: K.ema_update(plan, 0.999))
+        print("%-18s n=%d median %8.3f ms  best %8.3f ms  %7.1f GB/s" % ("ema_update", n, med, best, n * 12 / 1e9 / med * 1e3))
+
+
+if __name__ == "__main__":
+    main()
