@@ -1,0 +1,128 @@
+"""world_size-2 gloo tests (CPU) of the N>1 paths: the sharded pseudo-label generator (host logic, with
+the oracle-backed engine standing in for the HIP kernels) must equal the single-process run at
+batch_size = world * local_batch on the same image order, and the packed loss all-reduce of the
+recorder."""
+import json
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _gen_worker(rank, world, port, root, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from hiast_amd.utils.registry import register  # noqa: F401
+    from hiast_amd.utils.registry.registries import PSEUDO_POLICY
+    from hiast_amd.tools import synth_data
+    from test_host_cpu import OracleEngine
+    h, w, C = 32, 64, 19
+    c = synth_data.synthetic_cfg(root, n_train=7, n_val=1, h=h, w=w) if rank == 0 else None
+    dist.barrier()
+    objs = [c.to_dict() if rank == 0 else None]
+    dist.broadcast_object_list(objs, src=0)
+    from hiast_amd.utils.default_config import CfgNode
+    c = CfgNode(objs[0])
+    c.pseudo_policy.batch_size = 2
+    c.pseudo_policy.save_dir = os.path.join(root, "pseudo_w%d" % world, "pseudo_labels")
+    gen = PSEUDO_POLICY["IAS"](c, engine=OracleEngine(C, h, w))
+    gen.run()
+    if rank == 0:
+        np.save(out, gen.class_threshold)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_generator_equals_single_process(tmp_path):
+    from hiast_amd.utils.registry import register  # noqa: F401
+    from hiast_amd.utils.registry.registries import PSEUDO_POLICY
+    from hiast_amd.utils.default_config import CfgNode
+    from hiast_amd.tools import synth_data
+    from test_host_cpu import OracleEngine
+    from PIL import Image
+    root = str(tmp_path)
+    out = os.path.join(root, "thr_w2.npy")
+    mp.spawn(_gen_worker, args=(2, _free_port(), root, out), nprocs=2, join=True)
+    # single process, batch 4 (= world 2 x local 2), same seeded order
+    h, w, C = 32, 64, 19
+    c = synth_data.synthetic_cfg(root + "/again", n_train=7, n_val=1, h=h, w=w)
+    # reuse the SAME images as the 2-rank run
+    first = json.load(open(os.path.join(root, "data", "cityscapes_train.json")))
+    c.dataset.target.json_path = os.path.join(root, "data", "cityscapes_train.json")
+    c.dataset.target.image_dir = os.path.join(root, "data", "cityscapes")
+    assert len(first) == 7
+    c.pseudo_policy.batch_size = 4
+    c.pseudo_policy.save_dir = os.path.join(root, "pseudo_w1", "pseudo_labels")
+    gen = PSEUDO_POLICY["IAS"](c, engine=OracleEngine(C, h, w))
+    gen.run()
+    thr2 = np.load(out)
+    assert np.array_equal(thr2.view(np.uint64), gen.class_threshold.view(np.uint64))
+    d1, d2 = os.path.join(root, "pseudo_w1"), os.path.join(root, "pseudo_w2")
+    for f in ("statics_class.npy", "class_mean_probabilities.npy", "class_threshold.npy"):
+        a, b = np.load(os.path.join(d1, f)), np.load(os.path.join(d2, f))
+        assert np.array_equal(a, b), f
+    names = sorted(os.listdir(os.path.join(d1, "pseudo_labels")))
+    assert names == sorted(os.listdir(os.path.join(d2, "pseudo_labels"))) and len(names) == 7
+    for n in names:
+        assert np.array_equal(np.array(Image.open(os.path.join(d1, "pseudo_labels", n))),
+                              np.array(Image.open(os.path.join(d2, "pseudo_labels", n)))), n
+    s1 = json.load(open(os.path.join(d1, "sample_class_stats.json")))
+    s2 = json.load(open(os.path.join(d2, "sample_class_stats.json")))
+    key = lambda s: s["file"]
+    assert sorted(s1, key=key) == sorted(s2, key=key)
+    w1 = json.load(open(os.path.join(d1, "samples_with_class.json")))
+    w2 = json.load(open(os.path.join(d2, "samples_with_class.json")))
+    assert {k: sorted(v) for k, v in w1.items()} == {k: sorted(v) for k, v in w2.items()}
+
+
+def test_sharded_batch_sampler_partitions():
+    from hiast_amd.workflows.pseudo_label_generator import ShardedBatchSampler
+    for n, bs, world in [(7, 2, 2), (10, 3, 4), (4, 2, 8), (0, 2, 2)]:
+        parts = [list(ShardedBatchSampler(n, bs, r, world, True, 5)) for r in range(world)]
+        steps = {len(p) for p in parts}
+        assert len(steps) == 1                         # every rank takes the same number of steps
+        seen = [i for p in parts for b in p for i in b]
+        assert sorted(seen) == list(range(n))
+        single = [i for b in ShardedBatchSampler(n, bs * world, 0, 1, True, 5) for i in b]
+        inter = [i for t in range(len(parts[0])) for r in range(world) for i in parts[r][t]]
+        assert inter == single                         # rank-major order inside a global batch
+
+
+def _rec_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hiast_amd.utils.default_config import get_default_cfg
+    from hiast_amd.utils.result_recorder import ResultRecorder
+    rec = ResultRecorder(get_default_cfg(), rank, None, None, "model")
+    for it in range(3):
+        rec.record_losses({"a": torch.tensor(1.0 + rank + it), "b": torch.tensor(10.0 * (rank + 1))})
+    vals = rec.report_losses(3)
+    if rank == 0:
+        json.dump(vals, open(out, "w"))
+    dist.destroy_process_group()
+
+
+def test_recorder_packs_losses_into_one_allreduce(tmp_path):
+    out = str(tmp_path / "v.json")
+    mp.spawn(_rec_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    v = json.load(open(out))
+    assert abs(v["a"] - 2.5) < 1e-6 and abs(v["b"] - 15.0) < 1e-6
