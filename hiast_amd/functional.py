@@ -106,3 +106,66 @@ def st_loss(logits_lr, teacher_lr, plbl, size, region="ignored", w_t=1.0, w_k=0.
     ce, kld, ent, cst, _ = _StLossFn.apply(logits_lr, teacher_lr, plbl, int(size[0]), int(size[1]), region,
                                             float(w_t), float(w_k), float(w_e), float(w_c))
     return ce, kld, ent, cst
+
+
+def _sync_world(bn):
+    import torch.distributed as dist
+    if isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized():
+        return dist.get_world_size()
+    return 1
+
+
+class _BnActFn(torch.autograd.Function):
+    """y = relu?(BN(x) (+ res)) in two streaming kernels (stats, apply) forward and two backward;
+    SyncBN = one all-reduce of the [C,2] double sums between them (same exchange as the reference's SyncBN)."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, running_mean, running_var, training, momentum, eps, relu, world):
+        x = x.contiguous()
+        if res is not None:
+            res = res.contiguous()
+        ctx.training = training
+        if not training:
+            y, _, _ = K.bn_act_apply(x, res, gamma, beta, running_mean, running_var, None, 0.0, momentum, eps, relu)
+            return y
+        part = K.bn_stats(x)
+        count = float(x.shape[0] * x.shape[2] * x.shape[3])
+        if world > 1:
+            import torch.distributed as dist
+            part = part.sum(1, keepdim=True).contiguous()
+            dist.all_reduce(part)
+            count *= world
+        y, sm, si = K.bn_act_apply(x, res, gamma, beta, running_mean, running_var, part, count, momentum, eps, relu)
+        ctx.save_for_backward(x, y, gamma, sm, si)
+        ctx.relu, ctx.has_res, ctx.world, ctx.count = relu, res is not None, world, count
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not ctx.training:
+            raise NotImplementedError("backward through inference-mode fused BN is not needed by the hot path")
+        x, y, gamma, sm, si = ctx.saved_tensors
+        dy = dy.contiguous()
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        part = K.bn_act_bwd_stats(dy, y, x, sm, si, ctx.relu)
+        if ctx.world > 1:
+            import torch.distributed as dist
+            part = part.sum(1, keepdim=True).contiguous()
+            dist.all_reduce(part)
+        want_p = gamma is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3])
+        dx, dres, dg, db = K.bn_act_bwd_apply(dy, y, x, gamma, sm, si, part, ctx.count, ctx.relu,
+                                              ctx.has_res and ctx.needs_input_grad[1], want_p)
+        return (dx, dres, dg if ctx.needs_input_grad[2] else None, db if ctx.needs_input_grad[3] else None,
+                None, None, None, None, None, None, None)
+
+
+def bn_act(x, bn, res=None, relu=True):
+    """Fused replacement of `relu(bn(x) [+ res])` for a torch BatchNorm2d / SyncBatchNorm module `bn`
+    (which keeps owning the parameters and running statistics)."""
+    training = bn.training or (bn.running_mean is None)
+    if training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    return _BnActFn.apply(x, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum,
+                          bn.eps, relu, _sync_world(bn) if training else 1)

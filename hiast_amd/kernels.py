@@ -264,3 +264,72 @@ def confusion_hist(pred, target, K, inter=None, area_pred=None, area_tgt=None):
                                                _ptr(area_pred), _ptr(area_tgt), _stream()),
               "hiast_confusion_hist")
     return inter, area_pred, area_tgt
+
+
+# ------------------------------------------------------------------------------- K10 BN (+res) (+ReLU)
+def _bn_dtype(t):
+    if t.dtype == torch.float32:
+        return 0
+    if t.dtype == torch.bfloat16:
+        return 1
+    raise TypeError("bn_act supports float32 and bfloat16 activations, got %s" % t.dtype)
+
+
+def _bn_dims(x):
+    if not x.is_cuda:
+        raise _lib.HiastLibraryError("bn_act runs on the HIP device only")
+    assert x.dim() == 4 and x.is_contiguous()
+    B, C, H, W = x.shape
+    return B, C, H * W
+
+
+def bn_stats(x):
+    """-> part f64 [C, B, 2] = per-plane (Σx, Σx²)"""
+    B, C, HW = _bn_dims(x)
+    part = torch.empty((C, B, 2), dtype=torch.float64, device=x.device)
+    check(_lib.load().hiast_bn_stats(_ptr(x), B, C, HW, _bn_dtype(x), _ptr(part), _stream()), "hiast_bn_stats")
+    return part
+
+
+def bn_act_apply(x, res, gamma, beta, running_mean, running_var, part, count, momentum, eps, relu):
+    """part None -> inference with running statistics; else training with the given partial sums.
+    -> (y, save_mean, save_invstd)  (the last two None in inference)"""
+    B, C, HW = _bn_dims(x)
+    y = torch.empty_like(x)
+    if res is not None:
+        assert res.shape == x.shape and res.dtype == x.dtype and res.is_contiguous()
+    sm = si = None
+    npart = 0
+    if part is not None:
+        assert part.dtype == torch.float64 and part.is_contiguous() and part.shape[0] == C and part.shape[2] == 2
+        npart = part.shape[1]
+        sm = torch.empty(C, dtype=torch.float32, device=x.device)
+        si = torch.empty(C, dtype=torch.float32, device=x.device)
+    check(_lib.load().hiast_bn_act_apply(_ptr(x), _ptr(res), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(running_mean),
+                                         _ptr(running_var), _ptr(part), npart, float(count), float(momentum),
+                                         float(eps), int(bool(relu)), _ptr(sm), _ptr(si), B, C, HW, _bn_dtype(x),
+                                         _stream()), "hiast_bn_act_apply")
+    return y, sm, si
+
+
+def bn_act_bwd_stats(dy, y, x, save_mean, save_invstd, relu):
+    B, C, HW = _bn_dims(x)
+    assert dy.shape == x.shape and dy.dtype == x.dtype and dy.is_contiguous()
+    part = torch.empty((C, B, 2), dtype=torch.float64, device=x.device)
+    check(_lib.load().hiast_bn_act_bwd_stats(_ptr(dy), _ptr(y), _ptr(x), _ptr(save_mean), _ptr(save_invstd),
+                                             int(bool(relu)), B, C, HW, _bn_dtype(x), _ptr(part), _stream()),
+          "hiast_bn_act_bwd_stats")
+    return part
+
+
+def bn_act_bwd_apply(dy, y, x, gamma, save_mean, save_invstd, part, count, relu, want_dres, want_dparam):
+    B, C, HW = _bn_dims(x)
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    dg = torch.empty(C, dtype=torch.float32, device=x.device) if want_dparam else None
+    db = torch.empty(C, dtype=torch.float32, device=x.device) if want_dparam else None
+    check(_lib.load().hiast_bn_act_bwd_apply(_ptr(dy), _ptr(y), _ptr(x), _ptr(gamma), _ptr(save_mean),
+                                             _ptr(save_invstd), _ptr(part), part.shape[1], float(count),
+                                             int(bool(relu)), _ptr(dx), _ptr(dres), _ptr(dg), _ptr(db), B, C, HW,
+                                             _bn_dtype(x), _stream()), "hiast_bn_act_bwd_apply")
+    return dx, dres, dg, db

@@ -4,6 +4,19 @@ conv{1,2,3}/bn{1,2,3}/downsample.{0,1}) so released checkpoints load key-for-key
 Round 1: convolutions/BN run on PyTorch-ROCm (MIOpen); hand-written MFMA kernels for the
 layer3/4 bottlenecks are the next row of the scope table."""
 import torch.nn as nn
+import torch.nn.functional as F
+
+from hiast_amd import functional as HF
+
+
+def bn_act(bn, x, res=None, relu=True):
+    """relu?(bn(x) [+ res]) — one fused HIP op on the device (hiast_bn_*), plain torch on CPU tensors"""
+    if x.is_cuda:
+        return HF.bn_act(x, bn, res, relu)
+    y = bn(x)
+    if res is not None:
+        y = y + res
+    return F.relu(y) if relu else y
 
 
 class Bottleneck(nn.Module):
@@ -21,12 +34,10 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        idt = x if self.downsample is None else self.downsample(x)
-        o = self.relu(self.bn1(self.conv1(x)))
-        o = self.relu(self.bn2(self.conv2(o)))
-        o = self.bn3(self.conv3(o))
-        o += idt
-        return self.relu(o)
+        idt = x if self.downsample is None else bn_act(self.downsample[1], self.downsample[0](x), relu=False)
+        o = bn_act(self.bn1, self.conv1(x))
+        o = bn_act(self.bn2, self.conv2(o))
+        return bn_act(self.bn3, self.conv3(o), res=idt)        # += identity, ReLU
 
 
 class ResNet(nn.Module):
@@ -62,7 +73,7 @@ class ResNet(nn.Module):
         return nn.Sequential(*blocks)
 
     def forward(self, x, is_return_low=False):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.maxpool(bn_act(self.bn1, self.conv1(x)))
         low = self.layer1(x)
         x = self.layer4(self.layer3(self.layer2(low)))
         return (x, low) if is_return_low else x

@@ -132,6 +132,36 @@ int hiast_aspp_bwd_weight(const float* x, const float* dy, float* dw0, float* dw
                           const int* dil, void* workspace, size_t workspace_bytes,
                           hiast_stream_t stream);
 
+/* ---- K10: BatchNorm2d (+ residual) (+ ReLU), fused ----------------------------------------
+ * The conv -> BN -> ReLU / conv -> BN -> (+identity) -> ReLU chains of Bottleneck.forward,
+ * sseg/models/modules/resnet.py:78-98 (separate BN / add / ReLU passes in the reference).  "Frozen" BN still
+ * uses BATCH statistics in train() mode (utils/utils.py:60-65).
+ * x, res, y, dy, dx, dres: [B,C,HW] contiguous, dtype 0 = fp32, 1 = bf16; gamma/beta/statistics fp32 [C]
+ * (gamma/beta may be NULL = 1/0).  `part` = per-plane partial sums, double [C][npart][2]; between the
+ * stats call and the apply call the caller may sum `part` across ranks (SyncBN) — then pass the summed
+ * buffer with npart planes and the GLOBAL element count.
+ *   hiast_bn_stats        : part[c][n] = (Σx, Σx²) of plane (n,c)            (npart = B)
+ *   hiast_bn_act_apply    : y = relu?(x*scale_c + shift_c (+res));  part == NULL -> inference (running
+ *                           statistics), else training: mean/var from part/count, writes save_mean /
+ *                           save_invstd [C] and updates running_mean/var (momentum, unbiased variance;
+ *                           running_* may be NULL).
+ *   hiast_bn_act_bwd_stats: g = dy*(y>0 if relu); part[c][n] = (Σg, Σ g*xhat)
+ *   hiast_bn_act_bwd_apply: dx = gamma*invstd*(g - Σg/count - xhat*Σ(g*xhat)/count); dres = g (nullable);
+ *                           dgamma = Σ g*xhat, dbeta = Σg (nullable). */
+size_t hiast_bn_workspace_bytes(int B, int C);
+int hiast_bn_stats(const void* x, int B, int C, int64_t HW, int dtype, double* part, hiast_stream_t stream);
+int hiast_bn_act_apply(const void* x, const void* res, void* y, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, const double* part, int npart, double count,
+                       float momentum, float eps, int relu, float* save_mean, float* save_invstd, int B, int C,
+                       int64_t HW, int dtype, hiast_stream_t stream);
+int hiast_bn_act_bwd_stats(const void* dy, const void* y, const void* x, const float* save_mean,
+                           const float* save_invstd, int relu, int B, int C, int64_t HW, int dtype,
+                           double* part, hiast_stream_t stream);
+int hiast_bn_act_bwd_apply(const void* dy, const void* y, const void* x, const float* gamma,
+                           const float* save_mean, const float* save_invstd, const double* part, int npart,
+                           double count, int relu, void* dx, void* dres, float* dgamma, float* dbeta, int B,
+                           int C, int64_t HW, int dtype, hiast_stream_t stream);
+
 /* ---- K11: EMA teacher update ---------------------------------------------------------
  * utils/utils.py:115-123 update_ema_model: ema = ema*gamma + p*(1-gamma) over a list of
  * tensors in ONE launch (gamma, one_minus_gamma: the float32 roundings of the Python

@@ -278,3 +278,101 @@ def test_no_cpu_fallback(K):
     from hiast_amd._lib import HiastLibraryError
     with pytest.raises(HiastLibraryError):
         K.upsample_bilinear_ac_fwd(torch.zeros(1, 1, 2, 2), 4, 4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 64, 16, 32), (3, 10, 7, 9), (8, 256, 64, 128)])
+@pytest.mark.parametrize("res,relu", [(False, True), (True, True), (False, False)])
+def test_bn_act_train_fwd_bwd_vs_torch(K, dtype, shape, res, relu):
+    """fused BN(+res)(+ReLU) with batch statistics, forward, running-stat update and backward, vs
+    torch.nn.BatchNorm2d in float64 on the CPU."""
+    from hiast_amd import functional as HF
+    B, C, Hh, Ww = shape
+    x = synth.normal_f32(101, shape, 2.0) + 0.5
+    r = synth.normal_f32(102, shape, 1.0) if res else None
+    gy = synth.normal_f32(103, shape, 1.0)
+    gam = 1 + synth.normal_f32(104, (C,), 0.2)
+    bet = synth.normal_f32(105, (C,), 0.2)
+    bn = torch.nn.BatchNorm2d(C).cuda()
+    with torch.no_grad():
+        bn.weight.copy_(torch.from_numpy(gam))
+        bn.bias.copy_(torch.from_numpy(bet))
+    bn.train()
+    xd = torch.from_numpy(x).cuda().to(dtype).requires_grad_(True)
+    rd = torch.from_numpy(r).cuda().to(dtype).requires_grad_(True) if res else None
+    y = HF.bn_act(xd, bn, rd, relu)
+    y.backward(torch.from_numpy(gy).cuda().to(dtype))
+    # reference in float64 on the SAME (possibly bf16-rounded) inputs
+    xr = xd.detach().double().cpu().requires_grad_(True)
+    rr = rd.detach().double().cpu().requires_grad_(True) if res else None
+    ref = torch.nn.BatchNorm2d(C).double()
+    with torch.no_grad():
+        ref.weight.copy_(torch.from_numpy(gam))
+        ref.bias.copy_(torch.from_numpy(bet))
+    ref.train()
+    yr = ref(xr)
+    if res:
+        yr = yr + rr
+    if relu:
+        yr = torch.relu(yr)
+    yr.backward(torch.from_numpy(gy).cuda().to(dtype).double().cpu())
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert torch.allclose(y.detach().double().cpu(), yr.detach(), rtol=tol, atol=tol)
+    assert torch.allclose(bn.running_mean.double().cpu(), ref.running_mean, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(bn.running_var.double().cpu(), ref.running_var, rtol=1e-5, atol=1e-6)
+    assert int(bn.num_batches_tracked) == 1
+    # ReLU masks can differ where y is within rounding of 0; compare gradients away from those pixels
+    gx, gxr = xd.grad.double().cpu(), xr.grad
+    scale = gxr.abs().max()
+    bad = ((gx - gxr).abs() > (1e-4 if dtype == torch.float32 else 3e-2) * scale).float().mean()
+    assert bad < (1e-4 if dtype == torch.float32 else 2e-2)
+    assert torch.allclose(bn.weight.grad.double().cpu(), ref.weight.grad, rtol=2e-2 if dtype != torch.float32 else 1e-4,
+                          atol=2e-2 * float(ref.weight.grad.abs().max()) if dtype != torch.float32 else 1e-4)
+    if res:
+        assert ((rd.grad.double().cpu() - rr.grad).abs() > 1e-6).float().mean() < 2e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bn_act_eval_vs_torch(K, dtype):
+    from hiast_amd import functional as HF
+    shape = (2, 32, 9, 13)
+    x = synth.normal_f32(111, shape, 2.0)
+    r = synth.normal_f32(112, shape, 1.0)
+    bn = torch.nn.BatchNorm2d(32).cuda()
+    with torch.no_grad():
+        bn.weight.copy_(torch.from_numpy(1 + synth.normal_f32(113, (32,), 0.2)))
+        bn.bias.copy_(torch.from_numpy(synth.normal_f32(114, (32,), 0.2)))
+        bn.running_mean.copy_(torch.from_numpy(synth.normal_f32(115, (32,), 0.5)))
+        bn.running_var.copy_(torch.from_numpy(0.5 + synth.rng(116).random(32, dtype=np.float32)))
+    bn.eval()
+    xd, rd = torch.from_numpy(x).cuda().to(dtype), torch.from_numpy(r).cuda().to(dtype)
+    y = HF.bn_act(xd, bn, rd, True)
+    want = torch.relu(bn(xd.float()) + rd.float())
+    assert torch.allclose(y.float(), want, rtol=1e-5 if dtype == torch.float32 else 1e-2,
+                          atol=1e-5 if dtype == torch.float32 else 2e-2)
+
+
+def test_trunk_fused_matches_plain_modules(K):
+    """whole DeepLab_V2 forward on the device (fused BN/ReLU/add + HIP ASPP) vs the same weights through the
+    oracle's functional torch-CPU restatement: eval fp32, logits <= 1e-3 relative (the north_star contract)."""
+    from oracle import deeplab_ref
+    from hiast_amd.utils.registry import register  # noqa: F401
+    from hiast_amd.utils.registry.registries import SEG_MODEL
+    from make_golden import seeded_state_dict
+    m = SEG_MODEL["DeepLab_V2"](19, 256)
+    sd = seeded_state_dict(m, 9000)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    x = torch.from_numpy(synth.normal_f32(901, (1, 3, 129, 257)))
+    with torch.no_grad():
+        pred, feat = m(x.cuda())
+        want, wfeat = deeplab_ref.deeplab_v2(x, sd)
+    err = (pred.cpu() - want).abs().max() / want.abs().max()
+    assert err < 1e-3, float(err)
+    m.train()
+    xb = torch.from_numpy(synth.normal_f32(902, (2, 3, 65, 129)))
+    with torch.no_grad():
+        pred, _ = m(xb.cuda())
+        want, _ = deeplab_ref.deeplab_v2(xb, sd, train=True)
+    err = (pred.cpu() - want).abs().max() / want.abs().max()
+    assert err < 2e-3, float(err)
