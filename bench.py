@@ -297,10 +297,18 @@ def main():
         if s is not None:
             avg_ms, nimg, n = s
             ach = ASPP_FLOP_PER_IMG * nimg / (avg_ms * 1e-3) / 1e12
-            out["roofline"] = {"kernel": "hiast::aspp_fwd_kernel<2>", "bound": "mfma", "achieved": ach,
+            traffic, tnote = None, "no PMC profile committed for this launch shape"
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_aspp_fwd.json")
+            if os.path.exists(pmc) and nimg == 8:       # HBM bytes per launch from the committed rocprofv3 --pmc passes
+                pj = json.load(open(pmc))
+                traffic = pj["hbm_bytes_x2_fetch"]
+                tnote = ("HBM bytes/launch from %s: (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correction); "
+                         "uncorrected %.0f MB; algorithmic %.0f MB" % (pj["source"], pj["hbm_bytes_uncorrected"] / 1e6,
+                                                                        pj["algorithmic_bytes"] / 1e6))
+            out["roofline"] = {"kernel": "hiast::aspp_fwd16_kernel<4,3>", "bound": "mfma", "achieved": ach,
                                "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA,
-                               "traffic": None, "avg_launch_ms": avg_ms, "launches": n,
-                               "note": "fp32 MFMA peak; algorithmic 22.95 GFLOP/img x %d img per launch" % nimg}
+                               "traffic": traffic, "avg_launch_ms": avg_ms, "launches": n,
+                               "note": "fp32 MFMA peak; algorithmic 22.95 GFLOP/img x %d img per launch; %s" % (nimg, tnote)}
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(cfg, tuple(args.cpu_size), args.cpu_threads)

@@ -31,6 +31,22 @@ struct Taps {
     int dx[NTAP];
 };
 
+// XCD-aware work assignment: the dispatcher deals consecutive workgroup ids round-robin over the 8 XCDs
+// (each with a private 4 MB L2).  Work items are ordered image-major, so giving XCD k the k-th contiguous
+// eighth of them keeps all tiles of one image (whose shifted re-reads share a channel slab) on one L2.
+// Placement only changes speed, never results.
+__device__ __forceinline__ void xcd_remap(int& bx, int& by, int& bz)
+{
+    const int gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
+    const int total = gx * gy * gz;
+    int lid = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    if ((total & 7) == 0) lid = (lid & 7) * (total >> 3) + (lid >> 3);
+    // item order: image (y) major, then split (z), then pixel tile (x)
+    bx = lid % gx;
+    bz = (lid / gx) % gz;
+    by = lid / (gx * gz);
+}
+
 static Taps make_taps(const int* dil)
 {
     Taps t;
@@ -95,8 +111,8 @@ __global__ __launch_bounds__(256) void aspp_fwd_kernel(const float* __restrict__
 {
     __shared__ float s_w[2][KC * COP];
     const int hw = h * w;
-    const int n = blockIdx.y;
-    const int split = blockIdx.z;
+    int bx, n, split;
+    xcd_remap(bx, n, split);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 31, ksub = lane >> 5;
     const int ci0 = split * ci_per_split, ci1 = ci0 + ci_per_split;
@@ -104,7 +120,7 @@ __global__ __launch_bounds__(256) void aspp_fwd_kernel(const float* __restrict__
     int pix[MT], py[MT], px[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-        pix[m] = (blockIdx.x * 4 + wave) * (32 * MT) + m * 32 + col;
+        pix[m] = (bx * 4 + wave) * (32 * MT) + m * 32 + col;
         const int pc = pix[m] < hw ? pix[m] : hw - 1;
         py[m] = pc / w;
         px[m] = pc - py[m] * w;
@@ -185,6 +201,141 @@ __global__ __launch_bounds__(256) void aspp_fwd_kernel(const float* __restrict__
         for (int r = 0; r < 16; ++r) {
             const int co = (r & 3) + 8 * (r >> 2) + 4 * ksub;
             if (co < Cout) on[(size_t)co * hw + pix[m]] = acc[m][r] + (add_bias ? bias[co] : 0.f);
+        }
+    }
+}
+
+// ---- forward, no row padding: output channels 0..15 on v_mfma_f32_16x16x4_f32 (rows = channel,
+// columns = 16 consecutive pixels, k = 4 input channels), channels 16..16+NV-1 (NV <= 3) on the
+// otherwise idle VALU: every lane already holds x[ci = k0 + (lane>>4)][pixel = lane&15] as its B
+// operand, so it adds w[c][ci] * x to NV private partial sums that are folded over the four k-lanes
+// at the end.  For C = 19 this removes the 19 -> 32 padding of the 32x32 variant (41 % of its MFMA work).
+// Wave = NP groups of 16 pixels; block = 4 waves.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int KC16 = 64;      // input channels per staged chunk of the 16-row kernel
+
+template <int NP, int NV>
+__global__ __launch_bounds__(256) void aspp_fwd16_kernel(const float* __restrict__ x,
+                                                         const float* __restrict__ wpack,
+                                                         float* __restrict__ out, int Cin, int h, int w,
+                                                         int Cout, Taps taps, int ci_per_split, int add_bias)
+{
+    __shared__ float s_w[2][KC16 * COP];
+    const int hw = h * w;
+    int bx, n, split;
+    xcd_remap(bx, n, split);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, kq = lane >> 4;
+    const int ci0 = split * ci_per_split;
+
+    int pix[NP], py[NP], px[NP];
+#pragma unroll
+    for (int g = 0; g < NP; ++g) {
+        pix[g] = (bx * 4 + wave) * (16 * NP) + g * 16 + col;
+        const int pc = pix[g] < hw ? pix[g] : hw - 1;
+        py[g] = pc / w;
+        px[g] = pc - py[g] * w;
+    }
+    // Input operand through a raw buffer descriptor over image n: per-lane byte offset in a VGPR (fixed
+    // for a whole (chunk, tap)), channel advance in the SCALAR offset (no per-load VALU address math),
+    // and out-of-image lanes get an offset beyond num_records, for which the hardware returns 0:
+    // the conv's zero padding costs neither a branch nor a select.
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(x + (size_t)n * Cin * hw), 0, (int)((size_t)Cin * hw * sizeof(float)), 0x00020000);
+
+    f32x4 acc[NP];
+    float accv[NV > 0 ? NV : 1][NP];
+#pragma unroll
+    for (int g = 0; g < NP; ++g) {
+        acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int v = 0; v < (NV > 0 ? NV : 1); ++v) accv[v][g] = 0.f;
+    }
+
+    const int nchunk = ci_per_split / KC16;
+    const int niter = nchunk * NTAP;
+    auto wsrc = [&](int it) {
+        const int chunk2 = it / NTAP, tap2 = it - chunk2 * NTAP;
+        return reinterpret_cast<const float4*>(wpack + ((size_t)tap2 * Cin + ci0 + chunk2 * KC16) * COP);
+    };
+    {
+        const float4* src = wsrc(0);
+        reinterpret_cast<float4*>(s_w[0])[threadIdx.x] = src[threadIdx.x];
+        reinterpret_cast<float4*>(s_w[0])[threadIdx.x + 256] = src[threadIdx.x + 256];
+    }
+    __syncthreads();
+
+    for (int it = 0; it < niter; ++it) {
+        const int buf = it & 1;
+        const bool more = it + 1 < niter;
+        float4 nx0 = make_float4(0, 0, 0, 0), nx1 = nx0;
+        if (more) {
+            const float4* src = wsrc(it + 1);
+            nx0 = src[threadIdx.x];
+            nx1 = src[threadIdx.x + 256];
+        }
+        const int chunk = it / NTAP, tap = it - chunk * NTAP;
+        const int cib = ci0 + chunk * KC16;
+        const int dy = taps.dy[tap], dx = taps.dx[tap];
+        int voff[NP];
+#pragma unroll
+        for (int g = 0; g < NP; ++g) {
+            const int yy = py[g] + dy, xx = px[g] + dx;
+            const bool ok = pix[g] < hw && yy >= 0 && yy < h && xx >= 0 && xx < w;
+            voff[g] = ok ? (kq * hw + yy * w + xx) * 4 : (int)0x80000000;
+        }
+        const int sbase = cib * hw * 4;
+        float bs[KC16 / 4][NP];
+#pragma unroll
+        for (int ks = 0; ks < KC16 / 4; ++ks)
+#pragma unroll
+            for (int g = 0; g < NP; ++g)
+                bs[ks][g] = __int_as_float(
+                    __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[g], sbase + ks * 4 * hw * 4, 0));
+        const float* sw = s_w[buf] + kq * COP;
+#pragma unroll
+        for (int ks = 0; ks < KC16 / 4; ++ks) {
+            const float a = sw[ks * 4 * COP + col];                          // A[co = col][k = kq]
+            float wv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (NV > 0) {
+                const float4 t = *reinterpret_cast<const float4*>(sw + ks * 4 * COP + 16);   // co 16..19
+                wv[0] = t.x; wv[1] = t.y; wv[2] = t.z; wv[3] = t.w;
+            }
+#pragma unroll
+            for (int g = 0; g < NP; ++g) {
+                const float bv = bs[ks][g];
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[g], 0, 0, 0);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) accv[v][g] = fmaf(wv[v], bv, accv[v][g]);
+            }
+        }
+        if (more) {
+            reinterpret_cast<float4*>(s_w[buf ^ 1])[threadIdx.x] = nx0;
+            reinterpret_cast<float4*>(s_w[buf ^ 1])[threadIdx.x + 256] = nx1;
+        }
+        __syncthreads();
+    }
+
+    const float* bias = wpack + (size_t)NTAP * Cin * COP;
+    float* on = out + ((size_t)split * gridDim.y + n) * Cout * hw;
+#pragma unroll
+    for (int g = 0; g < NP; ++g) {
+        if (pix[g] < hw) {          // MFMA rows: co = 4*(lane>>4) + r, column = pixel
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = 4 * kq + r;
+                if (co < Cout) on[(size_t)co * hw + pix[g]] = acc[g][r] + (add_bias ? bias[co] : 0.f);
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            float t = accv[v][g];
+            t += __shfl_xor(t, 16, 64);
+            t += __shfl_xor(t, 32, 64);
+            const int co = 16 + v;
+            if (kq == 0 && pix[g] < hw && co < Cout)
+                on[(size_t)co * hw + pix[g]] = t + (add_bias ? bias[co] : 0.f);
         }
     }
 }
@@ -319,103 +470,139 @@ __global__ __launch_bounds__(256) void aspp_bwd_data_kernel(const float* __restr
 
 // ---------------------------------------------------------------------------------- bwd weight
 // dWp[tap][co][ci] = Σ_n Σ_p dY[n][co][p] * X[n][ci][p + off(tap)]   (K = B*h*w pixels)
-// MFMA rows = co (padded 32), columns = 32 input channels; both operands are needed
-// "pixel-minor", so a 64-pixel piece of a row is staged through LDS: the dY slab [32][64] and, for
-// the block's dilation d, the three X slabs rows y-d, y, y+d x [32 ch][64 + 2d] (zero-filled
-// outside the image), which serve the 8 ring taps of that dilation (+ the centre tap).
-// Block = (32-channel tile, dilation, pixel-range split); its 4 waves share the slabs and own
-// 2 taps each (wave 0 of dilation 0 also owns the centre tap).  Split partials are reduced in a
-// fixed order by aspp_wgrad_reduce_kernel (bitwise reproducible, no float atomics).
-constexpr int WG_KP = 64;
-constexpr int WG_LDY = WG_KP + 1;
+// v_mfma_f32_16x16x4_f32: rows = co 0..15, columns = 16 input channels, k = 4 pixels; channels
+// co 16..18 on the VALU (as in the forward kernel).  Both operands are pixel-contiguous in NCHW, so each
+// lane fetches FOUR consecutive pixels with one 16-byte load and feeds them to four MFMAs: the k index of
+// MFMA t is pixel 4*kq + t of a 16-pixel step (the same permutation on both operands, so the sum over k
+// is unchanged).  No LDS: dY rows are shared through L1, X planes stream from L2.
+// Wave = 2 channel tiles (32 channels) x the 8 ring taps of one dilation (+ the centre tap for
+// dilation 0); block = 4 waves = 128 channels; pixel-range split-K over blockIdx.z, partials reduced
+// in fixed order by aspp_wgrad_reduce_kernel.  Row shifts that leave the image are skipped (wave
+// uniform); column shifts are masked per element only in the steps that touch a row end.
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
+template <int NV, int NTILE>
 __global__ __launch_bounds__(256) void aspp_bwd_weight_kernel(const float* __restrict__ x,
                                                               const float* __restrict__ dy,
                                                               float* __restrict__ partial, int B,
                                                               int Cin, int h, int w, int Cout,
                                                               int dil0, int dil1, int dil2, int dil3,
-                                                              int nsplit, int lxw)
+                                                              int nsplit)
 {
-    extern __shared__ float s_mem[];
-    float* s_dy = s_mem;                       // [32][WG_LDY]
-    float* s_x = s_mem + 32 * WG_LDY;          // [3][32][lxw]
     const int hw = h * w;
-    const int cib = blockIdx.x * 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    const int cib = (blockIdx.x * 4 + wave) * (16 * NTILE);
     const int g = blockIdx.y;
     const int split = blockIdx.z;
     const int d = g == 0 ? dil0 : (g == 1 ? dil1 : (g == 2 ? dil2 : dil3));
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int col = lane & 31, ksub = lane >> 5;
+    const bool has_centre = (g == 0);
+    constexpr int NT = 9;                      // 8 ring taps + centre (only accumulated when g == 0)
 
-    // this wave's taps: ring positions 2*wave, 2*wave+1 of dilation g (k -> (ky,kx) skipping centre)
-    int t_row[3], t_dx[3];
+    f32x4 acc[NTILE][NT];
+    float accv[NV > 0 ? NV : 1][NTILE][NT];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        int k = 2 * wave + t;
-        k += (k >= 4) ? 1 : 0;
-        t_row[t] = k / 3;                      // 0: y-d, 1: y, 2: y+d
-        t_dx[t] = (k % 3 - 1) * d;
-    }
-    t_row[2] = 1; t_dx[2] = 0;                 // centre tap
-    const bool has_centre = (g == 0 && wave == 0);
+    for (int tt = 0; tt < NTILE; ++tt)
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            acc[tt][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int v = 0; v < (NV > 0 ? NV : 1); ++v) accv[v][tt][k] = 0.f;
+        }
 
-    f32x16 acc[3];
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-    const int pieces_per_row = (w + WG_KP - 1) / WG_KP;
-    const int total = B * h * pieces_per_row;
+    const int steps_per_row = (w + 15) / 16;
+    const int total = B * h * steps_per_row;
     const int per = (total + nsplit - 1) / nsplit;
     const int u0 = split * per, u1 = (u0 + per < total) ? u0 + per : total;
 
     for (int u = u0; u < u1; ++u) {
-        const int piece = u % pieces_per_row;
-        const int row = (u / pieces_per_row) % h;
-        const int n = u / (pieces_per_row * h);
-        const int x0 = piece * WG_KP;
-        const float* xn = x + ((size_t)n * Cin + cib) * hw;
-        const float* dyn = dy + (size_t)n * Cout * hw;
-        __syncthreads();                       // previous piece fully consumed
-        for (int idx = threadIdx.x; idx < 32 * WG_KP; idx += 256) {
-            const int co = idx / WG_KP, c = idx - co * WG_KP;
-            const int xx = x0 + c;
-            s_dy[co * WG_LDY + c] = (co < Cout && xx < w) ? dyn[(size_t)co * hw + row * w + xx] : 0.f;
+        const int st = u % steps_per_row;
+        const int row = (u / steps_per_row) % h;
+        const int n = u / (steps_per_row * h);
+        const int c0 = st * 16 + 4 * kq;                     // this lane's first pixel column
+        const float* dyn = dy + (size_t)n * Cout * hw + row * w;
+        const float* xn = x + ((size_t)n * Cin + cib + j) * hw;
+        // A: dY[co = j][c0..c0+3] (rows >= Cout are zero), VALU rows dY[16+v][...]
+        float av[4] = {0.f, 0.f, 0.f, 0.f};
+        float dv[NV > 0 ? NV : 1][4];
+        {
+            const bool full = c0 + 3 < w;
+            if (j < Cout) {
+                const float* p = dyn + (size_t)j * hw + c0;
+                if (full) { const f32x4u t = *reinterpret_cast<const f32x4u*>(p); av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w; }
+                else { for (int t = 0; t < 4; ++t) av[t] = (c0 + t < w) ? p[t] : 0.f; }
+            }
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const float* p = dyn + (size_t)(16 + v) * hw + c0;
+                if (16 + v < Cout) {
+                    if (full) { const f32x4u t = *reinterpret_cast<const f32x4u*>(p); dv[v][0] = t.x; dv[v][1] = t.y; dv[v][2] = t.z; dv[v][3] = t.w; }
+                    else { for (int t = 0; t < 4; ++t) dv[v][t] = (c0 + t < w) ? p[t] : 0.f; }
+                } else { dv[v][0] = dv[v][1] = dv[v][2] = dv[v][3] = 0.f; }
+            }
         }
-        const int span = WG_KP + 2 * d;
-        for (int idx = threadIdx.x; idx < 96 * span; idx += 256) {
-            const int pr = idx / span, c = idx - pr * span;
-            const int slab = pr >> 5, ci = pr & 31;
-            const int yy = row + (slab - 1) * d;
-            const int xx = x0 - d + c;
-            const bool in = yy >= 0 && yy < h && xx >= 0 && xx < w;
-            s_x[(slab * 32 + ci) * lxw + c] = in ? xn[(size_t)ci * hw + yy * w + xx] : 0.f;
+        // phase 1: issue every X load of the step (NTILE tiles x up to 9 taps), phase 2: the MFMAs
+        float bv[NTILE][NT][4];
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            int kk = k; kk += (kk >= 4 && k < 8) ? 1 : 0;     // ring index -> 3x3 position (skip centre)
+            const int oy = k == 8 ? 0 : (kk / 3 - 1) * d;
+            const int ox = k == 8 ? 0 : (kk % 3 - 1) * d;
+            const int yy = row + oy;
+            const bool rowok = (k < 8 || has_centre) && yy >= 0 && yy < h;   // wave-uniform
+            const int stc = st * 16 + ox;                    // first source column of the step
+            const bool edge = stc < 0 || stc + 15 >= w;      // wave-uniform
+            const int sc = c0 + ox;
+#pragma unroll
+            for (int tt = 0; tt < NTILE; ++tt) {
+                if (!rowok) {
+                    bv[tt][k][0] = bv[tt][k][1] = bv[tt][k][2] = bv[tt][k][3] = 0.f;
+                } else if (!edge) {
+                    const f32x4u t = *reinterpret_cast<const f32x4u*>(xn + (size_t)tt * 16 * hw + yy * w + sc);
+                    bv[tt][k][0] = t.x; bv[tt][k][1] = t.y; bv[tt][k][2] = t.z; bv[tt][k][3] = t.w;
+                } else {
+                    const float* p = xn + (size_t)tt * 16 * hw + yy * w + sc;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int cc = sc + t;
+                        const bool in = cc >= 0 && cc < w;
+                        const float vload = p[in ? t : -sc];  // redirect to column 0 of the row: valid address
+                        bv[tt][k][t] = in ? vload : 0.f;
+                    }
+                }
+            }
         }
-        __syncthreads();
-        const float* pa = s_dy + col * WG_LDY + ksub;
-        const float* pb0 = s_x + (t_row[0] * 32 + col) * lxw + d + t_dx[0] + ksub;
-        const float* pb1 = s_x + (t_row[1] * 32 + col) * lxw + d + t_dx[1] + ksub;
-        const float* pb2 = s_x + (32 + col) * lxw + d + ksub;
-#pragma unroll 8
-        for (int ks = 0; ks < WG_KP / 2; ++ks) {
-            const float a = pa[2 * ks];
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pb0[2 * ks], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pb1[2 * ks], acc[1], 0, 0, 0);
-            if (has_centre) acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pb2[2 * ks], acc[2], 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            if (k == 8 && !has_centre) continue;
+#pragma unroll
+            for (int tt = 0; tt < NTILE; ++tt)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    acc[tt][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[tt][k][t], acc[tt][k], 0, 0, 0);
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) accv[v][tt][k] = fmaf(dv[v][t], bv[tt][k][t], accv[v][tt][k]);
+                }
         }
     }
 
-    // partial[split][tap][co 32][Cin]
+    // partial[split][tap][co 32][Cin]; MFMA rows co = 4*kq + r, column ci = cib + 16*tt + j
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        if (t == 2 && !has_centre) continue;
-        const int tap = t == 2 ? 0 : 1 + 8 * g + 2 * wave + t;
-        float* dst = partial + (((size_t)split * NTAP + tap) * COP) * Cin + cib + col;
+    for (int k = 0; k < NT; ++k) {
+        if (k == 8 && !has_centre) continue;
+        const int tap = k == 8 ? 0 : 1 + 8 * g + k;
+        float* dst = partial + (((size_t)split * NTAP + tap) * COP) * Cin + cib + j;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = (r & 3) + 8 * (r >> 2) + 4 * ksub;
-            dst[(size_t)co * Cin] = acc[t][r];
+        for (int tt = 0; tt < NTILE; ++tt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(size_t)(4 * kq + r) * Cin + tt * 16] = acc[tt][k][r];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                float t = accv[v][tt][k];
+                t += __shfl_xor(t, 16, 64);
+                t += __shfl_xor(t, 32, 64);
+                if (kq == 0) dst[(size_t)(16 + v) * Cin + tt * 16] = t;
+            }
         }
     }
 }
@@ -462,18 +649,18 @@ __global__ __launch_bounds__(256) void aspp_db_kernel(const float* __restrict__ 
     if (threadIdx.x == 0) db[co] = (float)s[0];
 }
 
-static int pick_splitk(int B, int hw, int Cin, int MT)
+static int pick_splitk(int B, int hw, int Cin, int px_per_block)
 {
-    const int blocks = ((hw + 128 * MT - 1) / (128 * MT)) * B;
+    const int blocks = ((hw + px_per_block - 1) / px_per_block) * B;
     const char* env = getenv("HIAST_ASPP_SPLITK");          // tuning override
     if (env && atoi(env) > 0) {
         int s = atoi(env);
-        while (s > 1 && ((Cin / s) % KC != 0 || Cin % s != 0)) s >>= 1;
+        while (s > 1 && ((Cin / s) % KC16 != 0 || Cin % s != 0)) s >>= 1;
         return s > 8 ? 8 : s;
     }
     // >= 4 blocks (16 waves) per CU so that other waves' MFMAs cover a wave's load latency
     int s = 1;
-    while (blocks * s < 1024 && s < 8 && (Cin / (s * 2)) % KC == 0 && Cin / (s * 2) >= 64) s *= 2;
+    while (blocks * s < 1024 && s < 8 && (Cin / (s * 2)) % KC16 == 0 && Cin / (s * 2) >= 64) s *= 2;
     return s;
 }
 
@@ -487,9 +674,9 @@ extern "C" size_t hiast_aspp_wpack_bytes(int Cin, int Cout)
 
 static int wgrad_nsplit(int B, int h, int w)
 {
-    const int total = B * h * ((w + hiast::WG_KP - 1) / hiast::WG_KP);
-    int s = 8;
-    while (s > 1 && total / s < 16) s >>= 1;
+    const int total = B * h * ((w + 15) / 16);      // 16-pixel steps
+    int s = 16;
+    while (s > 1 && total / s < 32) s >>= 1;
     return s;
 }
 
@@ -531,27 +718,40 @@ extern "C" int hiast_aspp_fwd(const float* x, const float* wpack, float* y, int 
     int e = aspp_check(B, Cin, h, w, Cout);
     if (e) return e;
     const int hw = h * w;
-    constexpr int MT = 2;
-    const int splitk = hiast::pick_splitk(B, hw, Cin, MT);
     const hiast::Taps taps = hiast::make_taps(dil);
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((hw + 128 * MT - 1) / (128 * MT), B, splitk);
-    if (splitk == 1) {
-        hipLaunchKernelGGL(hiast::aspp_fwd_kernel<MT>, grid, dim3(256), 0, st, x, wpack, y, Cin, h, w,
-                           Cout, taps, Cin, 1);
-        HIAST_CHECK_LAUNCH();
-        return 0;
-    }
+    const bool narrow = Cout <= 19;                 // 16 MFMA rows + up to 3 VALU channels
+    constexpr int MT = 2, NP = 4;
+    const int px_per_block = narrow ? 4 * 16 * NP : 128 * MT;
+    const int splitk = hiast::pick_splitk(B, hw, Cin, px_per_block);
+    dim3 grid((hw + px_per_block - 1) / px_per_block, B, splitk);
     const long long per_split = (long long)B * Cout * hw;
-    if (!workspace || workspace_bytes < (size_t)splitk * per_split * sizeof(float)) return HIAST_E_WS;
-    float* partial = (float*)workspace;
-    hipLaunchKernelGGL(hiast::aspp_fwd_kernel<MT>, grid, dim3(256), 0, st, x, wpack, partial, Cin, h, w,
-                       Cout, taps, Cin / splitk, 0);
+    float* dst = y;
+    if (splitk > 1) {
+        if (!workspace || workspace_bytes < (size_t)splitk * per_split * sizeof(float)) return HIAST_E_WS;
+        dst = (float*)workspace;
+    }
+    const int cps = Cin / splitk, ab = splitk == 1 ? 1 : 0;
+#define F16(NV) hipLaunchKernelGGL((hiast::aspp_fwd16_kernel<NP, NV>), grid, dim3(256), 0, st, x, wpack, dst, Cin, \
+                                   h, w, Cout, taps, cps, ab)
+    if (narrow) {
+        switch (Cout > 16 ? Cout - 16 : 0) {
+            case 0: F16(0); break;
+            case 1: F16(1); break;
+            case 2: F16(2); break;
+            default: F16(3); break;
+        }
+    } else {
+        hipLaunchKernelGGL(hiast::aspp_fwd_kernel<MT>, grid, dim3(256), 0, st, x, wpack, dst, Cin, h, w, Cout,
+                           taps, cps, ab);
+    }
+#undef F16
     HIAST_CHECK_LAUNCH();
-    hipLaunchKernelGGL(hiast::aspp_reduce_kernel, dim3((unsigned)((per_split + 255) / 256)), dim3(256), 0,
-                       st, partial, wpack + (size_t)hiast::NTAP * Cin * hiast::COP, y, per_split, splitk,
-                       Cout, hw);
-    HIAST_CHECK_LAUNCH();
+    if (splitk > 1) {
+        hipLaunchKernelGGL(hiast::aspp_reduce_kernel, dim3((unsigned)((per_split + 255) / 256)), dim3(256), 0,
+                           st, dst, wpack + (size_t)hiast::NTAP * Cin * hiast::COP, y, per_split, splitk, Cout, hw);
+        HIAST_CHECK_LAUNCH();
+    }
     return 0;
 }
 
@@ -587,14 +787,27 @@ extern "C" int hiast_aspp_bwd_weight(const float* x, const float* dy, float* dw0
     if (dmax > 64) return HIAST_E_RANGE;
     const int nsplit = wgrad_nsplit(B, h, w);
     if (workspace_bytes < (size_t)nsplit * hiast::NTAP * hiast::COP * Cin * sizeof(float)) return HIAST_E_WS;
-    int lxw = hiast::WG_KP + 2 * dmax;
-    lxw |= 1;                                             // odd row pitch: conflict-free column reads
-    const size_t lds = (size_t)(32 * hiast::WG_LDY + 96 * lxw) * sizeof(float);
+    const char* envt = getenv("HIAST_ASPP_WG_NTILE");      // tuning override
+    const int ntile = (envt && atoi(envt) == 2) ? 2 : 1;
+    if (Cin % (64 * ntile) != 0 || Cout > 19) return HIAST_E_RANGE;
     hipStream_t st = (hipStream_t)stream;
     float* partial = (float*)workspace;
-    dim3 grid(Cin / 32, 4, nsplit);
-    hipLaunchKernelGGL(hiast::aspp_bwd_weight_kernel, grid, dim3(256), lds, st, x, dy, partial, B, Cin, h, w,
-                       Cout, dil[0], dil[1], dil[2], dil[3], nsplit, lxw);
+    // every (split, tap, co < Cout, ci) element of `partial` is written exactly once by the kernel
+    dim3 grid(Cin / (64 * ntile), 4, nsplit);
+#define WG(NV)                                                                                                  \
+    if (ntile == 2)                                                                                             \
+        hipLaunchKernelGGL((hiast::aspp_bwd_weight_kernel<NV, 2>), grid, dim3(256), 0, st, x, dy, partial, B, Cin, \
+                           h, w, Cout, dil[0], dil[1], dil[2], dil[3], nsplit);                                  \
+    else                                                                                                        \
+        hipLaunchKernelGGL((hiast::aspp_bwd_weight_kernel<NV, 1>), grid, dim3(256), 0, st, x, dy, partial, B, Cin, \
+                           h, w, Cout, dil[0], dil[1], dil[2], dil[3], nsplit)
+    switch (Cout > 16 ? Cout - 16 : 0) {
+        case 0: WG(0); break;
+        case 1: WG(1); break;
+        case 2: WG(2); break;
+        default: WG(3); break;
+    }
+#undef WG
     HIAST_CHECK_LAUNCH();
     const long long total = 4ll * Cout * Cin * 9;
     hipLaunchKernelGGL(hiast::aspp_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,

@@ -41,6 +41,11 @@ class DeepLab_V2(nn.Module):
         self.backbone = build_resnet101(pretrained=False, output_stride=8)
         self.aspp = ASPP_V2([6, 12, 18, 24], [6, 12, 18, 24], num_classes)
         self.representation = nn.Sequential(nn.Conv2d(2048, output_dim, 1))
+        # dead branch: its output is discarded by the reference, so it never receives a gradient there
+        # either (grad is None, Adam skips it).  Marking it non-trainable keeps DDP's reducer from waiting
+        # for gradients that cannot arrive; the parameters stay in the state dict.
+        for p in self.representation.parameters():
+            p.requires_grad = False
 
     def forward(self, x):
         feat = self.backbone(x)            # [B, 2048, H/8, W/8]
