@@ -515,74 +515,76 @@ __global__ __launch_bounds__(256) void aspp_bwd_weight_kernel(const float* __res
     const int per = (total + nsplit - 1) / nsplit;
     const int u0 = split * per, u1 = (u0 + per < total) ? u0 + per : total;
 
+    // The loop walks INPUT rows r: the X vector x[ci][r][c0+ox..] (3 column shifts) is fetched once and
+    // meets dY of the three output rows y = r - oy that use it, so each X row leaves L2 once per dilation
+    // instead of three times (an output-row loop re-fetched every row 3x per dilation: 10x HBM over-fetch
+    // in the PMC profile).
     for (int u = u0; u < u1; ++u) {
         const int st = u % steps_per_row;
-        const int row = (u / steps_per_row) % h;
+        const int row = (u / steps_per_row) % h;             // input row r
         const int n = u / (steps_per_row * h);
         const int c0 = st * 16 + 4 * kq;                     // this lane's first pixel column
-        const float* dyn = dy + (size_t)n * Cout * hw + row * w;
-        const float* xn = x + ((size_t)n * Cin + cib + j) * hw;
-        // A: dY[co = j][c0..c0+3] (rows >= Cout are zero), VALU rows dY[16+v][...]
-        float av[4] = {0.f, 0.f, 0.f, 0.f};
-        float dv[NV > 0 ? NV : 1][4];
-        {
-            const bool full = c0 + 3 < w;
-            if (j < Cout) {
-                const float* p = dyn + (size_t)j * hw + c0;
-                if (full) { const f32x4u t = *reinterpret_cast<const f32x4u*>(p); av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w; }
-                else { for (int t = 0; t < 4; ++t) av[t] = (c0 + t < w) ? p[t] : 0.f; }
-            }
+        const float* dyn = dy + (size_t)n * Cout * hw;
+        const float* xr = x + ((size_t)n * Cin + cib + j) * hw + row * w;
+        const bool full = c0 + 3 < w;
+
+        float bv[NTILE][3][4];
 #pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                const float* p = dyn + (size_t)(16 + v) * hw + c0;
-                if (16 + v < Cout) {
-                    if (full) { const f32x4u t = *reinterpret_cast<const f32x4u*>(p); dv[v][0] = t.x; dv[v][1] = t.y; dv[v][2] = t.z; dv[v][3] = t.w; }
-                    else { for (int t = 0; t < 4; ++t) dv[v][t] = (c0 + t < w) ? p[t] : 0.f; }
-                } else { dv[v][0] = dv[v][1] = dv[v][2] = dv[v][3] = 0.f; }
-            }
-        }
-        // phase 1: issue every X load of the step (NTILE tiles x up to 9 taps), phase 2: the MFMAs
-        float bv[NTILE][NT][4];
-#pragma unroll
-        for (int k = 0; k < NT; ++k) {
-            int kk = k; kk += (kk >= 4 && k < 8) ? 1 : 0;     // ring index -> 3x3 position (skip centre)
-            const int oy = k == 8 ? 0 : (kk / 3 - 1) * d;
-            const int ox = k == 8 ? 0 : (kk % 3 - 1) * d;
-            const int yy = row + oy;
-            const bool rowok = (k < 8 || has_centre) && yy >= 0 && yy < h;   // wave-uniform
+        for (int sx = 0; sx < 3; ++sx) {
+            const int ox = (sx - 1) * d;
             const int stc = st * 16 + ox;                    // first source column of the step
             const bool edge = stc < 0 || stc + 15 >= w;      // wave-uniform
             const int sc = c0 + ox;
 #pragma unroll
             for (int tt = 0; tt < NTILE; ++tt) {
-                if (!rowok) {
-                    bv[tt][k][0] = bv[tt][k][1] = bv[tt][k][2] = bv[tt][k][3] = 0.f;
-                } else if (!edge) {
-                    const f32x4u t = *reinterpret_cast<const f32x4u*>(xn + (size_t)tt * 16 * hw + yy * w + sc);
-                    bv[tt][k][0] = t.x; bv[tt][k][1] = t.y; bv[tt][k][2] = t.z; bv[tt][k][3] = t.w;
+                const float* p = xr + (size_t)tt * 16 * hw + sc;
+                if (!edge) {
+                    const f32x4u t = *reinterpret_cast<const f32x4u*>(p);
+                    bv[tt][sx][0] = t.x; bv[tt][sx][1] = t.y; bv[tt][sx][2] = t.z; bv[tt][sx][3] = t.w;
                 } else {
-                    const float* p = xn + (size_t)tt * 16 * hw + yy * w + sc;
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const int cc = sc + t;
                         const bool in = cc >= 0 && cc < w;
                         const float vload = p[in ? t : -sc];  // redirect to column 0 of the row: valid address
-                        bv[tt][k][t] = in ? vload : 0.f;
+                        bv[tt][sx][t] = in ? vload : 0.f;
                     }
                 }
             }
         }
 #pragma unroll
-        for (int k = 0; k < NT; ++k) {
-            if (k == 8 && !has_centre) continue;
+        for (int qy = 0; qy < 3; ++qy) {
+            const int y = row - (qy - 1) * d;                // output row whose tap (qy, *) reads input row r
+            if (y < 0 || y >= h) continue;                   // wave-uniform
+            float av[4] = {0.f, 0.f, 0.f, 0.f};
+            float dv[NV > 0 ? NV : 1][4];
+            if (j < Cout) {
+                const float* p = dyn + (size_t)j * hw + y * w + c0;
+                if (full) { const f32x4u t = *reinterpret_cast<const f32x4u*>(p); av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w; }
+                else { for (int t = 0; t < 4; ++t) av[t] = (c0 + t < w) ? p[t] : 0.f; }
+            }
 #pragma unroll
-            for (int tt = 0; tt < NTILE; ++tt)
+            for (int v = 0; v < NV; ++v) {
+                const float* p = dyn + (size_t)(16 + v) * hw + y * w + c0;
+                if (16 + v < Cout) {
+                    if (full) { const f32x4u t = *reinterpret_cast<const f32x4u*>(p); dv[v][0] = t.x; dv[v][1] = t.y; dv[v][2] = t.z; dv[v][3] = t.w; }
+                    else { for (int t = 0; t < 4; ++t) dv[v][t] = (c0 + t < w) ? p[t] : 0.f; }
+                } else { dv[v][0] = dv[v][1] = dv[v][2] = dv[v][3] = 0.f; }
+            }
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    acc[tt][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[tt][k][t], acc[tt][k], 0, 0, 0);
+            for (int sx = 0; sx < 3; ++sx) {
+                const int pos = qy * 3 + sx;
+                if (pos == 4 && !has_centre) continue;
+                const int k = pos == 4 ? 8 : (pos < 4 ? pos : pos - 1);
 #pragma unroll
-                    for (int v = 0; v < NV; ++v) accv[v][tt][k] = fmaf(dv[v][t], bv[tt][k][t], accv[v][tt][k]);
-                }
+                for (int tt = 0; tt < NTILE; ++tt)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        acc[tt][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[tt][sx][t], acc[tt][k], 0, 0, 0);
+#pragma unroll
+                        for (int v = 0; v < NV; ++v) accv[v][tt][k] = fmaf(dv[v][t], bv[tt][sx][t], accv[v][tt][k]);
+                    }
+            }
         }
     }
 

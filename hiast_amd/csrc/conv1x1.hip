@@ -1,0 +1,243 @@
+// K9a — 1x1 bottleneck projections of the ResNet trunk for the fp32 (pseudo-label) forward, as ONE
+// fused kernel: GEMM + BatchNorm(eval) + residual add + ReLU
+// (reference: Bottleneck.forward, sseg/models/modules/resnet.py:78-98: conv1 -> bn1 -> relu and
+//  conv3 -> bn3 -> += identity -> relu, each a separate cuDNN / ATen pass there).
+//
+//   Y[m][n] = act( (Σ_k X[m][k] * W[n][k]) * scale_n + shift_n (+ R[m][n]) )
+//   X: [M = B*H*W pixels][K = Cin]  fp32, NHWC (channels-last) activations
+//   W: [N = Cout][K]                fp32 (the conv weight [Cout,Cin,1,1] as stored)
+//
+// Arithmetic: "split-bf16": every fp32 operand is split on the fly into hi = bf16(v) and
+// lo = bf16(v - hi); the product is accumulated in fp32 as hi*hi + hi*lo + lo*hi on
+// v_mfma_f32_32x32x16_bf16 (the dropped lo*lo term is 2^-16 relative).  Measured |err| vs fp64 is
+// ~5e-6 of max|Y| (fp32 MFMA: ~2e-6; plain bf16: 2e-3), well inside the 1e-3 logits contract, at
+// 3/16 of the fp32-MFMA cost: gfx950 has no TF32/xf32 path, this is the fast exact-class option.
+//
+// Structure: 128 x BN block tile (BN = 128 or 64), BK = 32, 4 waves as 2 x 2 (wave tile 64 x BN/2),
+// register-staged global loads (fp32 -> hi/lo happens between the load and the LDS write), LDS double
+// buffered with one barrier per k-step, rows padded to 80 B so ds_read_b128 fragments are conflict free.
+#include <hip/hip_bf16.h>
+
+#include "common.h"
+
+namespace hiast {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int C1_BM = 128;
+constexpr int C1_BK = 32;
+constexpr int C1_PITCH = 40;      // bf16 elements per LDS row (32 + 8 pad) = 80 bytes
+
+__device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo)
+{
+    const float f[4] = {v.x, v.y, v.z, v.w};
+    unsigned short h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const __hip_bfloat16 hb = __float2bfloat16(f[i]);
+        const float hf = __bfloat162float(hb);
+        const __hip_bfloat16 lb = __float2bfloat16(f[i] - hf);
+        h[i] = __bfloat16_as_ushort(hb);
+        l[i] = __bfloat16_as_ushort(lb);
+    }
+    hi = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+    lo = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+}
+
+template <int BN, bool RES, bool RELU>
+__global__ __launch_bounds__(256) void conv1x1_bn_act_kernel(
+    const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ var, float eps,
+    const float* __restrict__ R, float* __restrict__ Y, int M, int K, int N)
+{
+    constexpr int TN = BN / 64;                       // 32-wide column tiles per wave (2 or 1)
+    constexpr int A_F4 = C1_BM * C1_BK / 4 / 256;     // float4 per thread per k-step (4)
+    constexpr int B_F4 = BN * C1_BK / 4 / 256;        // 4 or 2
+    // [buf][A_hi | A_lo | B_hi | B_lo]
+    constexpr int A_BYTES = C1_BM * C1_PITCH * 2, B_BYTES = BN * C1_PITCH * 2;
+    constexpr int BUF_BYTES = 2 * A_BYTES + 2 * B_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * C1_BM, n0 = blockIdx.y * BN;
+    const int nk = K / C1_BK;
+
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // global -> register staging: float4 index f = tid + 256*i; row = f / 8, c4 = f % 8
+    float4 ra[A_F4], rb[B_F4];
+    auto gload = [&](int kt) {
+        const int k0 = kt * C1_BK;
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int f = tid + 256 * i, row = f >> 3, c4 = f & 7;
+            int m = m0 + row;
+            m = m < M ? m : M - 1;                                   // tail rows: valid address, never stored
+            ra[i] = *reinterpret_cast<const float4*>(X + (size_t)m * K + k0 + c4 * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) {
+            const int f = tid + 256 * i, row = f >> 3, c4 = f & 7;
+            rb[i] = *reinterpret_cast<const float4*>(W + (size_t)(n0 + row) * K + k0 + c4 * 4);
+        }
+    };
+    auto lds_store = [&](int buf) {
+        unsigned char* base = smem + buf * BUF_BYTES;
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int f = tid + 256 * i, row = f >> 3, c4 = f & 7;
+            uint2 hi, lo;
+            split4(ra[i], hi, lo);
+            *reinterpret_cast<uint2*>(base + (row * C1_PITCH + c4 * 4) * 2) = hi;
+            *reinterpret_cast<uint2*>(base + A_BYTES + (row * C1_PITCH + c4 * 4) * 2) = lo;
+        }
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) {
+            const int f = tid + 256 * i, row = f >> 3, c4 = f & 7;
+            uint2 hi, lo;
+            split4(rb[i], hi, lo);
+            *reinterpret_cast<uint2*>(base + 2 * A_BYTES + (row * C1_PITCH + c4 * 4) * 2) = hi;
+            *reinterpret_cast<uint2*>(base + 2 * A_BYTES + B_BYTES + (row * C1_PITCH + c4 * 4) * 2) = lo;
+        }
+    };
+
+    gload(0);
+    lds_store(0);
+    __syncthreads();
+
+    const int frow = lane & 31, fk = (lane >> 5) * 8;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        const unsigned char* base = smem + buf * BUF_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < C1_BK / 16; ++kk) {
+            bf16x8 ah[2], al[2], bh[TN], bl[TN];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int off = ((wm * 64 + a * 32 + frow) * C1_PITCH + kk * 16 + fk) * 2;
+                ah[a] = *reinterpret_cast<const bf16x8*>(base + off);
+                al[a] = *reinterpret_cast<const bf16x8*>(base + A_BYTES + off);
+            }
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int off = ((wn * (BN / 2) + b * 32 + frow) * C1_PITCH + kk * 16 + fk) * 2;
+                bh[b] = *reinterpret_cast<const bf16x8*>(base + 2 * A_BYTES + off);
+                bl[b] = *reinterpret_cast<const bf16x8*>(base + 2 * A_BYTES + B_BYTES + off);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+                }
+        }
+        if (kt + 1 < nk) lds_store(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: D row (pixel) = (r&3) + 8*(r>>2) + 4*(lane>>5), column (channel) = lane & 31
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int n = n0 + wn * (BN / 2) + b * 32 + (lane & 31);
+        const float invstd = 1.0f / sqrtf(var[n] + eps);
+        const float sc = (gamma ? gamma[n] : 1.0f) * invstd;
+        const float sh = fmaf(-mean[n], sc, beta ? beta[n] : 0.0f);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < M) {
+                    float o = fmaf(acc[a][b][r], sc, sh);
+                    if (RES) o += R[(size_t)m * N + n];
+                    if (RELU) o = o > 0.f ? o : 0.f;
+                    Y[(size_t)m * N + n] = o;
+                }
+            }
+        }
+    }
+}
+
+// NHWC BatchNorm(eval) (+ReLU) for the activations that come out of the library 3x3 / 7x7 convolutions:
+// y[m][c] = act(x[m][c]*scale_c + shift_c), 4 channels per thread (float4), C % 4 == 0.
+template <bool RELU>
+__global__ __launch_bounds__(256) void bn_act_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta,
+                                                          const float* __restrict__ mean,
+                                                          const float* __restrict__ var, float eps,
+                                                          long long total4, int C)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const int c = (int)((i * 4) % C);
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float invstd = 1.0f / sqrtf(var[c + k] + eps);
+            const float sc = (gamma ? gamma[c + k] : 1.0f) * invstd;
+            const float sh = fmaf(-mean[c + k], sc, beta ? beta[c + k] : 0.0f);
+            float t = fmaf(o[k], sc, sh);
+            o[k] = RELU ? (t > 0.f ? t : 0.f) : t;
+        }
+        reinterpret_cast<float4*>(y)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+}  // namespace hiast
+
+extern "C" int hiast_conv1x1_bn_act_nhwc(const float* x, const float* w, const float* gamma, const float* beta,
+                                         const float* mean, const float* var, float eps, const float* res,
+                                         int relu, float* y, int64_t M, int K, int N, hiast_stream_t stream)
+{
+    if (!x || !w || !mean || !var || !y) return HIAST_E_ARG;
+    if (M <= 0 || K <= 0 || N <= 0) return HIAST_E_ARG;
+    if (K % hiast::C1_BK != 0 || N % 64 != 0 || M > (1ll << 31) - 256) return HIAST_E_RANGE;
+    if ((((uintptr_t)x) | ((uintptr_t)w)) & 15) return HIAST_E_RANGE;
+    hipStream_t st = (hipStream_t)stream;
+    const int BN = (N % 128 == 0) ? 128 : 64;
+    dim3 grid((unsigned)((M + hiast::C1_BM - 1) / hiast::C1_BM), N / BN);
+#define L(BNV, RES, RELU)                                                                                       \
+    hipLaunchKernelGGL((hiast::conv1x1_bn_act_kernel<BNV, RES, RELU>), grid, dim3(256), 0, st, x, w, gamma, beta, \
+                       mean, var, eps, res, y, (int)M, K, N)
+#define LL(BNV)                                                   \
+    if (res) { if (relu) L(BNV, true, true); else L(BNV, true, false); } \
+    else { if (relu) L(BNV, false, true); else L(BNV, false, false); }
+    if (BN == 128) { LL(128) } else { LL(64) }
+#undef LL
+#undef L
+    HIAST_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int hiast_bn_act_nhwc_infer(const float* x, float* y, const float* gamma, const float* beta,
+                                       const float* mean, const float* var, float eps, int relu, int64_t M,
+                                       int C, hiast_stream_t stream)
+{
+    if (!x || !y || !mean || !var) return HIAST_E_ARG;
+    if (M <= 0 || C <= 0) return HIAST_E_ARG;
+    if (C % 4 != 0 || ((((uintptr_t)x) | ((uintptr_t)y)) & 15)) return HIAST_E_RANGE;
+    const long long total4 = (long long)M * C / 4;
+    long long nb = (total4 + 256 * 4 - 1) / (256 * 4);
+    const int grid = (int)(nb < 1 ? 1 : (nb > 4096 ? 4096 : nb));
+    hipStream_t st = (hipStream_t)stream;
+    if (relu)
+        hipLaunchKernelGGL(hiast::bn_act_nhwc_kernel<true>, dim3(grid), dim3(256), 0, st, x, y, gamma, beta, mean,
+                           var, eps, total4, C);
+    else
+        hipLaunchKernelGGL(hiast::bn_act_nhwc_kernel<false>, dim3(grid), dim3(256), 0, st, x, y, gamma, beta, mean,
+                           var, eps, total4, C);
+    HIAST_CHECK_LAUNCH();
+    return 0;
+}

@@ -333,3 +333,34 @@ def bn_act_bwd_apply(dy, y, x, gamma, save_mean, save_invstd, part, count, relu,
                                              int(bool(relu)), _ptr(dx), _ptr(dres), _ptr(dg), _ptr(db), B, C, HW,
                                              _bn_dtype(x), _stream()), "hiast_bn_act_bwd_apply")
     return dx, dres, dg, db
+
+
+# ------------------------------------------------------------------------------- K9a NHWC fp32 eval path
+def conv1x1_bn_act_nhwc(x2d, weight, bn, res2d=None, relu=True):
+    """x2d [M,K] fp32 (NHWC activations flattened), weight [N,K,1,1] or [N,K] fp32, bn: a BatchNorm2d in eval
+    mode (running statistics) -> y [M,N] fp32."""
+    _req(x2d, torch.float32, 2, "x2d")
+    M, K_ = x2d.shape
+    w = weight.reshape(weight.shape[0], -1)
+    _req(w, torch.float32, 2, "weight")
+    N = w.shape[0]
+    assert w.shape[1] == K_
+    if res2d is not None:
+        _req(res2d, torch.float32, 2, "res2d")
+        assert tuple(res2d.shape) == (M, N)
+    y = torch.empty((M, N), dtype=torch.float32, device=x2d.device)
+    check(_lib.load().hiast_conv1x1_bn_act_nhwc(_ptr(x2d), _ptr(w), _ptr(bn.weight), _ptr(bn.bias),
+                                                _ptr(bn.running_mean), _ptr(bn.running_var), float(bn.eps),
+                                                _ptr(res2d), int(bool(relu)), _ptr(y), M, K_, N, _stream()),
+          "hiast_conv1x1_bn_act_nhwc")
+    return y
+
+
+def bn_act_nhwc_infer(x2d, bn, relu=True):
+    _req(x2d, torch.float32, 2, "x2d")
+    M, C = x2d.shape
+    y = torch.empty_like(x2d)
+    check(_lib.load().hiast_bn_act_nhwc_infer(_ptr(x2d), _ptr(y), _ptr(bn.weight), _ptr(bn.bias),
+                                              _ptr(bn.running_mean), _ptr(bn.running_var), float(bn.eps),
+                                              int(bool(relu)), M, C, _stream()), "hiast_bn_act_nhwc_infer")
+    return y

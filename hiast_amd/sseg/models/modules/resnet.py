@@ -3,6 +3,7 @@
 conv{1,2,3}/bn{1,2,3}/downsample.{0,1}) so released checkpoints load key-for-key.
 Round 1: convolutions/BN run on PyTorch-ROCm (MIOpen); hand-written MFMA kernels for the
 layer3/4 bottlenecks are the next row of the scope table."""
+import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -17,6 +18,17 @@ def bn_act(bn, x, res=None, relu=True):
     if res is not None:
         y = y + res
     return F.relu(y) if relu else y
+
+
+def _nhwc2d(t):
+    """logical NCHW tensor with channels-last strides -> zero-copy [B*H*W, C] view"""
+    B, C, H, W = t.shape
+    return t.permute(0, 2, 3, 1).reshape(B * H * W, C)
+
+
+def _from2d(y2d, B, H, W):
+    """[B*H*W, C] -> logical NCHW tensor with channels-last strides (zero-copy)"""
+    return y2d.view(B, H, W, y2d.shape[1]).permute(0, 3, 1, 2)
 
 
 class Bottleneck(nn.Module):
@@ -38,6 +50,28 @@ class Bottleneck(nn.Module):
         o = bn_act(self.bn1, self.conv1(x))
         o = bn_act(self.bn2, self.conv2(o))
         return bn_act(self.bn3, self.conv3(o), res=idt)        # += identity, ReLU
+
+    def forward_eval_nhwc(self, x):
+        """fp32 inference on channels-last activations (pseudo-label forward): the two 1x1 convs run as the
+        fused split-bf16 GEMM + BN + (residual) + ReLU kernel (hiast_conv1x1_bn_act_nhwc); the 3x3 conv
+        stays on the library, followed by the channels-last BN+ReLU kernel."""
+        from hiast_amd import kernels as K
+        B, _, H, W = x.shape
+        x2d = _nhwc2d(x)
+        o = K.conv1x1_bn_act_nhwc(x2d, self.conv1.weight, self.bn1, None, True)
+        o = F.conv2d(_from2d(o, B, H, W), self.conv2.weight, None, self.conv2.stride, self.conv2.padding,
+                     self.conv2.dilation)
+        Ho, Wo = o.shape[2:]
+        o = K.bn_act_nhwc_infer(_nhwc2d(o), self.bn2, True)
+        if self.downsample is None:
+            idt = x2d
+        else:
+            dconv, dbn = self.downsample[0], self.downsample[1]
+            xs = x if dconv.stride == (1, 1) else x[:, :, ::dconv.stride[0], ::dconv.stride[1]].contiguous(
+                memory_format=torch.channels_last)
+            idt = K.conv1x1_bn_act_nhwc(_nhwc2d(xs), dconv.weight, dbn, None, False)
+        out = K.conv1x1_bn_act_nhwc(o, self.conv3.weight, self.bn3, idt, True)
+        return _from2d(out, B, Ho, Wo)
 
 
 class ResNet(nn.Module):
@@ -72,7 +106,25 @@ class ResNet(nn.Module):
         blocks += [Bottleneck(self.inplanes, planes, 1, dil[1]) for _ in range(1, n)]
         return nn.Sequential(*blocks)
 
+    def _fast_eval_ok(self, x):
+        return (not self.training and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()
+                and not torch.is_grad_enabled())
+
+    def forward_eval_nhwc(self, x):
+        from hiast_amd import kernels as K
+        x = x.contiguous(memory_format=torch.channels_last)
+        o = self.conv1(x)
+        B, _, H, W = o.shape
+        o = _from2d(K.bn_act_nhwc_infer(_nhwc2d(o), self.bn1, True), B, H, W)
+        o = self.maxpool(o)
+        for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for blk in stage:
+                o = blk.forward_eval_nhwc(o)
+        return o.contiguous()            # back to NCHW for the ASPP kernel
+
     def forward(self, x, is_return_low=False):
+        if not is_return_low and self._fast_eval_ok(x):
+            return self.forward_eval_nhwc(x)
         x = self.maxpool(bn_act(self.bn1, self.conv1(x)))
         low = self.layer1(x)
         x = self.layer4(self.layer3(self.layer2(low)))

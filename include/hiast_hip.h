@@ -162,6 +162,21 @@ int hiast_bn_act_bwd_apply(const void* dy, const void* y, const void* x, const f
                            double count, int relu, void* dx, void* dres, float* dgamma, float* dbeta, int B,
                            int C, int64_t HW, int dtype, hiast_stream_t stream);
 
+/* ---- K9a: 1x1 bottleneck convolution + BN(eval) + residual + ReLU (fp32 pseudo-label forward) ------
+ * conv1 -> bn1 -> relu and conv3 -> bn3 -> (+= identity) -> relu of Bottleneck.forward,
+ * sseg/models/modules/resnet.py:78-98, as ONE kernel on channels-last activations:
+ *   y[m][n] = act((Σ_k x[m][k]*w[n][k]) * gamma_n/sqrt(var_n+eps) + (beta_n - mean_n*...) (+ res[m][n]))
+ * x [M = B*H*W][K = Cin] fp32 (NHWC), w [N = Cout][K] fp32 (the conv weight as stored), res/y [M][N] fp32.
+ * Split-bf16 arithmetic (hi*hi + hi*lo + lo*hi on bf16 MFMA, fp32 accumulate): ~5e-6 of max|y| vs fp64,
+ * i.e. fp32-class results at 3/16 of the fp32-MFMA cost.  K % 32 == 0, N % 64 == 0, 16-byte aligned x, w.
+ * hiast_bn_act_nhwc_infer: y[m][c] = act(x[m][c]*scale_c + shift_c) for the outputs of the library
+ * 3x3 / 7x7 convolutions on the same channels-last path (C % 4 == 0). */
+int hiast_conv1x1_bn_act_nhwc(const float* x, const float* w, const float* gamma, const float* beta,
+                              const float* mean, const float* var, float eps, const float* res, int relu,
+                              float* y, int64_t M, int K, int N, hiast_stream_t stream);
+int hiast_bn_act_nhwc_infer(const float* x, float* y, const float* gamma, const float* beta, const float* mean,
+                            const float* var, float eps, int relu, int64_t M, int C, hiast_stream_t stream);
+
 /* ---- K11: EMA teacher update ---------------------------------------------------------
  * utils/utils.py:115-123 update_ema_model: ema = ema*gamma + p*(1-gamma) over a list of
  * tensors in ONE launch (gamma, one_minus_gamma: the float32 roundings of the Python

@@ -376,3 +376,42 @@ def test_trunk_fused_matches_plain_modules(K):
         want, _ = deeplab_ref.deeplab_v2(xb, sd, train=True)
     err = (pred.cpu() - want).abs().max() / want.abs().max()
     assert err < 2e-3, float(err)
+
+
+@pytest.mark.parametrize("shape", [(4096, 256, 64), (1000, 64, 256), (8192, 1024, 256), (300, 2048, 512)])
+@pytest.mark.parametrize("res,relu", [(False, True), (True, True), (False, False)])
+def test_conv1x1_split_bf16_vs_fp64(K, shape, res, relu):
+    """fused 1x1 conv + BN(eval) + residual + ReLU (split-bf16 MFMA) vs float64: <= 3e-5 of max|y|
+    (fp32-class; the contract for logits is 1e-3)."""
+    M, Kd, N = shape
+    x = synth.normal_f32(201, (M, Kd), 1.0)
+    w = synth.normal_f32(202, (N, Kd), (2.0 / Kd) ** 0.5)
+    r = synth.normal_f32(203, (M, N), 1.0) if res else None
+    bn = torch.nn.BatchNorm2d(N).cuda().eval()
+    with torch.no_grad():
+        bn.weight.copy_(torch.from_numpy(1 + synth.normal_f32(204, (N,), 0.2)))
+        bn.bias.copy_(torch.from_numpy(synth.normal_f32(205, (N,), 0.2)))
+        bn.running_mean.copy_(torch.from_numpy(synth.normal_f32(206, (N,), 0.3)))
+        bn.running_var.copy_(torch.from_numpy(0.5 + synth.rng(207).random(N, dtype=np.float32)))
+    y = K.conv1x1_bn_act_nhwc(dev(x), dev(w), bn, dev(r) if res else None, relu).cpu().double()
+    sc = bn.weight.double().cpu() / torch.sqrt(bn.running_var.double().cpu() + bn.eps)
+    sh = bn.bias.double().cpu() - bn.running_mean.double().cpu() * sc
+    want = (torch.from_numpy(x).double() @ torch.from_numpy(w).double().t()) * sc + sh
+    if res:
+        want = want + torch.from_numpy(r).double()
+    if relu:
+        want = torch.relu(want)
+    assert (y - want).abs().max() <= 3e-5 * want.abs().max()
+
+
+def test_bn_act_nhwc_infer(K):
+    M, C = 1234, 64
+    x = synth.normal_f32(211, (M, C), 2.0)
+    bn = torch.nn.BatchNorm2d(C).cuda().eval()
+    with torch.no_grad():
+        bn.running_mean.copy_(torch.from_numpy(synth.normal_f32(212, (C,), 0.3)))
+        bn.running_var.copy_(torch.from_numpy(0.5 + synth.rng(213).random(C, dtype=np.float32)))
+        bn.weight.copy_(torch.from_numpy(1 + synth.normal_f32(214, (C,), 0.2)))
+    y = K.bn_act_nhwc_infer(dev(x), bn, True)
+    want = torch.relu(bn(dev(x).t().reshape(1, C, M, 1))).reshape(C, M).t()
+    assert torch.allclose(y, want, rtol=1e-5, atol=1e-5)
