@@ -146,26 +146,46 @@ __global__ __launch_bounds__(256) void conv1x1_bn_act_kernel(
         __syncthreads();
     }
 
-    // epilogue: D row (pixel) = (r&3) + 8*(r>>2) + 4*(lane>>5), column (channel) = lane & 31
+    // epilogue through LDS (the staging buffers are free now): accumulators -> fp32 tile [128][BN+4] with
+    // the BN scale/shift applied, then every thread moves float4s along the channel axis, so the
+    // residual read and the output write are whole 512-byte row segments (16 B per lane) instead of
+    // 4-byte accesses (the K <= 256 "expanding" convs are bound by exactly this traffic).
+    constexpr int CP = BN + 4;
+    float* sC = reinterpret_cast<float*>(smem);
+    static_assert(C1_BM * CP * 4 <= 2 * BUF_BYTES, "epilogue tile must fit the staging buffers");
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
-        const int n = n0 + wn * (BN / 2) + b * 32 + (lane & 31);
+        const int nl = wn * (BN / 2) + b * 32 + (lane & 31);
+        const int n = n0 + nl;
         const float invstd = 1.0f / sqrtf(var[n] + eps);
         const float sc = (gamma ? gamma[n] : 1.0f) * invstd;
         const float sh = fmaf(-mean[n], sc, beta ? beta[n] : 0.0f);
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m < M) {
-                    float o = fmaf(acc[a][b][r], sc, sh);
-                    if (RES) o += R[(size_t)m * N + n];
-                    if (RELU) o = o > 0.f ? o : 0.f;
-                    Y[(size_t)m * N + n] = o;
-                }
+                const int ml = wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                sC[ml * CP + nl] = fmaf(acc[a][b][r], sc, sh);
             }
+    }
+    __syncthreads();
+    constexpr int F4_PER_ROW = BN / 4;
+#pragma unroll 4
+    for (int f = tid; f < C1_BM * F4_PER_ROW; f += 256) {
+        const int ml = f / F4_PER_ROW, c4 = f - ml * F4_PER_ROW;
+        const int m = m0 + ml;
+        if (m >= M) continue;
+        float4 o = *reinterpret_cast<const float4*>(sC + ml * CP + c4 * 4);
+        const size_t g = (size_t)m * N + n0 + c4 * 4;
+        if (RES) {
+            const float4 rr = *reinterpret_cast<const float4*>(R + g);
+            o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
         }
+        if (RELU) {
+            o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f;
+            o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
+        }
+        *reinterpret_cast<float4*>(Y + g) = o;
     }
 }
 

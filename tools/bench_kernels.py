@@ -92,3 +92,25 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def bench_conv1x1():
+    import torch
+    dev = torch.device("cuda")
+    for (M, Kd, N, res) in [(65536, 1024, 256, False), (65536, 256, 1024, True), (65536, 2048, 512, False),
+                            (65536, 512, 2048, True), (262144, 256, 64, False), (262144, 64, 256, True),
+                            (65536, 512, 128, False), (65536, 128, 512, True)]:
+        x = torch.randn(M, Kd, device=dev)
+        w = torch.randn(N, Kd, device=dev) * 0.05
+        r = torch.randn(M, N, device=dev) if res else None
+        bn = torch.nn.BatchNorm2d(N).to(dev).eval()
+        med, best = timeit(lambda: K.conv1x1_bn_act_nhwc(x, w, bn, r, True))
+        fl = 2.0 * M * Kd * N / 1e9
+        byt = (M * Kd + M * N * (2 if res else 1) + N * Kd) * 4 / 1e9
+        f32 = timeit(lambda: torch.mm(x, w.t()))[0]
+        print("conv1x1 M%d K%d N%d res=%d: %7.3f ms  %6.1f TF/s fp32-equiv (%.0f TF/s bf16 MFMA)  %5.2f TB/s | torch.mm fp32 %7.3f ms"
+              % (M, Kd, N, res, med, fl / med, 3 * fl / med, byt / med, f32))
+
+
+if __name__ == "__main__" and len(sys.argv) > 2 and "conv1x1" in sys.argv[2]:
+    bench_conv1x1()
