@@ -45,11 +45,17 @@ __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo)
     lo = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
 }
 
-template <int BN, bool RES, bool RELU>
+// geometry of the 3x3 variant (TAPS == 9): input H x W, output Ho x Wo, stride, dilation (padding = dilation);
+// K is then the number of input channels and the GEMM reduction runs over 9 taps x K
+struct ConvGeo {
+    int H, W, Ho, Wo, stride, dil;
+};
+
+template <int BN, int TAPS, bool RES, bool RELU>
 __global__ __launch_bounds__(256) void conv1x1_bn_act_kernel(
     const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ var, float eps,
-    const float* __restrict__ R, float* __restrict__ Y, int M, int K, int N)
+    const float* __restrict__ R, float* __restrict__ Y, int M, int K, int N, ConvGeo geo)
 {
     constexpr int TN = BN / 64;                       // 32-wide column tiles per wave (2 or 1)
     constexpr int A_F4 = C1_BM * C1_BK / 4 / 256;     // float4 per thread per k-step (4)
@@ -62,7 +68,8 @@ __global__ __launch_bounds__(256) void conv1x1_bn_act_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.x * C1_BM, n0 = blockIdx.y * BN;
-    const int nk = K / C1_BK;
+    const int kchunks = K / C1_BK;
+    const int nk = TAPS * kchunks;
 
     f32x16 acc[2][TN];
 #pragma unroll
@@ -72,21 +79,46 @@ __global__ __launch_bounds__(256) void conv1x1_bn_act_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    // global -> register staging: float4 index f = tid + 256*i; row = f / 8, c4 = f % 8
+    // global -> register staging: float4 index f = tid + 256*i; row = f / 8, c4 = f % 8.  A thread's rows are
+    // the same for every k-step; for the 3x3 variant their (image, y, x) is decoded once and each tap only
+    // shifts it (out-of-image taps load a valid address and are zeroed by a select: no conditional loads).
     float4 ra[A_F4], rb[B_F4];
+    int rn[A_F4], ry[A_F4], rx[A_F4];
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {
+        int m = m0 + ((tid + 256 * i) >> 3);
+        m = m < M ? m : M - 1;                                       // tail rows: valid address, never stored
+        if (TAPS == 1) {
+            rn[i] = m; ry[i] = 0; rx[i] = 0;
+        } else {
+            const int hw = geo.Ho * geo.Wo;
+            rn[i] = m / hw;
+            const int r = m - rn[i] * hw;
+            ry[i] = (r / geo.Wo) * geo.stride;
+            rx[i] = (r - (r / geo.Wo) * geo.Wo) * geo.stride;
+        }
+    }
     auto gload = [&](int kt) {
-        const int k0 = kt * C1_BK;
+        const int tap = TAPS == 1 ? 0 : kt / kchunks;
+        const int k0 = (TAPS == 1 ? kt : kt - tap * kchunks) * C1_BK;
+        const int oy = TAPS == 1 ? 0 : (tap / 3 - 1) * geo.dil, ox = TAPS == 1 ? 0 : (tap % 3 - 1) * geo.dil;
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
-            const int f = tid + 256 * i, row = f >> 3, c4 = f & 7;
-            int m = m0 + row;
-            m = m < M ? m : M - 1;                                   // tail rows: valid address, never stored
-            ra[i] = *reinterpret_cast<const float4*>(X + (size_t)m * K + k0 + c4 * 4);
+            const int c4 = (tid + 256 * i) & 7;
+            if (TAPS == 1) {
+                ra[i] = *reinterpret_cast<const float4*>(X + (size_t)rn[i] * K + k0 + c4 * 4);
+            } else {
+                const int yy = ry[i] + oy, xx = rx[i] + ox;
+                const bool ok = yy >= 0 && yy < geo.H && xx >= 0 && xx < geo.W;
+                const size_t pix = ok ? ((size_t)rn[i] * geo.H + yy) * geo.W + xx : 0;
+                const float4 v = *reinterpret_cast<const float4*>(X + pix * K + k0 + c4 * 4);
+                ra[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
             const int f = tid + 256 * i, row = f >> 3, c4 = f & 7;
-            rb[i] = *reinterpret_cast<const float4*>(W + (size_t)(n0 + row) * K + k0 + c4 * 4);
+            rb[i] = *reinterpret_cast<const float4*>(W + (size_t)(n0 + row) * (TAPS * K) + kt * C1_BK + c4 * 4);
         }
     };
     auto lds_store = [&](int buf) {
@@ -217,28 +249,48 @@ __global__ __launch_bounds__(256) void bn_act_nhwc_kernel(const float* __restric
 
 }  // namespace hiast
 
-extern "C" int hiast_conv1x1_bn_act_nhwc(const float* x, const float* w, const float* gamma, const float* beta,
-                                         const float* mean, const float* var, float eps, const float* res,
-                                         int relu, float* y, int64_t M, int K, int N, hiast_stream_t stream)
+static int launch_conv(const float* x, const float* w, const float* gamma, const float* beta, const float* mean,
+                       const float* var, float eps, const float* res, int relu, float* y, int64_t M, int K, int N,
+                       int taps, hiast::ConvGeo geo, hipStream_t st)
 {
     if (!x || !w || !mean || !var || !y) return HIAST_E_ARG;
     if (M <= 0 || K <= 0 || N <= 0) return HIAST_E_ARG;
     if (K % hiast::C1_BK != 0 || N % 64 != 0 || M > (1ll << 31) - 256) return HIAST_E_RANGE;
     if ((((uintptr_t)x) | ((uintptr_t)w)) & 15) return HIAST_E_RANGE;
-    hipStream_t st = (hipStream_t)stream;
     const int BN = (N % 128 == 0) ? 128 : 64;
     dim3 grid((unsigned)((M + hiast::C1_BM - 1) / hiast::C1_BM), N / BN);
-#define L(BNV, RES, RELU)                                                                                       \
-    hipLaunchKernelGGL((hiast::conv1x1_bn_act_kernel<BNV, RES, RELU>), grid, dim3(256), 0, st, x, w, gamma, beta, \
-                       mean, var, eps, res, y, (int)M, K, N)
-#define LL(BNV)                                                   \
-    if (res) { if (relu) L(BNV, true, true); else L(BNV, true, false); } \
-    else { if (relu) L(BNV, false, true); else L(BNV, false, false); }
-    if (BN == 128) { LL(128) } else { LL(64) }
+#define L(BNV, T, RES, RELU)                                                                                        \
+    hipLaunchKernelGGL((hiast::conv1x1_bn_act_kernel<BNV, T, RES, RELU>), grid, dim3(256), 0, st, x, w, gamma, beta, \
+                       mean, var, eps, res, y, (int)M, K, N, geo)
+#define LL(BNV, T)                                                              \
+    if (res) { if (relu) L(BNV, T, true, true); else L(BNV, T, true, false); }  \
+    else { if (relu) L(BNV, T, false, true); else L(BNV, T, false, false); }
+    if (taps == 1) { if (BN == 128) { LL(128, 1) } else { LL(64, 1) } }
+    else { if (BN == 128) { LL(128, 9) } else { LL(64, 9) } }
 #undef LL
 #undef L
     HIAST_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int hiast_conv1x1_bn_act_nhwc(const float* x, const float* w, const float* gamma, const float* beta,
+                                         const float* mean, const float* var, float eps, const float* res,
+                                         int relu, float* y, int64_t M, int K, int N, hiast_stream_t stream)
+{
+    hiast::ConvGeo geo = {0, 0, 0, 0, 1, 1};
+    return launch_conv(x, w, gamma, beta, mean, var, eps, res, relu, y, M, K, N, 1, geo, (hipStream_t)stream);
+}
+
+extern "C" int hiast_conv3x3_bn_act_nhwc(const float* x, const float* w, const float* gamma, const float* beta,
+                                         const float* mean, const float* var, float eps, int relu, float* y,
+                                         int B, int H, int W, int Cin, int Cout, int stride, int dil,
+                                         hiast_stream_t stream)
+{
+    if (B <= 0 || H <= 0 || W <= 0 || stride <= 0 || dil <= 0) return HIAST_E_ARG;
+    const int Ho = (H + 2 * dil - 2 * dil - 1) / stride + 1, Wo = (W + 2 * dil - 2 * dil - 1) / stride + 1;
+    hiast::ConvGeo geo = {H, W, Ho, Wo, stride, dil};
+    return launch_conv(x, w, gamma, beta, mean, var, eps, nullptr, relu, y, (int64_t)B * Ho * Wo, Cin, Cout, 9, geo,
+                       (hipStream_t)stream);
 }
 
 extern "C" int hiast_bn_act_nhwc_infer(const float* x, float* y, const float* gamma, const float* beta,

@@ -364,3 +364,20 @@ def bn_act_nhwc_infer(x2d, bn, relu=True):
                                               _ptr(bn.running_mean), _ptr(bn.running_var), float(bn.eps),
                                               int(bool(relu)), M, C, _stream()), "hiast_bn_act_nhwc_infer")
     return y
+
+
+def conv3x3_bn_act_nhwc(x_nhwc, weight, bn, stride, dil, relu=True):
+    """x_nhwc [B,H,W,Cin] fp32 contiguous; weight [Cout,Cin,3,3] (torch layout; repacked here to
+    [Cout,3,3,Cin]); -> y [B,Ho,Wo,Cout] fp32"""
+    _req(x_nhwc, torch.float32, 4, "x_nhwc")
+    B, H, W, Cin = x_nhwc.shape
+    Cout = weight.shape[0]
+    assert tuple(weight.shape) == (Cout, Cin, 3, 3)
+    wp = weight.detach().permute(0, 2, 3, 1).contiguous()
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    y = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=x_nhwc.device)
+    check(_lib.load().hiast_conv3x3_bn_act_nhwc(_ptr(x_nhwc), _ptr(wp), _ptr(bn.weight), _ptr(bn.bias),
+                                                _ptr(bn.running_mean), _ptr(bn.running_var), float(bn.eps),
+                                                int(bool(relu)), _ptr(y), B, H, W, Cin, Cout, int(stride), int(dil),
+                                                _stream()), "hiast_conv3x3_bn_act_nhwc")
+    return y

@@ -52,17 +52,16 @@ class Bottleneck(nn.Module):
         return bn_act(self.bn3, self.conv3(o), res=idt)        # += identity, ReLU
 
     def forward_eval_nhwc(self, x):
-        """fp32 inference on channels-last activations (pseudo-label forward): the two 1x1 convs run as the
-        fused split-bf16 GEMM + BN + (residual) + ReLU kernel (hiast_conv1x1_bn_act_nhwc); the 3x3 conv
-        stays on the library, followed by the channels-last BN+ReLU kernel."""
+        """fp32 inference on channels-last activations (pseudo-label forward): all three convs run as fused
+        split-bf16 (implicit) GEMM + BN + (residual) + ReLU kernels (hiast_conv1x1_/conv3x3_bn_act_nhwc)."""
         from hiast_amd import kernels as K
         B, _, H, W = x.shape
         x2d = _nhwc2d(x)
         o = K.conv1x1_bn_act_nhwc(x2d, self.conv1.weight, self.bn1, None, True)
-        o = F.conv2d(_from2d(o, B, H, W), self.conv2.weight, None, self.conv2.stride, self.conv2.padding,
-                     self.conv2.dilation)
-        Ho, Wo = o.shape[2:]
-        o = K.bn_act_nhwc_infer(_nhwc2d(o), self.bn2, True)
+        o = K.conv3x3_bn_act_nhwc(o.view(B, H, W, -1), self.conv2.weight, self.bn2, self.conv2.stride[0],
+                                  self.conv2.dilation[0], True)
+        Ho, Wo = o.shape[1:3]
+        o = o.view(B * Ho * Wo, -1)
         if self.downsample is None:
             idt = x2d
         else:

@@ -174,6 +174,13 @@ int hiast_bn_act_bwd_apply(const void* dy, const void* y, const void* x, const f
 int hiast_conv1x1_bn_act_nhwc(const float* x, const float* w, const float* gamma, const float* beta,
                               const float* mean, const float* var, float eps, const float* res, int relu,
                               float* y, int64_t M, int K, int N, hiast_stream_t stream);
+/* 3x3 convolution (padding = dilation, stride 1 or 2) + BN(eval) + ReLU on the same path: conv2 -> bn2 -> relu
+ * of Bottleneck.forward (resnet.py:83-85), implicit GEMM over 9 taps x Cin with the same split-bf16
+ * arithmetic.  x [B,H,W,Cin] fp32 NHWC; w [Cout][3][3][Cin] fp32 (the conv weight permuted (0,2,3,1));
+ * y [B,Ho,Wo,Cout], Ho = (H-1)/stride + 1.  Cin % 32 == 0, Cout % 64 == 0. */
+int hiast_conv3x3_bn_act_nhwc(const float* x, const float* w, const float* gamma, const float* beta,
+                              const float* mean, const float* var, float eps, int relu, float* y, int B, int H,
+                              int W, int Cin, int Cout, int stride, int dil, hiast_stream_t stream);
 int hiast_bn_act_nhwc_infer(const float* x, float* y, const float* gamma, const float* beta, const float* mean,
                             const float* var, float eps, int relu, int64_t M, int C, hiast_stream_t stream);
 

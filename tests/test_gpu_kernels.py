@@ -415,3 +415,26 @@ def test_bn_act_nhwc_infer(K):
     y = K.bn_act_nhwc_infer(dev(x), bn, True)
     want = torch.relu(bn(dev(x).t().reshape(1, C, M, 1))).reshape(C, M).t()
     assert torch.allclose(y, want, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("cfg", [(2, 17, 23, 64, 64, 1, 1), (1, 16, 32, 256, 256, 1, 2), (1, 13, 9, 128, 128, 2, 1),
+                                 (2, 8, 16, 512, 512, 1, 4), (1, 33, 65, 32, 64, 1, 2)])
+def test_conv3x3_split_bf16_vs_fp64(K, cfg):
+    """fused 3x3 (dilated / strided) conv + BN(eval) + ReLU on channels-last fp32 vs float64 F.conv2d"""
+    B, H, W, Cin, Cout, stride, dil = cfg
+    x = synth.normal_f32(221, (B, Cin, H, W), 1.0)
+    w = synth.normal_f32(222, (Cout, Cin, 3, 3), (2.0 / (9 * Cin)) ** 0.5)
+    bn = torch.nn.BatchNorm2d(Cout).cuda().eval()
+    with torch.no_grad():
+        bn.weight.copy_(torch.from_numpy(1 + synth.normal_f32(224, (Cout,), 0.2)))
+        bn.bias.copy_(torch.from_numpy(synth.normal_f32(225, (Cout,), 0.2)))
+        bn.running_mean.copy_(torch.from_numpy(synth.normal_f32(226, (Cout,), 0.3)))
+        bn.running_var.copy_(torch.from_numpy(0.5 + synth.rng(227).random(Cout, dtype=np.float32)))
+    xn = dev(x).permute(0, 2, 3, 1).contiguous()
+    y = K.conv3x3_bn_act_nhwc(xn, dev(w), bn, stride, dil, True).permute(0, 3, 1, 2).cpu().double()
+    ref = torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), None, stride, dil, dil)
+    sc = bn.weight.double().cpu() / torch.sqrt(bn.running_var.double().cpu() + bn.eps)
+    sh = bn.bias.double().cpu() - bn.running_mean.double().cpu() * sc
+    ref = torch.relu(ref * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    assert y.shape == ref.shape
+    assert (y - ref).abs().max() <= 3e-5 * ref.abs().max()
