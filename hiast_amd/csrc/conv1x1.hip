@@ -51,23 +51,41 @@ struct ConvGeo {
     int H, W, Ho, Wo, stride, dil;
 };
 
-template <int BN, int TAPS, bool RES, bool RELU>
+// TA = float : fp32 activations, split-bf16 arithmetic (3 MFMAs per operand pair)   [pseudo-label forward]
+// TA = bf16  : bf16 activations in/out, plain bf16 MFMA (fp32 accumulate), weights converted from the fp32
+//              master copy while staging                                           [teacher forward under AMP]
+template <typename TA, int BN, int TAPS, bool RES, bool RELU>
 __global__ __launch_bounds__(256) void conv1x1_bn_act_kernel(
-    const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ gamma,
+    const TA* __restrict__ X, const float* __restrict__ W, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ var, float eps,
-    const float* __restrict__ R, float* __restrict__ Y, int M, int K, int N, ConvGeo geo)
+    const TA* __restrict__ R, TA* __restrict__ Y, int M, int K, int N, ConvGeo geo)
 {
+    constexpr bool SPLIT = sizeof(TA) == 4;
     constexpr int TN = BN / 64;                       // 32-wide column tiles per wave (2 or 1)
-    constexpr int A_F4 = C1_BM * C1_BK / 4 / 256;     // float4 per thread per k-step (4)
-    constexpr int B_F4 = BN * C1_BK / 4 / 256;        // 4 or 2
-    // [buf][A_hi | A_lo | B_hi | B_lo]
+    constexpr int A_F4 = SPLIT ? C1_BM * C1_BK / 4 / 256 : C1_BM * C1_BK / 8 / 256;   // 16-byte loads per thread (4 | 2)
+    constexpr int B_F4 = BN * C1_BK / 4 / 256;        // 4 or 2 (weights are always fp32)
+    // [buf][A_hi | A_lo | B_hi | B_lo]   (the *_lo planes exist only in split mode)
     constexpr int A_BYTES = C1_BM * C1_PITCH * 2, B_BYTES = BN * C1_PITCH * 2;
-    constexpr int BUF_BYTES = 2 * A_BYTES + 2 * B_BYTES;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF_BYTES];
+    constexpr int BUF_BYTES = (SPLIT ? 2 : 1) * (A_BYTES + B_BYTES);
+    constexpr int A_LO = A_BYTES, B_HI = (SPLIT ? 2 : 1) * A_BYTES, B_LO = B_HI + B_BYTES;
+    constexpr int EPI_BYTES = C1_BM * (BN + 4) * 4;
+    constexpr int SMEM_BYTES = 2 * BUF_BYTES > EPI_BYTES ? 2 * BUF_BYTES : EPI_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.x * C1_BM, n0 = blockIdx.y * BN;
+    // XCD-aware tile order: work items are numbered with the channel tile fastest, and XCD k (workgroup ids
+    // k, k+8, ... under round-robin dispatch) takes the k-th contiguous eighth of them, so the column blocks
+    // that re-read one 128-row activation tile run back to back on ONE L2 instead of on eight.
+    int bm, bn_;
+    {
+        const int gx = gridDim.x, gy = gridDim.y, total = gx * gy;
+        int lid = blockIdx.x + gx * blockIdx.y;
+        if ((total & 7) == 0) lid = (lid & 7) * (total >> 3) + (lid >> 3);
+        bn_ = lid % gy;
+        bm = lid / gy;
+    }
+    const int m0 = bm * C1_BM, n0 = bn_ * BN;
     const int kchunks = K / C1_BK;
     const int nk = TAPS * kchunks;
 
@@ -82,11 +100,14 @@ __global__ __launch_bounds__(256) void conv1x1_bn_act_kernel(
     // global -> register staging: float4 index f = tid + 256*i; row = f / 8, c4 = f % 8.  A thread's rows are
     // the same for every k-step; for the 3x3 variant their (image, y, x) is decoded once and each tap only
     // shifts it (out-of-image taps load a valid address and are zeroed by a select: no conditional loads).
-    float4 ra[A_F4], rb[B_F4];
+    constexpr int A_ROW_SHIFT = SPLIT ? 3 : 2;        // 16-byte loads per 32-element row: 8 (fp32) | 4 (bf16)
+    constexpr int A_PER = SPLIT ? 4 : 8;              // elements per 16-byte load
+    uint4 ra[A_F4];
+    float4 rb[B_F4];
     int rn[A_F4], ry[A_F4], rx[A_F4];
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {
-        int m = m0 + ((tid + 256 * i) >> 3);
+        int m = m0 + ((tid + 256 * i) >> A_ROW_SHIFT);
         m = m < M ? m : M - 1;                                       // tail rows: valid address, never stored
         if (TAPS == 1) {
             rn[i] = m; ry[i] = 0; rx[i] = 0;
@@ -104,15 +125,15 @@ __global__ __launch_bounds__(256) void conv1x1_bn_act_kernel(
         const int oy = TAPS == 1 ? 0 : (tap / 3 - 1) * geo.dil, ox = TAPS == 1 ? 0 : (tap % 3 - 1) * geo.dil;
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
-            const int c4 = (tid + 256 * i) & 7;
+            const int cc = (tid + 256 * i) & ((1 << A_ROW_SHIFT) - 1);
             if (TAPS == 1) {
-                ra[i] = *reinterpret_cast<const float4*>(X + (size_t)rn[i] * K + k0 + c4 * 4);
+                ra[i] = *reinterpret_cast<const uint4*>(X + (size_t)rn[i] * K + k0 + cc * A_PER);
             } else {
                 const int yy = ry[i] + oy, xx = rx[i] + ox;
                 const bool ok = yy >= 0 && yy < geo.H && xx >= 0 && xx < geo.W;
                 const size_t pix = ok ? ((size_t)rn[i] * geo.H + yy) * geo.W + xx : 0;
-                const float4 v = *reinterpret_cast<const float4*>(X + pix * K + k0 + c4 * 4);
-                ra[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+                const uint4 v = *reinterpret_cast<const uint4*>(X + pix * K + k0 + cc * A_PER);
+                ra[i] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
             }
         }
 #pragma unroll
@@ -125,19 +146,25 @@ __global__ __launch_bounds__(256) void conv1x1_bn_act_kernel(
         unsigned char* base = smem + buf * BUF_BYTES;
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
-            const int f = tid + 256 * i, row = f >> 3, c4 = f & 7;
-            uint2 hi, lo;
-            split4(ra[i], hi, lo);
-            *reinterpret_cast<uint2*>(base + (row * C1_PITCH + c4 * 4) * 2) = hi;
-            *reinterpret_cast<uint2*>(base + A_BYTES + (row * C1_PITCH + c4 * 4) * 2) = lo;
+            const int f = tid + 256 * i, row = f >> A_ROW_SHIFT, cc = f & ((1 << A_ROW_SHIFT) - 1);
+            if (SPLIT) {
+                uint2 hi, lo;
+                const float4 v = make_float4(__uint_as_float(ra[i].x), __uint_as_float(ra[i].y),
+                                             __uint_as_float(ra[i].z), __uint_as_float(ra[i].w));
+                split4(v, hi, lo);
+                *reinterpret_cast<uint2*>(base + (row * C1_PITCH + cc * 4) * 2) = hi;
+                *reinterpret_cast<uint2*>(base + A_LO + (row * C1_PITCH + cc * 4) * 2) = lo;
+            } else {
+                *reinterpret_cast<uint4*>(base + (row * C1_PITCH + cc * 8) * 2) = ra[i];
+            }
         }
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
             const int f = tid + 256 * i, row = f >> 3, c4 = f & 7;
             uint2 hi, lo;
             split4(rb[i], hi, lo);
-            *reinterpret_cast<uint2*>(base + 2 * A_BYTES + (row * C1_PITCH + c4 * 4) * 2) = hi;
-            *reinterpret_cast<uint2*>(base + 2 * A_BYTES + B_BYTES + (row * C1_PITCH + c4 * 4) * 2) = lo;
+            *reinterpret_cast<uint2*>(base + B_HI + (row * C1_PITCH + c4 * 4) * 2) = hi;
+            if (SPLIT) *reinterpret_cast<uint2*>(base + B_LO + (row * C1_PITCH + c4 * 4) * 2) = lo;
         }
     };
 
@@ -157,20 +184,22 @@ __global__ __launch_bounds__(256) void conv1x1_bn_act_kernel(
             for (int a = 0; a < 2; ++a) {
                 const int off = ((wm * 64 + a * 32 + frow) * C1_PITCH + kk * 16 + fk) * 2;
                 ah[a] = *reinterpret_cast<const bf16x8*>(base + off);
-                al[a] = *reinterpret_cast<const bf16x8*>(base + A_BYTES + off);
+                if (SPLIT) al[a] = *reinterpret_cast<const bf16x8*>(base + A_LO + off);
             }
 #pragma unroll
             for (int b = 0; b < TN; ++b) {
                 const int off = ((wn * (BN / 2) + b * 32 + frow) * C1_PITCH + kk * 16 + fk) * 2;
-                bh[b] = *reinterpret_cast<const bf16x8*>(base + 2 * A_BYTES + off);
-                bl[b] = *reinterpret_cast<const bf16x8*>(base + 2 * A_BYTES + B_BYTES + off);
+                bh[b] = *reinterpret_cast<const bf16x8*>(base + B_HI + off);
+                if (SPLIT) bl[b] = *reinterpret_cast<const bf16x8*>(base + B_LO + off);
             }
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < TN; ++b) {
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+                    if (SPLIT) {
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+                    }
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
                 }
         }
@@ -184,7 +213,7 @@ __global__ __launch_bounds__(256) void conv1x1_bn_act_kernel(
     // 4-byte accesses (the K <= 256 "expanding" convs are bound by exactly this traffic).
     constexpr int CP = BN + 4;
     float* sC = reinterpret_cast<float*>(smem);
-    static_assert(C1_BM * CP * 4 <= 2 * BUF_BYTES, "epilogue tile must fit the staging buffers");
+    __syncthreads();          // (the last k-step's barrier already passed; keeps the reuse of smem explicit)
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
         const int nl = wn * (BN / 2) + b * 32 + (lane & 31);
@@ -201,23 +230,56 @@ __global__ __launch_bounds__(256) void conv1x1_bn_act_kernel(
             }
     }
     __syncthreads();
-    constexpr int F4_PER_ROW = BN / 4;
+    if (SPLIT) {
+        constexpr int F4_PER_ROW = BN / 4;
 #pragma unroll 4
-    for (int f = tid; f < C1_BM * F4_PER_ROW; f += 256) {
-        const int ml = f / F4_PER_ROW, c4 = f - ml * F4_PER_ROW;
-        const int m = m0 + ml;
-        if (m >= M) continue;
-        float4 o = *reinterpret_cast<const float4*>(sC + ml * CP + c4 * 4);
-        const size_t g = (size_t)m * N + n0 + c4 * 4;
-        if (RES) {
-            const float4 rr = *reinterpret_cast<const float4*>(R + g);
-            o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+        for (int f = tid; f < C1_BM * F4_PER_ROW; f += 256) {
+            const int ml = f / F4_PER_ROW, c4 = f - ml * F4_PER_ROW;
+            const int m = m0 + ml;
+            if (m >= M) continue;
+            float4 o = *reinterpret_cast<const float4*>(sC + ml * CP + c4 * 4);
+            const size_t g = (size_t)m * N + n0 + c4 * 4;
+            if (RES) {
+                const float4 rr = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(R) + g);
+                o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+            }
+            if (RELU) {
+                o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f;
+                o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
+            }
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(Y) + g) = o;
         }
-        if (RELU) {
-            o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f;
-            o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
+    } else {
+        constexpr int V8_PER_ROW = BN / 8;
+#pragma unroll 4
+        for (int f = tid; f < C1_BM * V8_PER_ROW; f += 256) {
+            const int ml = f / V8_PER_ROW, c8 = f - ml * V8_PER_ROW;
+            const int m = m0 + ml;
+            if (m >= M) continue;
+            float o[8];
+            const float4 o0 = *reinterpret_cast<const float4*>(sC + ml * CP + c8 * 8);
+            const float4 o1 = *reinterpret_cast<const float4*>(sC + ml * CP + c8 * 8 + 4);
+            o[0] = o0.x; o[1] = o0.y; o[2] = o0.z; o[3] = o0.w; o[4] = o1.x; o[5] = o1.y; o[6] = o1.z; o[7] = o1.w;
+            const size_t g = (size_t)m * N + n0 + c8 * 8;
+            if (RES) {
+                const uint4 rr = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(R) + g);
+                const unsigned wds[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    o[2 * q] += __uint_as_float(wds[q] << 16);
+                    o[2 * q + 1] += __uint_as_float(wds[q] & 0xFFFF0000u);
+                }
+            }
+            unsigned pk[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float a0 = o[2 * q], a1 = o[2 * q + 1];
+                if (RELU) { a0 = a0 > 0.f ? a0 : 0.f; a1 = a1 > 0.f ? a1 : 0.f; }
+                pk[q] = (unsigned)__bfloat16_as_ushort(__float2bfloat16(a0)) |
+                        ((unsigned)__bfloat16_as_ushort(__float2bfloat16(a1)) << 16);
+            }
+            *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(Y) + g) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
         }
-        *reinterpret_cast<float4*>(Y + g) = o;
     }
 }
 
@@ -247,21 +309,52 @@ __global__ __launch_bounds__(256) void bn_act_nhwc_kernel(const float* __restric
     }
 }
 
+// bf16 flavour: 8 channels per thread (C % 8 == 0)
+template <bool RELU>
+__global__ __launch_bounds__(256) void bn_act_nhwc_bf16_kernel(const unsigned short* __restrict__ x,
+                                                               unsigned short* __restrict__ y,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ var, float eps,
+                                                               long long total8, int C)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long long)gridDim.x * 256) {
+        const int c = (int)((i * 8) % C);
+        const uint4 v = reinterpret_cast<const uint4*>(x)[i];
+        const unsigned wds[4] = {v.x, v.y, v.z, v.w};
+        unsigned pk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float o[2] = {__uint_as_float(wds[q] << 16), __uint_as_float(wds[q] & 0xFFFF0000u)};
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int cc = c + 2 * q + k;
+                const float invstd = 1.0f / sqrtf(var[cc] + eps);
+                const float sc = (gamma ? gamma[cc] : 1.0f) * invstd;
+                const float sh = fmaf(-mean[cc], sc, beta ? beta[cc] : 0.0f);
+                const float t = fmaf(o[k], sc, sh);
+                o[k] = RELU ? (t > 0.f ? t : 0.f) : t;
+            }
+            pk[q] = (unsigned)__bfloat16_as_ushort(__float2bfloat16(o[0])) |
+                    ((unsigned)__bfloat16_as_ushort(__float2bfloat16(o[1])) << 16);
+        }
+        reinterpret_cast<uint4*>(y)[i] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    }
+}
+
 }  // namespace hiast
 
-static int launch_conv(const float* x, const float* w, const float* gamma, const float* beta, const float* mean,
-                       const float* var, float eps, const float* res, int relu, float* y, int64_t M, int K, int N,
-                       int taps, hiast::ConvGeo geo, hipStream_t st)
+template <typename TA>
+static int launch_conv_t(const void* x, const float* w, const float* gamma, const float* beta, const float* mean,
+                         const float* var, float eps, const void* res, int relu, void* y, int64_t M, int K, int N,
+                         int taps, hiast::ConvGeo geo, hipStream_t st)
 {
-    if (!x || !w || !mean || !var || !y) return HIAST_E_ARG;
-    if (M <= 0 || K <= 0 || N <= 0) return HIAST_E_ARG;
-    if (K % hiast::C1_BK != 0 || N % 64 != 0 || M > (1ll << 31) - 256) return HIAST_E_RANGE;
-    if ((((uintptr_t)x) | ((uintptr_t)w)) & 15) return HIAST_E_RANGE;
     const int BN = (N % 128 == 0) ? 128 : 64;
     dim3 grid((unsigned)((M + hiast::C1_BM - 1) / hiast::C1_BM), N / BN);
-#define L(BNV, T, RES, RELU)                                                                                        \
-    hipLaunchKernelGGL((hiast::conv1x1_bn_act_kernel<BNV, T, RES, RELU>), grid, dim3(256), 0, st, x, w, gamma, beta, \
-                       mean, var, eps, res, y, (int)M, K, N, geo)
+#define L(BNV, T, RES, RELU)                                                                                       \
+    hipLaunchKernelGGL((hiast::conv1x1_bn_act_kernel<TA, BNV, T, RES, RELU>), grid, dim3(256), 0, st, (const TA*)x, \
+                       w, gamma, beta, mean, var, eps, (const TA*)res, (TA*)y, (int)M, K, N, geo)
 #define LL(BNV, T)                                                              \
     if (res) { if (relu) L(BNV, T, true, true); else L(BNV, T, true, false); }  \
     else { if (relu) L(BNV, T, false, true); else L(BNV, T, false, false); }
@@ -273,43 +366,67 @@ static int launch_conv(const float* x, const float* w, const float* gamma, const
     return 0;
 }
 
-extern "C" int hiast_conv1x1_bn_act_nhwc(const float* x, const float* w, const float* gamma, const float* beta,
-                                         const float* mean, const float* var, float eps, const float* res,
-                                         int relu, float* y, int64_t M, int K, int N, hiast_stream_t stream)
+static int launch_conv(const void* x, const float* w, const float* gamma, const float* beta, const float* mean,
+                       const float* var, float eps, const void* res, int relu, void* y, int64_t M, int K, int N,
+                       int taps, hiast::ConvGeo geo, int dtype, hipStream_t st)
 {
-    hiast::ConvGeo geo = {0, 0, 0, 0, 1, 1};
-    return launch_conv(x, w, gamma, beta, mean, var, eps, res, relu, y, M, K, N, 1, geo, (hipStream_t)stream);
+    if (!x || !w || !mean || !var || !y) return HIAST_E_ARG;
+    if (M <= 0 || K <= 0 || N <= 0) return HIAST_E_ARG;
+    if (K % hiast::C1_BK != 0 || N % 64 != 0 || M > (1ll << 31) - 256 || (dtype != 0 && dtype != 1)) return HIAST_E_RANGE;
+    if ((((uintptr_t)x) | ((uintptr_t)w) | ((uintptr_t)y) | ((uintptr_t)res)) & 15) return HIAST_E_RANGE;
+    if (dtype == 0)
+        return launch_conv_t<float>(x, w, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, st);
+    return launch_conv_t<__hip_bfloat16>(x, w, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, st);
 }
 
-extern "C" int hiast_conv3x3_bn_act_nhwc(const float* x, const float* w, const float* gamma, const float* beta,
-                                         const float* mean, const float* var, float eps, int relu, float* y,
-                                         int B, int H, int W, int Cin, int Cout, int stride, int dil,
+extern "C" int hiast_conv1x1_bn_act_nhwc(const void* x, const float* w, const float* gamma, const float* beta,
+                                         const float* mean, const float* var, float eps, const void* res,
+                                         int relu, void* y, int64_t M, int K, int N, int dtype,
+                                         hiast_stream_t stream)
+{
+    hiast::ConvGeo geo = {0, 0, 0, 0, 1, 1};
+    return launch_conv(x, w, gamma, beta, mean, var, eps, res, relu, y, M, K, N, 1, geo, dtype, (hipStream_t)stream);
+}
+
+extern "C" int hiast_conv3x3_bn_act_nhwc(const void* x, const float* w, const float* gamma, const float* beta,
+                                         const float* mean, const float* var, float eps, int relu, void* y,
+                                         int B, int H, int W, int Cin, int Cout, int stride, int dil, int dtype,
                                          hiast_stream_t stream)
 {
     if (B <= 0 || H <= 0 || W <= 0 || stride <= 0 || dil <= 0) return HIAST_E_ARG;
-    const int Ho = (H + 2 * dil - 2 * dil - 1) / stride + 1, Wo = (W + 2 * dil - 2 * dil - 1) / stride + 1;
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
     hiast::ConvGeo geo = {H, W, Ho, Wo, stride, dil};
     return launch_conv(x, w, gamma, beta, mean, var, eps, nullptr, relu, y, (int64_t)B * Ho * Wo, Cin, Cout, 9, geo,
-                       (hipStream_t)stream);
+                       dtype, (hipStream_t)stream);
 }
 
-extern "C" int hiast_bn_act_nhwc_infer(const float* x, float* y, const float* gamma, const float* beta,
+extern "C" int hiast_bn_act_nhwc_infer(const void* x, void* y, const float* gamma, const float* beta,
                                        const float* mean, const float* var, float eps, int relu, int64_t M,
-                                       int C, hiast_stream_t stream)
+                                       int C, int dtype, hiast_stream_t stream)
 {
     if (!x || !y || !mean || !var) return HIAST_E_ARG;
     if (M <= 0 || C <= 0) return HIAST_E_ARG;
-    if (C % 4 != 0 || ((((uintptr_t)x) | ((uintptr_t)y)) & 15)) return HIAST_E_RANGE;
-    const long long total4 = (long long)M * C / 4;
-    long long nb = (total4 + 256 * 4 - 1) / (256 * 4);
+    const int vec = dtype ? 8 : 4;
+    if ((dtype != 0 && dtype != 1) || C % vec != 0 || ((((uintptr_t)x) | ((uintptr_t)y)) & 15)) return HIAST_E_RANGE;
+    const long long totalv = (long long)M * C / vec;
+    long long nb = (totalv + 256 * 4 - 1) / (256 * 4);
     const int grid = (int)(nb < 1 ? 1 : (nb > 4096 ? 4096 : nb));
     hipStream_t st = (hipStream_t)stream;
-    if (relu)
-        hipLaunchKernelGGL(hiast::bn_act_nhwc_kernel<true>, dim3(grid), dim3(256), 0, st, x, y, gamma, beta, mean,
-                           var, eps, total4, C);
-    else
-        hipLaunchKernelGGL(hiast::bn_act_nhwc_kernel<false>, dim3(grid), dim3(256), 0, st, x, y, gamma, beta, mean,
-                           var, eps, total4, C);
+    if (dtype == 0) {
+        if (relu)
+            hipLaunchKernelGGL(hiast::bn_act_nhwc_kernel<true>, dim3(grid), dim3(256), 0, st, (const float*)x, (float*)y,
+                               gamma, beta, mean, var, eps, totalv, C);
+        else
+            hipLaunchKernelGGL(hiast::bn_act_nhwc_kernel<false>, dim3(grid), dim3(256), 0, st, (const float*)x, (float*)y,
+                               gamma, beta, mean, var, eps, totalv, C);
+    } else {
+        if (relu)
+            hipLaunchKernelGGL(hiast::bn_act_nhwc_bf16_kernel<true>, dim3(grid), dim3(256), 0, st,
+                               (const unsigned short*)x, (unsigned short*)y, gamma, beta, mean, var, eps, totalv, C);
+        else
+            hipLaunchKernelGGL(hiast::bn_act_nhwc_bf16_kernel<false>, dim3(grid), dim3(256), 0, st,
+                               (const unsigned short*)x, (unsigned short*)y, gamma, beta, mean, var, eps, totalv, C);
+    }
     HIAST_CHECK_LAUNCH();
     return 0;
 }

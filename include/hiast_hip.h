@@ -162,27 +162,29 @@ int hiast_bn_act_bwd_apply(const void* dy, const void* y, const void* x, const f
                            double count, int relu, void* dx, void* dres, float* dgamma, float* dbeta, int B,
                            int C, int64_t HW, int dtype, hiast_stream_t stream);
 
-/* ---- K9a: 1x1 bottleneck convolution + BN(eval) + residual + ReLU (fp32 pseudo-label forward) ------
- * conv1 -> bn1 -> relu and conv3 -> bn3 -> (+= identity) -> relu of Bottleneck.forward,
- * sseg/models/modules/resnet.py:78-98, as ONE kernel on channels-last activations:
+/* ---- K9: trunk convolutions of the inference forwards, fused with BN(eval) + residual + ReLU ---------
+ * conv1 -> bn1 -> relu, conv2 -> bn2 -> relu and conv3 -> bn3 -> (+= identity) -> relu of Bottleneck.forward,
+ * sseg/models/modules/resnet.py:78-98 (separate cuDNN / ATen passes there), each as ONE kernel on
+ * channels-last (NHWC) activations:
  *   y[m][n] = act((Σ_k x[m][k]*w[n][k]) * gamma_n/sqrt(var_n+eps) + (beta_n - mean_n*...) (+ res[m][n]))
- * x [M = B*H*W][K = Cin] fp32 (NHWC), w [N = Cout][K] fp32 (the conv weight as stored), res/y [M][N] fp32.
- * Split-bf16 arithmetic (hi*hi + hi*lo + lo*hi on bf16 MFMA, fp32 accumulate): ~5e-6 of max|y| vs fp64,
- * i.e. fp32-class results at 3/16 of the fp32-MFMA cost.  K % 32 == 0, N % 64 == 0, 16-byte aligned x, w.
- * hiast_bn_act_nhwc_infer: y[m][c] = act(x[m][c]*scale_c + shift_c) for the outputs of the library
- * 3x3 / 7x7 convolutions on the same channels-last path (C % 4 == 0). */
-int hiast_conv1x1_bn_act_nhwc(const float* x, const float* w, const float* gamma, const float* beta,
-                              const float* mean, const float* var, float eps, const float* res, int relu,
-                              float* y, int64_t M, int K, int N, hiast_stream_t stream);
-/* 3x3 convolution (padding = dilation, stride 1 or 2) + BN(eval) + ReLU on the same path: conv2 -> bn2 -> relu
- * of Bottleneck.forward (resnet.py:83-85), implicit GEMM over 9 taps x Cin with the same split-bf16
- * arithmetic.  x [B,H,W,Cin] fp32 NHWC; w [Cout][3][3][Cin] fp32 (the conv weight permuted (0,2,3,1));
- * y [B,Ho,Wo,Cout], Ho = (H-1)/stride + 1.  Cin % 32 == 0, Cout % 64 == 0. */
-int hiast_conv3x3_bn_act_nhwc(const float* x, const float* w, const float* gamma, const float* beta,
-                              const float* mean, const float* var, float eps, int relu, float* y, int B, int H,
-                              int W, int Cin, int Cout, int stride, int dil, hiast_stream_t stream);
-int hiast_bn_act_nhwc_infer(const float* x, float* y, const float* gamma, const float* beta, const float* mean,
-                            const float* var, float eps, int relu, int64_t M, int C, hiast_stream_t stream);
+ * dtype 0: fp32 activations, "split-bf16" arithmetic (hi*hi + hi*lo + lo*hi on bf16 MFMA, fp32 accumulate):
+ *          ~5e-6 of max|y| vs fp64, i.e. fp32-class results at 3/16 of the fp32-MFMA cost — the
+ *          pseudo-label forward (the reference runs it in fp32, workflows/pseudo_label_generator.py:190-191);
+ * dtype 1: bf16 activations in/out, plain bf16 MFMA — the EMA-teacher forward under mixed precision
+ *          (workflows/trainer/consistency_self_training_trainer.py:113-116 under apex O1).
+ * Weights stay fp32 master copies: w [N = Cout][K] (1x1: the conv weight as stored; 3x3: permuted (0,2,3,1) to
+ * [Cout][3][3][Cin]).  x [M = B*H*W][K = Cin]; 3x3: padding = dilation, stride 1 or 2, Ho = (H-1)/stride + 1.
+ * Cin % 32 == 0, Cout % 64 == 0, 16-byte aligned buffers.
+ * hiast_bn_act_nhwc_infer: y[m][c] = act(x[m][c]*scale_c + shift_c) for the stem (library 7x7 conv) output. */
+int hiast_conv1x1_bn_act_nhwc(const void* x, const float* w, const float* gamma, const float* beta,
+                              const float* mean, const float* var, float eps, const void* res, int relu,
+                              void* y, int64_t M, int K, int N, int dtype, hiast_stream_t stream);
+int hiast_conv3x3_bn_act_nhwc(const void* x, const float* w, const float* gamma, const float* beta,
+                              const float* mean, const float* var, float eps, int relu, void* y, int B, int H,
+                              int W, int Cin, int Cout, int stride, int dil, int dtype, hiast_stream_t stream);
+int hiast_bn_act_nhwc_infer(const void* x, void* y, const float* gamma, const float* beta, const float* mean,
+                            const float* var, float eps, int relu, int64_t M, int C, int dtype,
+                            hiast_stream_t stream);
 
 /* ---- K11: EMA teacher update ---------------------------------------------------------
  * utils/utils.py:115-123 update_ema_model: ema = ema*gamma + p*(1-gamma) over a list of

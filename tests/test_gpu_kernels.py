@@ -438,3 +438,56 @@ def test_conv3x3_split_bf16_vs_fp64(K, cfg):
     ref = torch.relu(ref * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
     assert y.shape == ref.shape
     assert (y - ref).abs().max() <= 3e-5 * ref.abs().max()
+
+
+@pytest.mark.parametrize("shape", [(4096, 256, 64), (1000, 64, 256), (8192, 1024, 256)])
+def test_conv1x1_bf16_vs_fp64(K, shape):
+    """bf16-activation flavour (teacher forward): bf16 inputs, fp32 accumulate, bf16 output"""
+    M, Kd, N = shape
+    x = torch.from_numpy(synth.normal_f32(231, (M, Kd), 1.0)).cuda().bfloat16()
+    w = synth.normal_f32(232, (N, Kd), (2.0 / Kd) ** 0.5)
+    r = torch.from_numpy(synth.normal_f32(233, (M, N), 1.0)).cuda().bfloat16()
+    bn = torch.nn.BatchNorm2d(N).cuda().eval()
+    with torch.no_grad():
+        bn.running_var.copy_(torch.from_numpy(0.5 + synth.rng(237).random(N, dtype=np.float32)))
+        bn.running_mean.copy_(torch.from_numpy(synth.normal_f32(236, (N,), 0.3)))
+    y = K.conv1x1_bn_act_nhwc(x, dev(w), bn, r, True)
+    assert y.dtype == torch.bfloat16
+    sc = bn.weight.double().cpu() / torch.sqrt(bn.running_var.double().cpu() + bn.eps)
+    sh = bn.bias.double().cpu() - bn.running_mean.double().cpu() * sc
+    wb = torch.from_numpy(w).bfloat16().double()
+    want = torch.relu((x.double().cpu() @ wb.t()) * sc + sh + r.double().cpu())
+    assert (y.double().cpu() - want).abs().max() <= 1.2e-2 * want.abs().max()     # bf16 output rounding
+
+
+def test_conv3x3_bf16_vs_fp64(K):
+    B, H, W, Cin, Cout, stride, dil = 1, 16, 32, 256, 256, 1, 2
+    x = torch.from_numpy(synth.normal_f32(241, (B, Cin, H, W), 1.0)).cuda().bfloat16()
+    w = synth.normal_f32(242, (Cout, Cin, 3, 3), (2.0 / (9 * Cin)) ** 0.5)
+    bn = torch.nn.BatchNorm2d(Cout).cuda().eval()
+    y = K.conv3x3_bn_act_nhwc(x.permute(0, 2, 3, 1).contiguous(), dev(w), bn, stride, dil, True)
+    ref = torch.nn.functional.conv2d(x.double().cpu(), torch.from_numpy(w).bfloat16().double(), None, stride, dil, dil)
+    ref = torch.relu(ref / (1 + bn.eps) ** 0.5)
+    assert (y.permute(0, 3, 1, 2).double().cpu() - ref).abs().max() <= 1.2e-2 * ref.abs().max()
+
+
+def test_teacher_bf16_fast_path_close_to_library_path(K):
+    """EMA-teacher forward under bf16 autocast: channels-last fused kernels vs the plain module path"""
+    from hiast_amd.utils.registry import register  # noqa: F401
+    from hiast_amd.utils.registry.registries import SEG_MODEL
+    from make_golden import seeded_state_dict
+    m = SEG_MODEL["DeepLab_V2"](19, 256)
+    m.load_state_dict(seeded_state_dict(m, 9000))
+    m = m.cuda().eval()
+    x = torch.from_numpy(synth.normal_f32(903, (2, 3, 129, 257))).cuda()
+    import os
+    os.environ["HIAST_BF16_NHWC"] = "1"
+    try:
+        with torch.no_grad():
+            ref, _ = m(x)                                    # fp32 fast path
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                fast, _ = m(x)                               # bf16 fast path
+    finally:
+        os.environ.pop("HIAST_BF16_NHWC", None)
+    rel = (fast.float() - ref).abs().max() / ref.abs().max()
+    assert rel < 5e-2, float(rel)                        # bf16 through ~100 layers
