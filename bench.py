@@ -42,8 +42,11 @@ def parse():
     p.add_argument("--warmup", type=int, default=2)
     p.add_argument("--batch", type=int, default=8, help="images per GPU per step")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-size", type=int, nargs=2, default=[H // 2, W // 2],
+    p.add_argument("--cpu-size", type=int, nargs=2, default=[H, W],
                    help="H W of the CPU-baseline sample image (time is scaled to 512x1024 by the pixel ratio)")
+    p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' only for "
+                   "functional tests of the N>1 path on a single GPU")
+    p.add_argument("--same-device", action="store_true", help="testing: every rank uses cuda:0")
     p.add_argument("--cpu-threads", type=int, default=32)
     p.add_argument("--trainer", default="ConsistencySelfTrainingTrainer",
                    choices=["ConsistencySelfTrainingTrainer", "SelfTrainingTrainer"])
@@ -68,39 +71,80 @@ def make_cfg(world, trainer):
     return c
 
 
-class AsppTimer:
-    """HIP-event timing of hiast_aspp_fwd launches on torch's current stream (the stream the kernel is
-    enqueued on)."""
+class KernelTimer:
+    """HIP-event timing of selected C-ABI launches on torch's current stream (the stream the kernels are
+    enqueued on), grouped by launch shape."""
 
     def __init__(self):
-        self.pairs = []
+        self.groups = {}
         self.on = False
+
+    def wrap(self, module, name, key_fn):
+        orig = getattr(module, name)
+        timer = self
+
+        def timed(*a, **k):
+            if not timer.on:
+                return orig(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            y = orig(*a, **k)
+            e1.record()
+            timer.groups.setdefault(key_fn(*a, **k), []).append((e0, e1))
+            return y
+        setattr(module, name, timed)
 
     def install(self):
         from hiast_amd import kernels as K
-        orig = K.aspp_fwd
-        timer = self
+        ws = {}
 
-        def timed(x, wpack, Cout, dil, workspace=None):
-            if not timer.on:
-                return orig(x, wpack, Cout, dil, workspace)
-            ws = workspace if workspace is not None else K.aspp_workspace(x.shape[0], x.shape[1], x.shape[2],
-                                                                          x.shape[3], Cout, x.device)
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            y = orig(x, wpack, Cout, dil, ws)
-            b.record()
-            timer.pairs.append((a, b, x.shape[0]))
-            return y
-        K.aspp_fwd = timed
+        def aspp_key(x, wpack, Cout, dil, workspace=None):
+            return ("aspp_fwd", tuple(x.shape), Cout)
+
+        def c3_key(x_nhwc, weight, bn, stride, dil, relu=True):
+            return ("conv3x3", tuple(x_nhwc.shape), weight.shape[0], stride, dil, str(x_nhwc.dtype))
+        self.wrap(K, "aspp_fwd", aspp_key)
+        self.wrap(K, "conv3x3_bn_act_nhwc", c3_key)
 
     def summary(self):
-        if not self.pairs:
-            return None
-        ms = [a.elapsed_time(b) for a, b, _ in self.pairs]
-        imgs = self.pairs[0][2]
-        avg = float(np.mean(ms))
-        return avg, imgs, len(ms)
+        out = []
+        for key, pairs in self.groups.items():
+            ms = [a.elapsed_time(b) for a, b in pairs]
+            out.append((key, float(np.mean(ms)), len(ms), float(np.sum(ms))))
+        return sorted(out, key=lambda t: -t[3])
+
+
+def roofline_of(key, avg_ms, n, steps):
+    """-> roofline dict for one launch group"""
+    if key[0] == "aspp_fwd":
+        B, Cin, h, w = key[1]
+        flop = 2.0 * h * w * key[2] * Cin * 36 * B
+        ach = flop / (avg_ms * 1e-3) / 1e12
+        d = {"kernel": "hiast::aspp_fwd16_kernel<4,3>", "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA,
+             "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA, "traffic": None, "avg_launch_ms": avg_ms,
+             "launches_per_step": n / steps,
+             "note": "exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) peak 157.3; algorithmic %.2f GFLOP per launch (%d images)"
+                     % (flop / 1e9, B)}
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_aspp_fwd.json")
+        if os.path.exists(pmc) and B == 8:
+            pj = json.load(open(pmc))
+            d["traffic"] = pj["hbm_bytes_x2_fetch"]
+            d["note"] += ("; HBM bytes/launch from %s = (2*FETCH_SIZE + WRITE_SIZE)*1024, uncorrected %.0f MB, "
+                          "algorithmic %.0f MB" % (pj["source"], pj["hbm_bytes_uncorrected"] / 1e6,
+                                                   pj["algorithmic_bytes"] / 1e6))
+        return d
+    B, Hh, Ww, Cin = key[1]
+    Cout, stride = key[2], key[3]
+    M = B * ((Hh - 1) // stride + 1) * ((Ww - 1) // stride + 1)
+    flop = 2.0 * M * 9 * Cin * Cout
+    ach = flop / (avg_ms * 1e-3) / 1e12
+    peak = 2500.0 / 3.0
+    return {"kernel": "hiast::conv1x1_bn_act_kernel<float,128,9,false,true> (3x3 split-bf16 implicit GEMM + BN + ReLU)",
+            "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+            "avg_launch_ms": avg_ms, "launches_per_step": n / steps,
+            "note": "algorithmic (fp32-equivalent) %.1f GFLOP per launch: B=%d %dx%d Cin=%d Cout=%d dil=%d; the kernel "
+                    "issues 3 bf16 MFMA flops per algorithmic flop (hi*hi + hi*lo + lo*hi), so its ceiling is the dense "
+                    "bf16 MFMA peak 2500/3 TFLOP/s" % (flop / 1e9, B, Hh, Ww, Cin, Cout, key[4])}
 
 
 class HotPath:
@@ -230,15 +274,20 @@ def main():
     if rank == 0 and not os.path.exists(os.path.join(ROOT, "hiast_amd", "csrc", "libhiast_hip.so")):
         ge.build()
     assert torch.cuda.is_available(), "bench.py needs the MI355X; there is no CPU fallback"
+    if args.same_device:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=args.backend)
     torch.backends.cudnn.benchmark = bool(int(os.environ.get("HIAST_MIOPEN_FIND", "0")))
 
     cfg = make_cfg(world, args.trainer)
     hp = HotPath(cfg, device, rank, world, args.batch)
-    timer = AsppTimer()
+    timer = KernelTimer()
     timer.install()
 
     def sync():
@@ -293,22 +342,14 @@ def main():
                        "parallelism": "dp%d" % world if world > 1 else "single"},
             "phases_ms": {"pseudo_label": 1e3 * t_pl / args.steps, "train_step": 1e3 * t_tr / args.steps},
         }
-        s = timer.summary()
-        if s is not None:
-            avg_ms, nimg, n = s
-            ach = ASPP_FLOP_PER_IMG * nimg / (avg_ms * 1e-3) / 1e12
-            traffic, tnote = None, "no PMC profile committed for this launch shape"
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_aspp_fwd.json")
-            if os.path.exists(pmc) and nimg == 8:       # HBM bytes per launch from the committed rocprofv3 --pmc passes
-                pj = json.load(open(pmc))
-                traffic = pj["hbm_bytes_x2_fetch"]
-                tnote = ("HBM bytes/launch from %s: (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correction); "
-                         "uncorrected %.0f MB; algorithmic %.0f MB" % (pj["source"], pj["hbm_bytes_uncorrected"] / 1e6,
-                                                                        pj["algorithmic_bytes"] / 1e6))
-            out["roofline"] = {"kernel": "hiast::aspp_fwd16_kernel<4,3>", "bound": "mfma", "achieved": ach,
-                               "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA,
-                               "traffic": traffic, "avg_launch_ms": avg_ms, "launches": n,
-                               "note": "fp32 MFMA peak; algorithmic 22.95 GFLOP/img x %d img per launch; %s" % (nimg, tnote)}
+        groups = timer.summary()
+        if groups:
+            key, avg_ms, n, _tot = groups[0]            # dominant hand-written launch group of the step
+            out["roofline"] = roofline_of(key, avg_ms, n, args.steps)
+            others = [roofline_of(k, a, c, args.steps) for k, a, c, _ in groups[1:4]]
+            out["roofline_other"] = [{kk: o[kk] for kk in ("kernel", "bound", "achieved", "peak", "unit", "frac",
+                                                            "traffic", "avg_launch_ms", "launches_per_step", "note")}
+                                     for o in others]
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(cfg, tuple(args.cpu_size), args.cpu_threads)
