@@ -32,6 +32,8 @@ class CopyPaste:
     def calculate_class_probs(self):
         v = np.asarray(self.class_value, np.float64)
         p = np.where(np.isinf(v), 0.0, (1 - np.where(np.isinf(v), 1.0, v)) ** 2)
+        if p.sum() <= 0:                   # every class at confidence 1.0: fall back to uniform over finite classes
+            p = np.where(np.isinf(v), 0.0, 1.0)
         return p / p.sum()
 
     def get_hard_classes(self, class_value):
@@ -54,10 +56,18 @@ class CopyPaste:
         return self.run_original(img, lbl)
 
     def random_select(self, selected_classes):
+        """rejection-sample a hard class (preprocessor.py:70-77).  Deviation: a class that no pseudo-labelled
+        image contains is rejected too (the reference would raise in np.random.choice on its empty file list);
+        with every hard class populated the draw sequence is identical to the reference's."""
         ids = [i for i in range(self.cfg.dataset.num_classes)]
+        usable = [c for c in selected_classes if len(self.samples_with_class.get(int(c), [])) > 0]
+        if not usable:
+            return None
+        if float(np.sum(self.class_probs[np.asarray(usable, dtype=int)])) <= 0.0:
+            return np.random.choice(usable)     # degenerate: all usable classes have sampling probability 0
         while True:
             c = np.random.choice(ids, size=1, replace=False, p=self.class_probs)[0]
-            if c in selected_classes:
+            if c in usable:
                 return c
 
     def run_original(self, img, lbl):
@@ -66,6 +76,8 @@ class CopyPaste:
         present (preprocessor.py:104-118); one paste is therefore the whole behaviour."""
         mask = np.full(lbl.shape, 255, dtype=np.uint8)
         c = self.random_select(self.hard_classes)
+        if c is None:                      # nothing to paste from
+            return img, lbl, mask
         name = np.random.choice(self.samples_with_class[c])
         img_, lbl_, _ = self.dataset_copy_from.load_data(self.dataset_copy_from.get_file_to_idx(name))
         if img.shape != img_.shape:

@@ -1,0 +1,153 @@
+"""End-to-end on the MI355X with the real HIP engine, on a synthetic Cityscapes-layout dataset:
+config 2 (IAS pseudo-label generation) -> config 3 (a few HIAST self-training iterations incl. CopyPaste, EMA,
+validation, checkpoints) -> validate.py.  The generator's artefacts are replayed against the oracle
+(bit-exact label maps / thresholds given the same low-res logits); mIoU is compared with the oracle's."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+H, W, C = 128, 256, 19
+
+
+@pytest.fixture(scope="module")
+def world(tmp_path_factory):
+    assert torch.cuda.is_available()
+    from hiast_amd.utils.registry import register  # noqa: F401
+    from hiast_amd.utils.registry.registries import MODEL
+    from hiast_amd.tools import synth_data
+    from make_golden import seeded_state_dict
+    root = str(tmp_path_factory.mktemp("e2e"))
+    cfg = synth_data.synthetic_cfg(root, n_train=6, n_val=4, h=H, w=W)
+    m = MODEL["SelfTrainingSegmentor"](cfg)
+    sd = {"seg_model." + k: v for k, v in seeded_state_dict(m.seg_model, 777).items()}
+    # calibrate the random-init head so that max-probs are spread over (0.1, 1): logits std ~ 3
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    ds = synth_data.make_sample(5, H, W)[0].astype(np.float32).transpose(2, 0, 1)[None] / 255.0
+    with torch.no_grad():
+        z = m(torch.from_numpy((ds - 0.45) / 0.225).cuda(), lowres=True)["logits_lowres"]
+    scale = 3.0 / float(z.std())
+    for i in range(4):
+        sd["seg_model.aspp.conv2d_list.%d.weight" % i] = sd["seg_model.aspp.conv2d_list.%d.weight" % i] * scale
+        sd["seg_model.aspp.conv2d_list.%d.bias" % i] = sd["seg_model.aspp.conv2d_list.%d.bias" % i] * scale
+    del m
+    ck = os.path.join(root, "warmup.pth")
+    torch.save(sd, ck)
+    cfg.pseudo_policy.resume_from = ck
+    cfg.train.resume_from = ck
+    cfg.validate.resume_from = ck
+    return cfg, sd, root
+
+
+def test_config2_generator_matches_oracle(world):
+    from PIL import Image
+    from oracle import cref, ias_ref
+    from hiast_amd.utils.registry.registries import PSEUDO_POLICY
+    cfg, sd, root = world
+    gen = PSEUDO_POLICY["IAS"](cfg)
+    gen.run()
+    pdir = cfg.pseudo_policy.save_dir
+    assert len(os.listdir(pdir)) == 6
+    thr = np.load(os.path.join(pdir, "..", "class_threshold.npy"))
+    stats = np.load(os.path.join(pdir, "..", "statics_class.npy"))
+    # replay: same model forward on the device for the low-res logits, then the ORACLE for everything else
+    st = ias_ref.IASState(C, cfg.pseudo_policy.ias.alpha, cfg.pseudo_policy.ias.beta, cfg.pseudo_policy.ias.gamma, 0.99)
+    model = gen.engine.model
+    for data in gen.t_loader:
+        with torch.no_grad():
+            z = model(data["images"].cuda(), lowres=True)["logits_lowres"].float().cpu().numpy()
+        mp, am = cref.plabel_stage_a(z, H, W)
+        plbl = st.step(mp, am.astype(np.int64), data["image_paths"])
+        for b, p in enumerate(data["image_paths"]):
+            name = os.path.splitext(os.path.basename(p))[0] + "_pseudo_label.png"
+            got = np.array(Image.open(os.path.join(pdir, name)))
+            assert np.array_equal(got, plbl[b]), name
+    assert np.array_equal(thr.view(np.uint64), st.class_threshold.view(np.uint64))
+    assert np.array_equal(stats, st.statics_class)
+    assert stats.sum() > 0, "the synthetic warm-up model should keep some pixels"
+    means = np.load(os.path.join(pdir, "..", "class_mean_probabilities.npy"))
+    assert np.allclose(means, st.class_mean_probs, rtol=1e-6)
+
+
+def test_config3_hiast_training_round(world):
+    """ConsistencySelfTrainingTrainer for a few iterations on the labels of config 2."""
+    from hiast_amd.utils.registry.registries import TRAINER
+    cfg, sd, root = world
+    c = cfg.clone()
+    c.trainer = "ConsistencySelfTrainingTrainer"
+    c.dataset.target.pseudo_dir = cfg.pseudo_policy.save_dir
+    c.dataset.target.aug_type = ["PRS-%d-%d" % (H, W), "CCA"]      # small views: 'MS' always crops to 512x1024
+    c.cst_training.is_enabled = True
+    c.cst_training.cst_loss.weight = 0.5
+    c.preprocessor.type = "CopyPaste"
+    c.train.gpu_num = 1
+    c.train.batch_size = 2
+    c.train.total_iter = 2
+    c.train.iter_report = 1
+    c.train.iter_val = 2
+    c.train.lr = 3e-6
+    c.work_dir = os.path.join(root, "work_hiast")
+    c.freeze()
+    tr = TRAINER[c.trainer](c, 0)
+    p0 = next(tr.model.module.seg_model.aspp.parameters()).detach().clone()
+    e0 = next(tr.ema_model.seg_model.aspp.parameters()).detach().clone()
+    losses = tr.train()
+    assert set(losses) == {"target_seg_loss", "kld_confident_loss", "ent_ignored_loss", "cst_loss"}
+    assert all(torch.isfinite(v) for v in losses.values()), losses
+    tr.run()
+    p1 = next(tr.model.module.seg_model.aspp.parameters()).detach()
+    e1 = next(tr.ema_model.seg_model.aspp.parameters()).detach()
+    assert not torch.equal(p0, p1), "student did not move"
+    assert not torch.equal(e0, e1) and (e1 - e0).abs().max() < (p1 - p0).abs().max(), "EMA teacher must lag"
+    ck = os.path.join(c.work_dir, "checkpoints")
+    assert {"model_last.pth", "ema_model_last.pth"} <= set(os.listdir(ck))
+    saved = torch.load(os.path.join(ck, "model_last.pth"), map_location="cpu")
+    assert list(saved.keys()) == list(sd.keys())          # reference state-dict keys, no 'module.' prefix
+
+
+def test_config3_plain_self_training_trainer(world):
+    from hiast_amd.utils.registry.registries import TRAINER
+    cfg, sd, root = world
+    c = cfg.clone()
+    c.trainer = "SelfTrainingTrainer"
+    c.dataset.target.pseudo_dir = cfg.pseudo_policy.save_dir
+    c.dataset.target.aug_type = ["PRS-%d-%d" % (H, W)]
+    c.train.gpu_num = 1
+    c.train.batch_size = 2
+    c.train.total_iter = 2
+    c.train.iter_report = 1
+    c.train.iter_val = 100
+    c.work_dir = os.path.join(root, "work_st")
+    c.freeze()
+    tr = TRAINER[c.trainer](c, 0)
+    tr.run()
+
+
+def test_validate_gpu_matches_oracle_miou(world):
+    from oracle import deeplab_ref, metrics_ref
+    from hiast_amd.workflows.validator import Validator
+    cfg, sd, root = world
+    c = cfg.clone()
+    c.model.type = "SourceOnlySegmentor"
+    c.freeze()
+    v = Validator(c, device=torch.device("cuda"))
+    miou = v.run()
+    inter = np.zeros(C, np.int64)
+    union = np.zeros(C, np.int64)
+    torch.set_num_threads(16)
+    for data in v.v_loader:
+        with torch.no_grad():
+            logits, _, _ = deeplab_ref.segmentor_logits(data["images"], sd)
+        pred = torch.softmax(logits, 1).argmax(1).numpy()
+        i, u = metrics_ref.intersection_and_union(pred, data["labels"].numpy(), C)
+        inter += i
+        union += u
+    want, _, _ = metrics_ref.miou(inter, union)
+    assert abs(miou - want) <= 0.05 / 100 + 1e-9, (miou, want)       # north_star: mIoU equal to reference +-0.05 (points)
