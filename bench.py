@@ -139,8 +139,12 @@ def roofline_of(key, avg_ms, n, steps):
     flop = 2.0 * M * 9 * Cin * Cout
     ach = flop / (avg_ms * 1e-3) / 1e12
     peak = 2500.0 / 3.0
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv3x3.json")
+    if os.path.exists(pmc) and (B, Hh, Ww, Cin, Cout) == (8, 64, 128, 256, 256):
+        traffic = json.load(open(pmc))["hbm_bytes_x2_fetch"]     # (2*FETCH_SIZE + WRITE_SIZE)*1024, see the file
     return {"kernel": "hiast::conv1x1_bn_act_kernel<float,128,9,false,true> (3x3 split-bf16 implicit GEMM + BN + ReLU)",
-            "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+            "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
             "avg_launch_ms": avg_ms, "launches_per_step": n / steps,
             "note": "algorithmic (fp32-equivalent) %.1f GFLOP per launch: B=%d %dx%d Cin=%d Cout=%d dil=%d; the kernel "
                     "issues 3 bf16 MFMA flops per algorithmic flop (hi*hi + hi*lo + lo*hi), so its ceiling is the dense "
