@@ -27,7 +27,13 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int C1_BM = 128;
 constexpr int C1_BK = 32;
-constexpr int C1_PITCH = 40;      // bf16 elements per LDS row (32 + 8 pad) = 80 bytes
+constexpr int C1_PITCH = 32;      // bf16 elements per LDS row: 64 bytes, no padding
+
+// LDS image of a [rows][32 bf16] tile: 64-byte rows whose four 16-byte chunks are XOR-swizzled with
+// (row >> 2) & 3.  A ds_read_b128 fragment read (16 lanes = 16 rows, same logical chunk) then touches
+// 16 distinct 4-bank columns and a ds_write_b64 staging store (16 lanes = 2 whole rows) 32 distinct banks:
+// both conflict free (the padded 80-byte rows measured 33 % of LDS cycles as bank conflicts on the stores).
+__device__ __forceinline__ int lds_off(int row, int chunk16) { return row * 64 + ((chunk16 ^ ((row >> 2) & 3)) << 4); }
 
 __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo)
 {
@@ -152,10 +158,10 @@ __global__ __launch_bounds__(256) void conv1x1_bn_act_kernel(
                 const float4 v = make_float4(__uint_as_float(ra[i].x), __uint_as_float(ra[i].y),
                                              __uint_as_float(ra[i].z), __uint_as_float(ra[i].w));
                 split4(v, hi, lo);
-                *reinterpret_cast<uint2*>(base + (row * C1_PITCH + cc * 4) * 2) = hi;
-                *reinterpret_cast<uint2*>(base + A_LO + (row * C1_PITCH + cc * 4) * 2) = lo;
+                *reinterpret_cast<uint2*>(base + lds_off(row, cc >> 1) + (cc & 1) * 8) = hi;
+                *reinterpret_cast<uint2*>(base + A_LO + lds_off(row, cc >> 1) + (cc & 1) * 8) = lo;
             } else {
-                *reinterpret_cast<uint4*>(base + (row * C1_PITCH + cc * 8) * 2) = ra[i];
+                *reinterpret_cast<uint4*>(base + lds_off(row, cc)) = ra[i];
             }
         }
 #pragma unroll
@@ -163,8 +169,8 @@ __global__ __launch_bounds__(256) void conv1x1_bn_act_kernel(
             const int f = tid + 256 * i, row = f >> 3, c4 = f & 7;
             uint2 hi, lo;
             split4(rb[i], hi, lo);
-            *reinterpret_cast<uint2*>(base + B_HI + (row * C1_PITCH + c4 * 4) * 2) = hi;
-            if (SPLIT) *reinterpret_cast<uint2*>(base + B_LO + (row * C1_PITCH + c4 * 4) * 2) = lo;
+            *reinterpret_cast<uint2*>(base + B_HI + lds_off(row, c4 >> 1) + (c4 & 1) * 8) = hi;
+            if (SPLIT) *reinterpret_cast<uint2*>(base + B_LO + lds_off(row, c4 >> 1) + (c4 & 1) * 8) = lo;
         }
     };
 
@@ -172,7 +178,7 @@ __global__ __launch_bounds__(256) void conv1x1_bn_act_kernel(
     lds_store(0);
     __syncthreads();
 
-    const int frow = lane & 31, fk = (lane >> 5) * 8;
+    const int frow = lane & 31, fchunk = lane >> 5;
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) gload(kt + 1);
@@ -182,13 +188,13 @@ __global__ __launch_bounds__(256) void conv1x1_bn_act_kernel(
             bf16x8 ah[2], al[2], bh[TN], bl[TN];
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
-                const int off = ((wm * 64 + a * 32 + frow) * C1_PITCH + kk * 16 + fk) * 2;
+                const int off = lds_off(wm * 64 + a * 32 + frow, kk * 2 + fchunk);
                 ah[a] = *reinterpret_cast<const bf16x8*>(base + off);
                 if (SPLIT) al[a] = *reinterpret_cast<const bf16x8*>(base + A_LO + off);
             }
 #pragma unroll
             for (int b = 0; b < TN; ++b) {
-                const int off = ((wn * (BN / 2) + b * 32 + frow) * C1_PITCH + kk * 16 + fk) * 2;
+                const int off = lds_off(wn * (BN / 2) + b * 32 + frow, kk * 2 + fchunk);
                 bh[b] = *reinterpret_cast<const bf16x8*>(base + B_HI + off);
                 if (SPLIT) bl[b] = *reinterpret_cast<const bf16x8*>(base + B_LO + off);
             }
