@@ -150,9 +150,20 @@ def all_reduce_average(tensor, world_size):
 
 
 def init_logger(log_path):
-    logging.basicConfig(format="[%(asctime)s-%(levelname)s]: %(message)s", filename=log_path, filemode="a",
-                        level=logging.INFO)
+    """[time-level] lines to <work_dir>/train.log (append) and to stderr, like the reference's
+    init_logger_and_writer (utils.py:173-183) minus tensorboardX; handlers are attached to the named
+    logger (not through logging.basicConfig, which only takes effect once per process)."""
     logger = logging.getLogger("UDA.trainer")
-    if not logger.handlers:
-        logger.addHandler(logging.StreamHandler())
+    logger.setLevel(logging.INFO)
+    for h in list(logger.handlers):
+        logger.removeHandler(h)
+        h.close()
+    fmt = logging.Formatter("[%(asctime)s-%(levelname)s]: %(message)s")
+    fh = logging.FileHandler(log_path, mode="a")
+    fh.setFormatter(fmt)
+    sh = logging.StreamHandler()
+    sh.setFormatter(fmt)
+    logger.addHandler(fh)
+    logger.addHandler(sh)
+    logger.propagate = False
     return logger

@@ -151,3 +151,57 @@ def test_validate_gpu_matches_oracle_miou(world):
         union += u
     want, _, _ = metrics_ref.miou(inter, union)
     assert abs(miou - want) <= 0.05 / 100 + 1e-9, (miou, want)       # north_star: mIoU equal to reference +-0.05 (points)
+
+
+def _write_yaml(cfg, path, extra=None):
+    import yaml
+    d = cfg.to_dict()
+    if extra:
+        for k, v in extra.items():
+            node = d
+            parts = k.split(".")
+            for p in parts[:-1]:
+                node = node[p]
+            node[parts[-1]] = v
+    with open(path, "w") as f:
+        yaml.safe_dump(d, f)
+
+
+def test_cli_entry_points(world, monkeypatch):
+    """the three reference CLIs (same flags) through `python -m hiast_amd.<script>`'s main(): generate -> train
+    -> validate, configured by YAML files exactly like the reference's configs/*.yaml"""
+    import importlib
+    import hiast_amd.utils.default_config as dc
+    cfg, sd, root = world
+    ydir = os.path.join(root, "yaml")
+    os.makedirs(ydir, exist_ok=True)
+    base = os.path.join(ydir, "sl.yaml")
+    _write_yaml(cfg, base, {"pseudo_policy.save_dir": None, "train.total_iter": 2, "train.iter_report": 1,
+                            "train.iter_val": 100, "train.batch_size": 2,
+                            "dataset.target.aug_type": ["PRS-%d-%d" % (H, W)], "trainer": "SelfTrainingTrainer"})
+
+    def fresh(modname):
+        # every reference script mutates the module-global cfg: give each CLI call a fresh default tree
+        dc.cfg = dc.get_default_cfg()
+        m = importlib.import_module(modname)
+        return importlib.reload(m)
+
+    save_dir = os.path.join(root, "cli_pseudo", "pseudo_labels")
+    gen = fresh("hiast_amd.generate_pseudo_labels")
+    gen.main(["--config_file", base, "--pseudo_resume_from", cfg.pseudo_policy.resume_from,
+              "--pseudo_save_dir", save_dir, "--batch_size", "3"])
+    assert len(os.listdir(save_dir)) == 6
+    assert os.path.exists(os.path.join(save_dir, "..", "samples_with_class.json"))
+
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    tr = fresh("hiast_amd.train")
+    work = os.path.join(root, "cli_work")
+    tr.main(["--config_file", base, "--resume_from", cfg.train.resume_from, "--pseudo_save_dir", save_dir,
+             "--work_dir", work])
+    assert os.path.exists(os.path.join(work, "sl.yaml")) and os.path.exists(os.path.join(work, "train.log"))
+
+    val = fresh("hiast_amd.validate")
+    vy = os.path.join(ydir, "validate.yaml")
+    _write_yaml(cfg, vy, {"model.type": "SourceOnlySegmentor", "pseudo_policy.save_dir": None})
+    miou = val.main(["--config_file", vy, "--resume_from", cfg.validate.resume_from, "--device", "cuda"])
+    assert 0.0 <= miou <= 1.0
