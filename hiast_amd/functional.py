@@ -130,9 +130,8 @@ class _BnActFn(torch.autograd.Function):
             return y
         part = K.bn_stats(x)
         count = float(x.shape[0] * x.shape[2] * x.shape[3])
-        if world > 1:
+        if world > 1:      # SyncBN: sum the per-plane partials across ranks in place (one collective, no extra kernels)
             import torch.distributed as dist
-            part = part.sum(1, keepdim=True).contiguous()
             dist.all_reduce(part)
             count *= world
         y, sm, si = K.bn_act_apply(x, res, gamma, beta, running_mean, running_var, part, count, momentum, eps, relu)
@@ -151,7 +150,6 @@ class _BnActFn(torch.autograd.Function):
         part = K.bn_act_bwd_stats(dy, y, x, sm, si, ctx.relu)
         if ctx.world > 1:
             import torch.distributed as dist
-            part = part.sum(1, keepdim=True).contiguous()
             dist.all_reduce(part)
         want_p = gamma is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3])
         dx, dres, dg, db = K.bn_act_bwd_apply(dy, y, x, gamma, sm, si, part, ctx.count, ctx.relu,
