@@ -338,7 +338,10 @@ def main():
             "metric": "self-training images/sec (fwd+bwd+pseudo-label) at 1024x512",
             "value": imgs / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16 (train fwd/bwd) + f32 (pseudo-label fwd, ASPP, losses)",
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "dtype_detail": "bf16 MFMA with fp32 accumulate everywhere: plain bf16 in the training step (the reference "
+                            "trains under apex O1), split-bf16 (hi*hi+hi*lo+lo*hi, fp32-class) in the pseudo-label "
+                            "forward; ASPP head exact fp32 MFMA; losses / softmax / thresholds fp32 + integer",
             "data": "synthetic",
             "config": {"workload": "configs[2] self-training round (%s, region-adaptive reg on) bs=%d/GPU @1024x512 "
                                    "+ configs[1] IAS pseudo-label pass on the same batch" % (args.trainer, args.batch),

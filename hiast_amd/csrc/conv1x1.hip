@@ -125,6 +125,14 @@ __global__ __launch_bounds__(256) void conv1x1_bn_act_kernel(
             rx[i] = (r - (r / geo.Wo) * geo.Wo) * geo.stride;
         }
     }
+    // Raw buffer loads: a lane whose tap falls outside the image gets a byte offset beyond num_records and
+    // the hardware returns zeros — zero padding without a select, which the optimiser turns back into a
+    // branch around the load (and a branchy load costs an s_waitcnt vmcnt(0) each).
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const unsigned x_bytes = (unsigned)(((TAPS == 1) ? (size_t)M : (size_t)(M / (geo.Ho * geo.Wo)) * geo.H * geo.W) *
+                                        K * sizeof(TA));
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)x_bytes, 0x00020000);
+    constexpr int OOB = (int)0x80000000;
     auto gload = [&](int kt) {
         const int tap = TAPS == 1 ? 0 : kt / kchunks;
         const int k0 = (TAPS == 1 ? kt : kt - tap * kchunks) * C1_BK;
@@ -137,9 +145,10 @@ __global__ __launch_bounds__(256) void conv1x1_bn_act_kernel(
             } else {
                 const int yy = ry[i] + oy, xx = rx[i] + ox;
                 const bool ok = yy >= 0 && yy < geo.H && xx >= 0 && xx < geo.W;
-                const size_t pix = ok ? ((size_t)rn[i] * geo.H + yy) * geo.W + xx : 0;
-                const uint4 v = *reinterpret_cast<const uint4*>(X + pix * K + k0 + cc * A_PER);
-                ra[i] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
+                const int pix = (rn[i] * geo.H + yy) * geo.W + xx;
+                const int voff = ok ? (int)(((size_t)pix * K + k0 + cc * A_PER) * sizeof(TA)) : OOB;
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, 0, 0);
+                ra[i] = make_uint4(v.x, v.y, v.z, v.w);
             }
         }
 #pragma unroll
@@ -380,6 +389,10 @@ static int launch_conv(const void* x, const float* w, const float* gamma, const 
     if (M <= 0 || K <= 0 || N <= 0) return HIAST_E_ARG;
     if (K % hiast::C1_BK != 0 || N % 64 != 0 || M > (1ll << 31) - 256 || (dtype != 0 && dtype != 1)) return HIAST_E_RANGE;
     if ((((uintptr_t)x) | ((uintptr_t)w) | ((uintptr_t)y) | ((uintptr_t)res)) & 15) return HIAST_E_RANGE;
+    if (taps != 1) {   // buffer-descriptor addressing of the 3x3 input: byte offsets and the out-of-range marker need 31 bits
+        const size_t in_pix = (size_t)(M / ((size_t)geo.Ho * geo.Wo)) * geo.H * geo.W;
+        if (in_pix * K * (dtype ? 2 : 4) >= (1ull << 31)) return HIAST_E_RANGE;
+    }
     if (dtype == 0)
         return launch_conv_t<float>(x, w, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, st);
     return launch_conv_t<__hip_bfloat16>(x, w, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, st);
