@@ -55,12 +55,36 @@ def hist_quantile(hist_c, thr, q):
 
 
 def ias_threshold(hist, thr_prev, alpha, gamma):
-    """get_ias_threshold on histograms -> float32 [C]"""
+    """get_ias_threshold on histograms -> float32 [C].  Same arithmetic as hist_quantile per class, with the
+    cumulative sums of all classes taken in one pass (this runs between the two GPU passes of every batch)."""
     C = hist.shape[0]
+    # max-probs are >= 1/C, so the low bins are empty: start the cumulative sums at the first used bin
+    used = hist.any(axis=0)
+    first = int(np.argmax(used)) if used.any() else hist.shape[1] - 1
+    cum = np.cumsum(hist[:, first:], axis=1, dtype=np.int64)
+    bins = BIN_VALUE[first:]
+    thr_prev = np.asarray(thr_prev, np.float64)
     out = np.ones(C, dtype=np.float32)
+    idx = np.searchsorted(bins, thr_prev, side="left")
     for c in range(C):
-        q = 1 - alpha * thr_prev[c] ** gamma
-        out[c] = hist_quantile(hist[c], thr_prev[c], q)
+        cc = cum[c]
+        n = int(cc[-1]) + 1
+        thr = thr_prev[c]
+        r = int(cc[idx[c] - 1]) if idx[c] > 0 else 0
+        q = 1 - alpha * thr ** gamma
+        vi = (n - 1) * q
+        lo = np.floor(vi)
+        g = vi - lo
+        lo = int(lo)
+        hi = lo + 1
+        if vi >= n - 1:
+            lo = hi = n - 1
+        if vi < 0:
+            lo = hi = 0
+        a = thr if lo == r else bins[cc.searchsorted(lo if lo < r else lo - 1, side="right")]
+        b = a if hi == lo else (thr if hi == r else bins[cc.searchsorted(hi if hi < r else hi - 1, side="right")])
+        d = b - a
+        out[c] = (b - d * (1 - g)) if g >= 0.5 else (a + d * g)
     return out
 
 
