@@ -32,6 +32,11 @@ SIGNATURES = {
     "hiast_aspp_fwd": (c_int, [c_vp, c_vp, c_vp] + [c_int] * 5 + [c_vp, c_vp, c_sz, c_vp]),
     "hiast_aspp_bwd_data": (c_int, [c_vp, c_vp, c_vp] + [c_int] * 5 + [c_vp, c_vp]),
     "hiast_aspp_bwd_weight": (c_int, [c_vp] * 7 + [c_int] * 5 + [c_vp, c_vp, c_sz, c_vp]),
+    "hiast_aspp2_np": (c_int, [c_int]),
+    "hiast_aspp2_workspace_bytes": (c_sz, [c_int] * 6),
+    "hiast_aspp2_pack_weights": (c_int, [c_vp] * 8 + [c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "hiast_aspp2_fwd": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp] + [c_int] * 5 + [c_vp, c_vp, c_sz, c_vp]),
+    "hiast_aspp2_bwd": (c_int, [c_vp] * 9 + [c_int] * 5 + [c_vp, c_vp, c_sz, c_vp]),
     "hiast_bn_workspace_bytes": (c_sz, [c_int, c_int]),
     "hiast_bn_stats": (c_int, [c_vp, c_int, c_int, c_i64, c_int, c_vp, c_vp]),
     "hiast_bn_act_apply": (c_int, [c_vp] * 8 + [c_int, ctypes.c_double, c_f32, c_f32, c_int, c_vp, c_vp,

@@ -60,11 +60,13 @@ struct ConvGeo {
 // TA = float : fp32 activations, split-bf16 arithmetic (3 MFMAs per operand pair)   [pseudo-label forward]
 // TA = bf16  : bf16 activations in/out, plain bf16 MFMA (fp32 accumulate), weights converted from the fp32
 //              master copy while staging                                           [teacher forward under AMP]
-template <typename TA, int BN, int TAPS, bool RES, bool RELU>
+// TO = output (and residual) element type: TA, or float for a bf16 GEMM whose result is consumed in fp32
+// (the ASPP tap GEMM of aspp2.hip).  mean == nullptr: no BatchNorm (scale 1, shift 0) — a plain GEMM.
+template <typename TA, typename TO, int BN, int TAPS, bool RES, bool RELU>
 __global__ __launch_bounds__(256) void conv1x1_bn_act_kernel(
     const TA* __restrict__ X, const float* __restrict__ W, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ var, float eps,
-    const TA* __restrict__ R, TA* __restrict__ Y, int M, int K, int N, ConvGeo geo)
+    const TO* __restrict__ R, TO* __restrict__ Y, int M, int K, int N, ConvGeo geo)
 {
     constexpr bool SPLIT = sizeof(TA) == 4;
     constexpr int TN = BN / 64;                       // 32-wide column tiles per wave (2 or 1)
@@ -233,9 +235,12 @@ __global__ __launch_bounds__(256) void conv1x1_bn_act_kernel(
     for (int b = 0; b < TN; ++b) {
         const int nl = wn * (BN / 2) + b * 32 + (lane & 31);
         const int n = n0 + nl;
-        const float invstd = 1.0f / sqrtf(var[n] + eps);
-        const float sc = (gamma ? gamma[n] : 1.0f) * invstd;
-        const float sh = fmaf(-mean[n], sc, beta ? beta[n] : 0.0f);
+        float sc = 1.0f, sh = 0.0f;
+        if (mean) {
+            const float invstd = 1.0f / sqrtf(var[n] + eps);
+            sc = (gamma ? gamma[n] : 1.0f) * invstd;
+            sh = fmaf(-mean[n], sc, beta ? beta[n] : 0.0f);
+        }
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -245,7 +250,7 @@ __global__ __launch_bounds__(256) void conv1x1_bn_act_kernel(
             }
     }
     __syncthreads();
-    if (SPLIT) {
+    if (sizeof(TO) == 4) {
         constexpr int F4_PER_ROW = BN / 4;
 #pragma unroll 4
         for (int f = tid; f < C1_BM * F4_PER_ROW; f += 256) {
@@ -360,7 +365,7 @@ __global__ __launch_bounds__(256) void bn_act_nhwc_bf16_kernel(const unsigned sh
 
 }  // namespace hiast
 
-template <typename TA>
+template <typename TA, typename TO>
 static int launch_conv_t(const void* x, const float* w, const float* gamma, const float* beta, const float* mean,
                          const float* var, float eps, const void* res, int relu, void* y, int64_t M, int K, int N,
                          int taps, hiast::ConvGeo geo, hipStream_t st)
@@ -368,8 +373,8 @@ static int launch_conv_t(const void* x, const float* w, const float* gamma, cons
     const int BN = (N % 128 == 0) ? 128 : 64;
     dim3 grid((unsigned)((M + hiast::C1_BM - 1) / hiast::C1_BM), N / BN);
 #define L(BNV, T, RES, RELU)                                                                                       \
-    hipLaunchKernelGGL((hiast::conv1x1_bn_act_kernel<TA, BNV, T, RES, RELU>), grid, dim3(256), 0, st, (const TA*)x, \
-                       w, gamma, beta, mean, var, eps, (const TA*)res, (TA*)y, (int)M, K, N, geo)
+    hipLaunchKernelGGL((hiast::conv1x1_bn_act_kernel<TA, TO, BNV, T, RES, RELU>), grid, dim3(256), 0, st,          \
+                       (const TA*)x, w, gamma, beta, mean, var, eps, (const TO*)res, (TO*)y, (int)M, K, N, geo)
 #define LL(BNV, T)                                                              \
     if (res) { if (relu) L(BNV, T, true, true); else L(BNV, T, true, false); }  \
     else { if (relu) L(BNV, T, false, true); else L(BNV, T, false, false); }
@@ -385,17 +390,29 @@ static int launch_conv(const void* x, const float* w, const float* gamma, const 
                        const float* var, float eps, const void* res, int relu, void* y, int64_t M, int K, int N,
                        int taps, hiast::ConvGeo geo, int dtype, hipStream_t st)
 {
-    if (!x || !w || !mean || !var || !y) return HIAST_E_ARG;
+    if (!x || !w || !y || (mean && !var)) return HIAST_E_ARG;
     if (M <= 0 || K <= 0 || N <= 0) return HIAST_E_ARG;
-    if (K % hiast::C1_BK != 0 || N % 64 != 0 || M > (1ll << 31) - 256 || (dtype != 0 && dtype != 1)) return HIAST_E_RANGE;
+    if (K % hiast::C1_BK != 0 || N % 64 != 0 || M > (1ll << 31) - 256 || dtype < 0 || dtype > 2) return HIAST_E_RANGE;
     if ((((uintptr_t)x) | ((uintptr_t)w) | ((uintptr_t)y) | ((uintptr_t)res)) & 15) return HIAST_E_RANGE;
     if (taps != 1) {   // buffer-descriptor addressing of the 3x3 input: byte offsets and the out-of-range marker need 31 bits
         const size_t in_pix = (size_t)(M / ((size_t)geo.Ho * geo.Wo)) * geo.H * geo.W;
         if (in_pix * K * (dtype ? 2 : 4) >= (1ull << 31)) return HIAST_E_RANGE;
     }
     if (dtype == 0)
-        return launch_conv_t<float>(x, w, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, st);
-    return launch_conv_t<__hip_bfloat16>(x, w, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, st);
+        return launch_conv_t<float, float>(x, w, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, st);
+    if (dtype == 2)
+        return launch_conv_t<__hip_bfloat16, float>(x, w, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps,
+                                                    geo, st);
+    return launch_conv_t<__hip_bfloat16, __hip_bfloat16>(x, w, gamma, beta, mean, var, eps, res, relu, y, M, K, N,
+                                                         taps, geo, st);
+}
+
+// plain GEMM entry for other translation units (aspp2.hip): Y[M][N] = X[M][K] * W[N][K]^T, no BN / residual / ReLU.
+// dtype: 0 = fp32 in (split-bf16 arithmetic) / fp32 out, 1 = bf16 in / bf16 out, 2 = bf16 in / fp32 out.
+int hiast_gemm_nt_launch(const void* x, const float* w, void* y, int64_t M, int K, int N, int dtype, hipStream_t st)
+{
+    hiast::ConvGeo geo = {0, 0, 0, 0, 1, 1};
+    return launch_conv(x, w, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, 0, y, M, K, N, 1, geo, dtype, st);
 }
 
 extern "C" int hiast_conv1x1_bn_act_nhwc(const void* x, const float* w, const float* gamma, const float* beta,

@@ -45,6 +45,42 @@ def aspp(x, weights, biases, dil=ASPP_DILATIONS):
     return _AsppFn.apply(x, *weights, *biases, tuple(dil))
 
 
+class _Aspp2Fn(torch.autograd.Function):
+    """ASPP_V2.forward on a CHANNELS-LAST feature map (fp32: split-bf16 arithmetic, inference only; bf16: the
+    mixed-precision training step) as one GEMM + 33-tap shift-add (hiast_aspp2_*); y is fp32 NCHW."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, x, w0, w1, w2, w3, b0, b1, b2, b3, dil, need_bwd):
+        ws = [w.detach().float().contiguous() for w in (w0, w1, w2, w3)]
+        bs = [b.detach().float().contiguous() for b in (b0, b1, b2, b3)]
+        if need_bwd and x.dtype != torch.bfloat16:
+            raise TypeError("the channels-last ASPP backward is the bf16 one; fp32 training uses hiast_amd.functional.aspp")
+        wt, wd, bias = K.aspp2_pack_weights(ws, bs, need_dgrad=need_bwd and ctx.needs_input_grad[0])
+        y = K.aspp2_fwd(x, wt, bias, dil)
+        ctx.save_for_backward(x, wd)
+        ctx.dil = dil
+        return y
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, gy):
+        x, wd = ctx.saved_tensors
+        gy = gy.contiguous().float()
+        want_dx = ctx.needs_input_grad[0]
+        want_dw = any(ctx.needs_input_grad[1:9])
+        gx, gws, gb = K.aspp2_bwd(x, gy, wd, ctx.dil, want_dx, want_dw)
+        if gws is None:
+            gws = [None] * 4
+        return (gx, gws[0], gws[1], gws[2], gws[3], gb, gb, gb, gb, None, None)
+
+
+def aspp_nhwc(x, weights, biases, dil=ASPP_DILATIONS):
+    """x: logical [B,Cin,h,w] with channels-last memory (fp32 without grad, or bf16)"""
+    need_bwd = torch.is_grad_enabled() and any(t.requires_grad for t in (x, *weights, *biases))
+    return _Aspp2Fn.apply(x, *weights, *biases, tuple(dil), need_bwd)
+
+
 class _UpsampleFn(torch.autograd.Function):
     """F.interpolate(x, size, mode='bilinear', align_corners=True) (self_training_segmentor.py:27)"""
 

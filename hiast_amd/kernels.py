@@ -212,6 +212,92 @@ def aspp_bwd_weight(x, dy, dil, workspace=None):
     return dws, db
 
 
+# ------------------------------------------------------------------------------- K1b ASPP on NHWC (GEMM + shift-add)
+def _nhwc_view(x):
+    """logical [B,C,h,w] tensor whose memory is channels-last contiguous -> ([B,h,w,C] contiguous view, dtype code)"""
+    if not isinstance(x, torch.Tensor) or not x.is_cuda:
+        raise _lib.HiastLibraryError("x must be a CUDA(HIP) tensor: the HIP path has no CPU fallback")
+    if x.dim() != 4:
+        raise ValueError("x must be [B,C,h,w]")
+    v = x.permute(0, 2, 3, 1)
+    if not v.is_contiguous():
+        raise ValueError("x must be channels-last contiguous")
+    if x.dtype == torch.float32:
+        return v, 0
+    if x.dtype == torch.bfloat16:
+        return v, 1
+    raise TypeError("aspp_nhwc takes float32 or bfloat16 activations, got %s" % x.dtype)
+
+
+def aspp2_pack_weights(weights, biases, need_dgrad=True):
+    """-> (wt [NP,Cin], wd [Cin,NP] or None, bias [Cout]) fp32"""
+    assert len(weights) == 4 and len(biases) == 4
+    Cout, Cin = weights[0].shape[:2]
+    for wt_, b in zip(weights, biases):
+        _req(wt_, torch.float32, 4, "aspp weight")
+        _req(b, torch.float32, 1, "aspp bias")
+        assert tuple(wt_.shape) == (Cout, Cin, 3, 3) and b.numel() == Cout
+    lib = _lib.load()
+    NP = lib.hiast_aspp2_np(Cout)
+    if NP == 0:
+        raise _lib.HiastLibraryError("hiast_aspp2: unsupported Cout %d" % Cout)
+    dev = weights[0].device
+    wt = torch.empty((NP, Cin), dtype=torch.float32, device=dev)
+    wd = torch.empty((Cin, NP), dtype=torch.float32, device=dev) if need_dgrad else None
+    bias = torch.empty((Cout,), dtype=torch.float32, device=dev)
+    check(lib.hiast_aspp2_pack_weights(*[_ptr(t) for t in weights], *[_ptr(t) for t in biases], Cin, Cout, _ptr(wt),
+                                       _ptr(wd), _ptr(bias), _stream()), "hiast_aspp2_pack_weights")
+    return wt, wd, bias
+
+
+def aspp2_workspace(B, Cin, h, w, Cout, backward, device):
+    n = _lib.load().hiast_aspp2_workspace_bytes(B, Cin, h, w, Cout, int(bool(backward)))
+    if n == 0:
+        raise _lib.HiastLibraryError("hiast_aspp2: unsupported shape B=%d Cin=%d %dx%d Cout=%d" % (B, Cin, h, w, Cout))
+    return torch.empty((n + 15) // 16 * 4, dtype=torch.float32, device=device)
+
+
+def aspp2_fwd(x, wt, bias, dil, workspace=None):
+    """x: logical [B,Cin,h,w], channels-last memory, fp32 (split-bf16 arithmetic) or bf16 -> y [B,Cout,h,w] fp32 NCHW"""
+    xv, dt = _nhwc_view(x)
+    B, h, w, Cin = xv.shape
+    _req(wt, torch.float32, 2, "wt")
+    _req(bias, torch.float32, 1, "bias")
+    Cout = bias.numel()
+    lib = _lib.load()
+    assert tuple(wt.shape) == (lib.hiast_aspp2_np(Cout), Cin), "wt does not match (Cin, Cout)"
+    ws = workspace if workspace is not None else aspp2_workspace(B, Cin, h, w, Cout, False, x.device)
+    y = torch.empty((B, Cout, h, w), dtype=torch.float32, device=x.device)
+    check(lib.hiast_aspp2_fwd(_ptr(xv), dt, _ptr(wt), _ptr(bias), _ptr(y), B, Cin, h, w, Cout, _dil(dil), _ptr(ws),
+                              ws.numel() * 4, _stream()), "hiast_aspp2_fwd")
+    return y
+
+
+def aspp2_bwd(x, dy, wd, dil, want_dx=True, want_dw=True, workspace=None):
+    """x bf16 channels-last (logical [B,Cin,h,w]); dy [B,Cout,h,w] fp32 -> (dx bf16 channels-last or None,
+    [dW_i fp32 [Cout,Cin,3,3]] or None, db or None)"""
+    xv, dt = _nhwc_view(x)
+    if dt != 1:
+        raise TypeError("aspp2_bwd is the mixed-precision backward: x must be bfloat16")
+    B, h, w, Cin = xv.shape
+    _req(dy, torch.float32, 4, "dy")
+    Cout = dy.shape[1]
+    assert tuple(dy.shape) == (B, Cout, h, w)
+    lib = _lib.load()
+    NP = lib.hiast_aspp2_np(Cout)
+    if want_dx:
+        _req(wd, torch.float32, 2, "wd")
+        assert tuple(wd.shape) == (Cin, NP)
+    ws = workspace if workspace is not None else aspp2_workspace(B, Cin, h, w, Cout, True, x.device)
+    dx = torch.empty((B, h, w, Cin), dtype=torch.bfloat16, device=x.device) if want_dx else None
+    dws = [torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=x.device) for _ in range(4)] if want_dw else [None] * 4
+    db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_dw else None
+    check(lib.hiast_aspp2_bwd(_ptr(xv), _ptr(dy), _ptr(wd) if want_dx else _ptr(None), _ptr(dx),
+                              *[_ptr(t) for t in dws], _ptr(db), B, Cin, h, w, Cout, _dil(dil), _ptr(ws),
+                              ws.numel() * 4, _stream()), "hiast_aspp2_bwd")
+    return (dx.permute(0, 3, 1, 2) if want_dx else None), (dws if want_dw else None), db
+
+
 # ------------------------------------------------------------------------------- K11 EMA
 class EmaPlan:
     """Device tables for one (ema parameters, student parameters) pairing; built once."""

@@ -128,7 +128,7 @@ class ResNet(nn.Module):
         for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
             for blk in stage:
                 o = blk.forward_eval_nhwc(o)
-        return o.contiguous()            # back to NCHW for the ASPP kernel (fp32 cast happens there)
+        return o      # logical NCHW, channels-last memory: the ASPP head (hiast_aspp2_fwd) reads it as is
 
     def forward(self, x, is_return_low=False):
         if not is_return_low and self._fast_eval_ok(x):

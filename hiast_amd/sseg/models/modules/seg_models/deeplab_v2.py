@@ -6,6 +6,7 @@ The ASPP head runs as ONE hand-written gfx950 kernel over the four dilations on 
 (hiast_aspp_fwd / _bwd_data / _bwd_weight); on CPU tensors (config 1: CPU-only validate) the
 Conv2d holders run as plain torch convs.  `representation` keeps its parameters for checkpoint
 compatibility but is not computed: the reference computes it and drops the result (:63)."""
+import torch
 import torch.nn as nn
 
 from hiast_amd import functional as HF
@@ -26,7 +27,16 @@ class ASPP_V2(nn.Module):
 
     def forward(self, x):
         if x.is_cuda:
-            return HF.aspp(x, [m.weight for m in self.conv2d_list], [m.bias for m in self.conv2d_list], self.dilations)
+            ws, bs = [m.weight for m in self.conv2d_list], [m.bias for m in self.conv2d_list]
+            gemm_ok = x.shape[1] % 128 == 0 and ws[0].shape[0] <= 32
+            if gemm_ok and x.dtype == torch.bfloat16:
+                # mixed-precision step (teacher / student under autocast): channels-last GEMM + shift-add, bf16 MFMA
+                return HF.aspp_nhwc(x.contiguous(memory_format=torch.channels_last), ws, bs, self.dilations)
+            if (gemm_ok and x.dtype == torch.float32 and not torch.is_grad_enabled()
+                    and x.permute(0, 2, 3, 1).is_contiguous()):
+                # fp32 inference on the channels-last trunk output (pseudo-label forward): split-bf16 GEMM
+                return HF.aspp_nhwc(x, ws, bs, self.dilations)
+            return HF.aspp(x, ws, bs, self.dilations)   # exact-fp32 direct form (fp32 training, NCHW inference)
         out = self.conv2d_list[0](x)
         for m in self.conv2d_list[1:]:
             out = out + m(x)

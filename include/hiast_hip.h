@@ -132,6 +132,29 @@ int hiast_aspp_bwd_weight(const float* x, const float* dy, float* dw0, float* dw
                           const int* dil, void* workspace, size_t workspace_bytes,
                           hiast_stream_t stream);
 
+/* ---- K1b: the same ASPP head on CHANNELS-LAST activations, as one GEMM + a 33-tap shift-add ------------
+ * (deeplab_v2.py:20-24 + autograd, as K1).  T[p][tap*Cout+co] = Σ_ci x[p][ci]*W[tap][co][ci] is a plain
+ * [B*h*w x Cin] x [Cin x NP] GEMM on the bf16 matrix cores (NP = hiast_aspp2_np(Cout) = 33*Cout rounded up to
+ * 128), y[co][q] = bias[co] + Σ_tap T[q+off(tap)][tap*Cout+co]: the feature map is read once instead of 33x.
+ * x_nhwc [B,h,w,Cin]; dtype 0 = fp32 (split-bf16 arithmetic, fp32-class: the pseudo-label forward),
+ * 1 = bf16 (training step under mixed precision; the reference trains under apex O1). y [B,Cout,h,w] fp32 (NCHW,
+ * what the loss / pseudo-label kernels read).  Cin % 128 == 0, Cout <= 32.
+ * pack: wt [NP][Cin] fp32 (forward / wgrad layout), wd [Cin][NP] fp32 (dgrad layout; may be NULL), bias [Cout].
+ * bwd (bf16 x only): dy [B,Cout,h,w] fp32 -> dx_nhwc [B,h,w,Cin] bf16 (NULL = skip), dW_i [Cout,Cin,3,3] fp32 and
+ * db [Cout] (all NULL = skip); fp32 accumulation, pixel-range split with a fixed-order reduce (bitwise
+ * reproducible, no float atomics).  workspace: hiast_aspp2_workspace_bytes(..., backward) bytes. */
+int hiast_aspp2_np(int Cout);
+size_t hiast_aspp2_workspace_bytes(int B, int Cin, int h, int w, int Cout, int backward);
+int hiast_aspp2_pack_weights(const float* w0, const float* w1, const float* w2, const float* w3,
+                             const float* b0, const float* b1, const float* b2, const float* b3, int Cin,
+                             int Cout, float* wt, float* wd, float* bias, hiast_stream_t stream);
+int hiast_aspp2_fwd(const void* x_nhwc, int dtype, const float* wt, const float* bias, float* y, int B, int Cin,
+                    int h, int w, int Cout, const int* dil, void* workspace, size_t workspace_bytes,
+                    hiast_stream_t stream);
+int hiast_aspp2_bwd(const void* x_nhwc, const float* dy, const float* wd, void* dx_nhwc, float* dw0, float* dw1,
+                    float* dw2, float* dw3, float* db, int B, int Cin, int h, int w, int Cout, const int* dil,
+                    void* workspace, size_t workspace_bytes, hiast_stream_t stream);
+
 /* ---- K10: BatchNorm2d (+ residual) (+ ReLU), fused ----------------------------------------
  * The conv -> BN -> ReLU / conv -> BN -> (+identity) -> ReLU chains of Bottleneck.forward,
  * sseg/models/modules/resnet.py:78-98 (separate BN / add / ReLU passes in the reference).  "Frozen" BN still
@@ -174,6 +197,7 @@ int hiast_bn_act_bwd_apply(const void* dy, const void* y, const void* x, const f
  *          (workflows/trainer/consistency_self_training_trainer.py:113-116 under apex O1).
  * Weights stay fp32 master copies: w [N = Cout][K] (1x1: the conv weight as stored; 3x3: permuted (0,2,3,1) to
  * [Cout][3][3][Cin]).  x [M = B*H*W][K = Cin]; 3x3: padding = dilation, stride 1 or 2, Ho = (H-1)/stride + 1.
+ * dtype 2 (1x1 only): bf16 activations in, fp32 out/residual.  mean == NULL: no BatchNorm (a plain GEMM).
  * Cin % 32 == 0, Cout % 64 == 0, 16-byte aligned buffers.
  * hiast_bn_act_nhwc_infer: y[m][c] = act(x[m][c]*scale_c + shift_c) for the stem (library 7x7 conv) output. */
 int hiast_conv1x1_bn_act_nhwc(const void* x, const float* w, const float* gamma, const float* beta,

@@ -248,6 +248,110 @@ def test_aspp_bwd_vs_torch(K, shape):
     assert np.allclose(db.cpu().numpy(), bt[0].grad.numpy(), rtol=1e-5, atol=1e-5)
 
 
+ASPP2_SHAPES = [(1, 128, 9, 17, 19), (2, 256, 16, 32, 19), (1, 2048, 9, 17, 19), (3, 256, 30, 41, 9), (2, 128, 5, 70, 32)]
+
+
+def _bf16r(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).bfloat16().float().numpy()
+
+
+def _aspp2_rounded_weights(ws):
+    """what the bf16 GEMM multiplies with: every tap rounded to bf16, the four centre taps summed in fp32
+    (ascending) first — expressed as four conv weights again so the direct-form oracle can consume them"""
+    out = [_bf16r(w) for w in ws]
+    centre = ((ws[0][:, :, 1, 1] + ws[1][:, :, 1, 1]) + ws[2][:, :, 1, 1]) + ws[3][:, :, 1, 1]
+    out[0][:, :, 1, 1] = _bf16r(centre)
+    for i in (1, 2, 3):
+        out[i][:, :, 1, 1] = 0.0
+    return out
+
+
+def _cl(t):
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+@pytest.mark.parametrize("shape", ASPP2_SHAPES)
+@pytest.mark.parametrize("dil", [(6, 12, 18, 24), (1, 2, 3, 5)])
+def test_aspp2_fwd_fp32_split(K, shape, dil):
+    """channels-last GEMM + shift-add form, split-bf16 arithmetic, vs the C oracle (double accumulation) on the
+    SAME fp32 inputs: fp32-class (contract on logits: 1e-3 relative)."""
+    B, Cin, h, w, C = shape
+    x, ws, bs = _aspp_inputs(140, B, Cin, h, w, C)
+    wt, _, bias = K.aspp2_pack_weights([dev(t) for t in ws], [dev(t) for t in bs], need_dgrad=False)
+    y = K.aspp2_fwd(_cl(dev(x)), wt, bias, dil).cpu().numpy()
+    want = cref.aspp_fwd(x, ws, bs, dil)
+    assert np.abs(y - want).max() <= 3e-5 * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize("shape", ASPP2_SHAPES)
+def test_aspp2_fwd_bf16(K, shape):
+    """bf16 operands, fp32 accumulation: exact reference = the oracle on the bf16-rounded operands"""
+    B, Cin, h, w, C = shape
+    dil = (6, 12, 18, 24)
+    x, ws, bs = _aspp_inputs(150, B, Cin, h, w, C)
+    wt, _, bias = K.aspp2_pack_weights([dev(t) for t in ws], [dev(t) for t in bs], need_dgrad=False)
+    y = K.aspp2_fwd(_cl(dev(x).bfloat16()), wt, bias, dil).cpu().numpy()
+    want = cref.aspp_fwd(_bf16r(x), _aspp2_rounded_weights(ws), bs, dil)
+    assert np.abs(y - want).max() <= 3e-5 * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize("shape", [(2, 256, 16, 32, 19), (1, 512, 9, 17, 19), (2, 256, 20, 70, 9), (1, 128, 64, 128, 19)])
+def test_aspp2_bwd_vs_torch(K, shape):
+    """mixed-precision dgrad / wgrad (bf16 operands, fp32 accumulate) vs autograd of torch-CPU float64 convs on
+    the bf16-rounded operands; dx is delivered in bf16 (2^-9 relative rounding)."""
+    B, Cin, h, w, C = shape
+    dil = (6, 12, 18, 24)
+    x, ws, bs = _aspp_inputs(160, B, Cin, h, w, C)
+    gy = synth.normal_f32(170, (B, C, h, w))
+    xt = torch.from_numpy(_bf16r(x)).double().requires_grad_(True)
+    wt_ = [torch.from_numpy(t).double().requires_grad_(True) for t in _aspp2_rounded_weights(ws)]
+    y = sum(torch.nn.functional.conv2d(xt, wt_[i], None, 1, dil[i], dil[i]) for i in range(4))
+    y.backward(torch.from_numpy(_bf16r(gy)).double())
+    _, wd, _ = K.aspp2_pack_weights([dev(t) for t in ws], [dev(t) for t in bs], need_dgrad=True)
+    xd = _cl(dev(x).bfloat16())
+    dx, dws, db = K.aspp2_bwd(xd, dev(gy), wd, dil)
+    assert dx.shape == xd.shape and dx.permute(0, 2, 3, 1).is_contiguous()
+    ref = xt.grad.numpy()
+    err = np.abs(dx.float().cpu().numpy() - ref)
+    assert (err <= 2.0 ** -8 * np.abs(ref) + 1e-4 * np.abs(ref).max()).all()
+    for i in range(4):
+        r = wt_[i].grad.numpy().copy()
+        if i:
+            r[:, :, 1, 1] = wt_[0].grad.numpy()[:, :, 1, 1]      # every branch's centre tap sees the same gradient
+        assert np.abs(dws[i].cpu().numpy() - r).max() <= 5e-5 * np.abs(r).max(), i
+    assert np.allclose(db.cpu().numpy(), gy.astype(np.float64).sum((0, 2, 3)), rtol=1e-5, atol=1e-5)
+    # deterministic: fixed-order split reduction
+    dx2, dws2, _ = K.aspp2_bwd(xd, dev(gy), wd, dil)
+    assert torch.equal(dx, dx2) and all(torch.equal(a, b) for a, b in zip(dws, dws2))
+
+
+def test_aspp_nhwc_autograd_matches_direct_form(K):
+    """functional.aspp_nhwc (bf16, channels-last) against functional.aspp (exact fp32, NCHW) on the same data:
+    forward within bf16 operand rounding, gradients within bf16 rounding of x / dY."""
+    from hiast_amd import functional as HF
+    B, Cin, h, w, C = 2, 256, 24, 40, 19
+    x, ws, bs = _aspp_inputs(180, B, Cin, h, w, C)
+    gy = dev(synth.normal_f32(190, (B, C, h, w)))
+    outs = []
+    for nhwc in (False, True):
+        xt = dev(x).requires_grad_(True)
+        wts = [dev(t).requires_grad_(True) for t in ws]
+        bts = [dev(t).requires_grad_(True) for t in bs]
+        if nhwc:
+            y = HF.aspp_nhwc(_cl(xt.bfloat16()), wts, bts)
+        else:
+            y = HF.aspp(xt, wts, bts)
+        y.backward(gy)
+        outs.append((y.detach(), xt.grad, [t.grad for t in wts], [t.grad for t in bts]))
+    (y0, gx0, gw0, gb0), (y1, gx1, gw1, gb1) = outs
+    assert (y0 - y1).abs().max() <= 2e-2 * y0.abs().max()
+    assert (gx0 - gx1.float()).abs().max() <= 2e-2 * gx0.abs().max()
+    for a, b in zip(gw0, gw1):
+        assert (a - b).abs().max() <= 2e-2 * a.abs().max()
+    for a, b in zip(gb0, gb1):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-5)
+
+
 def test_ema_bit_exact(K):
     shapes = [(7, 5), (70001,), (3, 2, 3, 3), (64, 2048, 1, 1)]
     e = [synth.normal_f32(70 + i, s) for i, s in enumerate(shapes)]

@@ -49,6 +49,26 @@ def main():
             print("%-18s B=%d  median %8.3f ms  best %8.3f ms  %7.2f TFLOP/s (algorithmic, fp32)" %
                   (name, B, med, best, gf / med if "pack" not in name else 0))
         del x, dy
+    if "aspp2" in which:
+        ws = [torch.randn(C, Cin, 3, 3, device=dev) * 0.01 for _ in range(4)]
+        bs = [torch.randn(C, device=dev) * 0.1 for _ in range(4)]
+        dy = torch.randn(B, C, h, w, device=dev)
+        wt, wd, bias = K.aspp2_pack_weights(ws, bs)
+        gf = 2.0 * h * w * C * Cin * 36 * B / 1e9
+        x32 = torch.randn(B, Cin, h, w, device=dev).contiguous(memory_format=torch.channels_last)
+        x16 = x32.bfloat16()
+        wsf = K.aspp2_workspace(B, Cin, h, w, C, False, dev)
+        wsb = K.aspp2_workspace(B, Cin, h, w, C, True, dev)
+        for name, fn in (("aspp2_pack", lambda: K.aspp2_pack_weights(ws, bs)),
+                         ("aspp2_fwd fp32split", lambda: K.aspp2_fwd(x32, wt, bias, dil, wsf)),
+                         ("aspp2_fwd bf16", lambda: K.aspp2_fwd(x16, wt, bias, dil, wsf)),
+                         ("aspp2_bwd dx only", lambda: K.aspp2_bwd(x16, dy, wd, dil, True, False, wsb)),
+                         ("aspp2_bwd dw only", lambda: K.aspp2_bwd(x16, dy, wd, dil, False, True, wsb)),
+                         ("aspp2_bwd both", lambda: K.aspp2_bwd(x16, dy, wd, dil, True, True, wsb))):
+            med, best = timeit(fn)
+            print("%-20s B=%d  median %8.3f ms  best %8.3f ms  %7.2f TFLOP/s (algorithmic)" %
+                  (name, B, med, best, gf / med * (2 if "both" in name else 1) if "pack" not in name else 0), flush=True)
+        del x32, x16, dy
     if "plabel" in which:
         z = torch.randn(B, C, h, w, device=dev) * 3
         med, best = timeit(lambda: K.plabel_pass1(z, H, W))
