@@ -22,6 +22,9 @@
 #include "common.h"
 
 int hiast_gemm_nt_launch(const void* x, const float* w, void* y, int64_t M, int K, int N, int dtype, hipStream_t st);
+int hiast_igemm_launch(const void* x, const void* wp, const float* gamma, const float* beta, const float* mean,
+                       const float* var, float eps, const void* res, int relu, void* y, int64_t M, int K, int N,
+                       int taps, int H, int W, int stride, int dil, int planes, int out_f32, hipStream_t st);
 
 namespace hiast {
 
@@ -358,21 +361,25 @@ extern "C" int hiast_aspp2_pack_weights(const float* w0, const float* w1, const 
     return 0;
 }
 
-extern "C" int hiast_aspp2_fwd(const void* x_nhwc, int dtype, const float* wt, const float* bias, float* y, int B,
+extern "C" int hiast_aspp2_fwd(const void* x_nhwc, int dtype, const void* wt, const float* bias, float* y, int B,
                                int Cin, int h, int w, int Cout, const int* dil, void* workspace,
                                size_t workspace_bytes, hiast_stream_t stream)
 {
     if (!x_nhwc || !wt || !bias || !y || !dil || !workspace) return HIAST_E_ARG;
     int e = aspp2_check(B, Cin, h, w, Cout);
     if (e) return e;
-    if (dtype != 0 && dtype != 1) return HIAST_E_RANGE;
+    if (dtype < 0 || dtype > 2) return HIAST_E_RANGE;
     const int NP = aspp2_np(Cout);
     const long long M = (long long)B * h * w;
     if (workspace_bytes < (size_t)M * NP * sizeof(float)) return HIAST_E_WS;
     if ((((uintptr_t)x_nhwc) | ((uintptr_t)workspace) | ((uintptr_t)wt)) & 15) return HIAST_E_RANGE;
     hipStream_t st = (hipStream_t)stream;
     float* T = (float*)workspace;
-    e = hiast_gemm_nt_launch(x_nhwc, wt, T, M, Cin, NP, dtype == 0 ? 0 : 2, st);
+    if (dtype == 0)      // fp32 rows, fp32 weights: the register-staged kernel splits on the fly
+        e = hiast_gemm_nt_launch(x_nhwc, (const float*)wt, T, M, Cin, NP, 0, st);
+    else                 // bf16 rows (1) / split planes (2) with weights packed by hiast_pack_conv_weight: LDS-DMA kernel
+        e = hiast_igemm_launch(x_nhwc, wt, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, 0, T, M, Cin, NP, 1, 0, 0,
+                               1, 1, dtype, 1, st);
     if (e) return e;
     const hiast::Taps2 taps = hiast::make_taps2(dil);
     hipLaunchKernelGGL(hiast::aspp2_shift_add_kernel, dim3((h * w + 63) / 64, B), dim3(256), 0, st, T, bias, y, h, w,
@@ -381,7 +388,7 @@ extern "C" int hiast_aspp2_fwd(const void* x_nhwc, int dtype, const float* wt, c
     return 0;
 }
 
-extern "C" int hiast_aspp2_bwd(const void* x_nhwc, const float* dy, const float* wd, void* dx_nhwc, float* dw0,
+extern "C" int hiast_aspp2_bwd(const void* x_nhwc, const float* dy, const void* wd, void* dx_nhwc, float* dw0,
                                float* dw1, float* dw2, float* dw3, float* db, int B, int Cin, int h, int w, int Cout,
                                const int* dil, void* workspace, size_t workspace_bytes, hiast_stream_t stream)
 {
@@ -405,7 +412,9 @@ extern "C" int hiast_aspp2_bwd(const void* x_nhwc, const float* dy, const float*
                        h, w, Cout, NP, taps);
     HIAST_CHECK_LAUNCH();
     if (dx_nhwc) {
-        e = hiast_gemm_nt_launch(G, wd, dx_nhwc, M, NP, Cin, 1, st);       // dX[M][Cin] = G[M][NP] * wd[Cin][NP]^T
+        // dX[M][Cin] = G[M][NP] * wd[Cin][NP]^T, wd packed bf16 (hiast_pack_conv_weight, planes = 1)
+        e = hiast_igemm_launch(G, wd, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, 0, dx_nhwc, M, NP, Cin, 1, 0, 0, 1,
+                               1, 1, 0, st);
         if (e) return e;
     }
     if (want_w) {

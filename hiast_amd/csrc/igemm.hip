@@ -1,0 +1,485 @@
+// K9c — trunk convolutions (1x1 and 3x3, dilated / strided) of the inference forwards as an implicit GEMM whose
+// operands reach LDS by LDS-DMA (buffer_load ... lds), fused with BatchNorm(eval) + residual + ReLU
+// (reference: Bottleneck.forward, sseg/models/modules/resnet.py:78-98: conv -> bn -> relu / += identity as separate
+//  cuDNN / ATen passes).
+//
+//   Y[m][n] = act( (Σ_tap Σ_k X[m + off(tap)][k] * W[n][tap][k]) * scale_n + shift_n (+ R[m][n]) )
+//
+// Operand formats (channels-last, 16-bit).  Every row is a sequence of 128-byte SLABS, one per k-step:
+//   PL = 2  "split planes": an fp32-class value v is stored as hi = bf16(v), lo = bf16(v - hi); slab j of a row
+//           holds channels 32j .. 32j+31 as [hi x32 | lo x32] (4 bytes per value, like fp32).  The product is
+//           accumulated in fp32 as hi*hi + lo*hi + hi*lo on v_mfma_f32_32x32x16_bf16 (the dropped lo*lo term is
+//           2^-16 relative): ~5e-6 of max|Y| against fp64 at 3/16 of the exact-fp32 MFMA cost (gfx950 has no
+//           TF32/xf32).  The split is done ONCE, by the producing kernel's epilogue (and once per weight by
+//           hiast_pack_conv_weight) — conv1x1.hip re-splits every operand element in every block that stages it.
+//   PL = 1  plain bf16 rows; a slab is 64 consecutive channels (mixed-precision teacher forward).
+// Weights: Wp[n][tap][slab] (hiast_pack_conv_weight).
+//
+// Structure: 256 x BN block tile (BN = 256 | 128 | 64), 8 waves, one slab of k per step.  A k-step's tile
+// ((256 + BN) rows x 128 B) is written into LDS by the DMA path: each wave-instruction moves 8 whole 128-byte
+// lines (one row slab each: full L2 lines, the 64-byte half lines of a BK=32 bf16 tile measured ~10 TB/s chip-wide)
+// to a wave-uniform LDS address + 16 B x lane; the bank-conflict-free XOR swizzle of the image is therefore
+// applied to each lane's SOURCE chunk and again by the fragment reads.  Out-of-image taps and tail rows use a
+// buffer offset beyond num_records, for which the DMA writes zeros: zero padding costs no instruction.  Two LDS
+// buffers (the DMA of k-step t+1 flies while the MFMAs of k-step t run), one barrier per k-step, no VGPR staging
+// and no VALU in the loop besides address selection.  The 256-row tile halves the L2->LDS bytes per MFMA of a
+// 128 x 128 tile, which is what bounded the earlier kernels (~9 TB/s of L2 reads at 35 % MFMA utilisation).
+#include <hip/hip_bf16.h>
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace hiast {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 ig_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float ig_f32x16;
+
+constexpr int IG_BM = 256;
+
+struct IGeo {
+    int H, W, Ho, Wo, stride, dil;
+};
+
+// LDS image of a [rows][128 B] tile: 16-byte chunk c of row r lives at chunk c ^ ((r >> 1) & 7).  A ds_read_b128
+// fragment read (16 lanes = 16 distinct rows of a 32-row fragment, same logical chunk) then covers all sixteen
+// 16-byte slots of the 256-byte bank row: conflict free.
+__device__ __forceinline__ int ig_lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+__device__ __forceinline__ void ig_split(float v, unsigned short& h, unsigned short& l)
+{
+    const __hip_bfloat16 hb = __float2bfloat16(v);
+    h = __bfloat16_as_ushort(hb);
+    l = __bfloat16_as_ushort(__float2bfloat16(v - __bfloat162float(hb)));
+}
+
+typedef __attribute__((address_space(3))) void* ig_lds_ptr;
+
+// LDS-DMA: 64 lanes x 16 bytes from buffer offset (voff per lane + soff) to lds + 16*lane (lds wave-uniform).
+// Kept in a NON-template function: with the builtin inside a kernel template, hipcc (ROCm 7.2) emits no host
+// stub for the instantiations.
+__device__ __forceinline__ void ig_dma16(__amdgpu_buffer_rsrc_t rs, unsigned char* lds, int voff, int soff)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (ig_lds_ptr)lds, 16, voff, soff, 0, 0);
+}
+
+// element offset (in bf16 units) of channel c (a multiple of 8) of row m in a [M][C] activation
+template <int PL>
+__device__ __forceinline__ size_t ig_elem(size_t m, int c, int C)
+{
+    if (PL == 2) return (m * (C >> 5) + (c >> 5)) * 64 + (c & 31);     // lo plane: + 32
+    return m * C + c;
+}
+
+// OUTF32: write fp32 [M][N] — the ASPP tap GEMM; otherwise the output has the input's format.
+// Waves: WM x WN = 8; wave tile (256/WM) x (BN/WN) with BN/WN == 64.
+template <int PL, bool OUTF32, int BN, int TAPS, bool RES, bool RELU>
+__global__ __launch_bounds__(512) void igemm_bn_act_kernel(
+    const unsigned short* __restrict__ X, const unsigned short* __restrict__ Wp, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ var, float eps,
+    const unsigned short* __restrict__ R, void* __restrict__ Yv, int M, int K, int N, IGeo geo)
+{
+    constexpr int WN = BN / 64, WM = 8 / WN;
+    constexpr int TM = IG_BM / WM / 32;                 // 32-row tiles per wave (4 | 2 | 1)
+    constexpr int TN = 2;                               // 32-column tiles per wave
+    constexpr int KK = PL == 2 ? 2 : 4;                 // 16-deep MFMA steps per slab
+    constexpr int A_BYTES = IG_BM * 128, B_BYTES = BN * 128;
+    constexpr int BUF_BYTES = A_BYTES + B_BYTES;
+    constexpr int BG = BN / 64;                         // 8-row B groups per wave (4 | 2 | 1)
+    constexpr int EP = 68;                              // padded row of a wave's private epilogue tile (floats)
+    static_assert(2 * BUF_BYTES >= 8 * 32 * EP * 4, "epilogue staging must fit in the tile buffers");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * BUF_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    int bm, bn_;
+    {   // XCD-aware tile order (see conv1x1.hip): channel tile fastest, XCD k takes the k-th contiguous eighth
+        const int gx = gridDim.x, gy = gridDim.y, total = gx * gy;
+        int lid = blockIdx.x + gx * blockIdx.y;
+        if ((total & 7) == 0) lid = (lid & 7) * (total >> 3) + (lid >> 3);
+        bn_ = lid % gy;
+        bm = lid / gy;
+    }
+    const int m0 = bm * IG_BM, n0 = bn_ * BN;
+    const int KS = (K * PL) >> 6;                       // slabs per row (= k-steps per tap)
+    const int nk = TAPS * KS;
+
+    // ---- DMA addressing.  This wave fills A row groups {4*wave .. 4*wave+3} (8 rows each) and B row groups
+    // {BG*wave ..}; lane l supplies row (l >> 3) of a group and the logical 16-byte chunk that belongs at
+    // physical chunk (l & 7) of that row in the swizzled image.
+    const int srow = lane >> 3;
+    constexpr int OOB = (int)0x80000000;
+    const size_t in_pix = (TAPS == 1) ? (size_t)M : (size_t)(M / (geo.Ho * geo.Wo)) * geo.H * geo.W;
+    const __amdgpu_buffer_rsrc_t xrs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)(in_pix * KS * 128), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)Wp, 0, (int)((size_t)N * TAPS * KS * 128), 0x00020000);
+    int an[4], ay[4], ax[4], achunk[4];   // per A row group: image / row / column of the (stride-scaled) output pixel
+    bool aok[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int rl = (4 * wave + g) * 8 + srow;                      // tile row
+        achunk[g] = ((lane & 7) ^ ((rl >> 1) & 7)) * 16;
+        const int m = m0 + rl;
+        aok[g] = m < M;
+        const int mc = aok[g] ? m : 0;
+        if (TAPS == 1) {
+            an[g] = mc; ay[g] = 0; ax[g] = 0;
+        } else {
+            const int hw = geo.Ho * geo.Wo;
+            an[g] = mc / hw;
+            const int r = mc - an[g] * hw;
+            ay[g] = (r / geo.Wo) * geo.stride;
+            ax[g] = (r - (r / geo.Wo) * geo.Wo) * geo.stride;
+        }
+    }
+    int bvoff[BG];
+#pragma unroll
+    for (int g = 0; g < BG; ++g) {
+        const int rl = (BG * wave + g) * 8 + srow;
+        bvoff[g] = (int)((size_t)(n0 + rl) * TAPS * KS * 128) + ((lane & 7) ^ ((rl >> 1) & 7)) * 16;
+    }
+
+    // one DMA piece of k-step kt: p < 4 -> A row group p of this wave, else B row group p - 4
+    constexpr int NPIECE = 4 + BG;
+    auto piece = [&](int kt, int buf, int p) {
+        const int tap = TAPS == 1 ? 0 : kt / KS;
+        const int j = TAPS == 1 ? kt : kt - tap * KS;
+        unsigned char* base = smem + buf * BUF_BYTES;
+        if (p < 4) {
+            const int g = p;
+            int voff;
+            if (TAPS == 1) {
+                voff = aok[g] ? (int)((size_t)an[g] * KS * 128) + achunk[g] : OOB;
+            } else {
+                const int yy = ay[g] + (tap / 3 - 1) * geo.dil, xx = ax[g] + (tap % 3 - 1) * geo.dil;
+                const bool ok = aok[g] && yy >= 0 && yy < geo.H && xx >= 0 && xx < geo.W;
+                const int pix = (an[g] * geo.H + yy) * geo.W + xx;
+                voff = ok ? (int)((size_t)pix * KS * 128) + achunk[g] : OOB;
+            }
+            ig_dma16(xrs, base + (4 * wave + g) * 1024, voff, j * 128);
+        } else {
+            const int g = p - 4;
+            ig_dma16(wrs, base + A_BYTES + (BG * wave + g) * 1024, bvoff[g], (tap * KS + j) * 128);
+        }
+    };
+
+    ig_f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+#pragma unroll
+    for (int p = 0; p < NPIECE; ++p) piece(0, 0, p);
+    const int frow = lane & 31, fh = lane >> 5;
+    constexpr int NSLOT = KK * TM;                      // MFMA groups per k-step; the DMA pieces of the NEXT k-step
+                                                        // are issued between them, not in one burst after the barrier
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's share of tile kt has landed
+        __syncthreads();                                          // everyone's has; everyone left buffer buf^1
+        const bool more = kt + 1 < nk;
+        const unsigned char* ta = smem + buf * BUF_BYTES;
+        const unsigned char* tb = ta + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            ig_bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int row = wm * (TM * 32) + a * 32 + frow;
+                ah[a] = *reinterpret_cast<const ig_bf16x8*>(ta + ig_lds_off(row, kk * 2 + fh));
+                if (PL == 2) al[a] = *reinterpret_cast<const ig_bf16x8*>(ta + ig_lds_off(row, 4 + kk * 2 + fh));
+            }
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int row = wn * 64 + b * 32 + frow;
+                bh[b] = *reinterpret_cast<const ig_bf16x8*>(tb + ig_lds_off(row, kk * 2 + fh));
+                if (PL == 2) bl[b] = *reinterpret_cast<const ig_bf16x8*>(tb + ig_lds_off(row, 4 + kk * 2 + fh));
+            }
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int slot = kk * TM + a;
+                if (more) {
+#pragma unroll
+                    for (int p = 0; p < NPIECE; ++p)
+                        if (p >= slot * NPIECE / NSLOT && p < (slot + 1) * NPIECE / NSLOT) piece(kt + 1, buf ^ 1, p);
+                }
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    if (PL == 2) {
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+                    }
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: each wave moves its 32 x 64 sub-tiles through a PRIVATE LDS tile (BN scale/shift applied on
+    // the way in), then every lane owns 8 consecutive channels of a row: residual (+), ReLU, conversion and
+    // 16-byte stores (hi and lo of a 32-channel slab together fill one 128-byte line).
+    __syncthreads();                                    // all waves are done with the operand tiles
+    float* sW = reinterpret_cast<float*>(smem) + wave * (32 * EP);
+    float sc[TN], sh[TN];
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int n = n0 + wn * 64 + b * 32 + (lane & 31);
+        sc[b] = 1.0f; sh[b] = 0.0f;
+        if (mean) {
+            const float invstd = 1.0f / sqrtf(var[n] + eps);
+            sc[b] = (gamma ? gamma[n] : 1.0f) * invstd;
+            sh[b] = fmaf(-mean[n], sc[b], beta ? beta[n] : 0.0f);
+        }
+    }
+    const int erow = lane >> 3, ec8 = lane & 7;
+    const int nc = n0 + wn * 64 + ec8 * 8;
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                sW[rl * EP + b * 32 + (lane & 31)] = fmaf(acc[a][b][r], sc[b], sh[b]);
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int rl = ps * 8 + erow;
+            const int m = m0 + wm * (TM * 32) + a * 32 + rl;
+            float o[8];
+            const float4 o0 = *reinterpret_cast<const float4*>(sW + rl * EP + ec8 * 8);
+            const float4 o1 = *reinterpret_cast<const float4*>(sW + rl * EP + ec8 * 8 + 4);
+            o[0] = o0.x; o[1] = o0.y; o[2] = o0.z; o[3] = o0.w; o[4] = o1.x; o[5] = o1.y; o[6] = o1.z; o[7] = o1.w;
+            if (m < M) {
+                if (RES) {
+                    const size_t g = ig_elem<PL>((size_t)m, nc, N);
+                    const uint4 rh = *reinterpret_cast<const uint4*>(R + g);
+                    const unsigned wh[4] = {rh.x, rh.y, rh.z, rh.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        o[2 * q] += __uint_as_float(wh[q] << 16);
+                        o[2 * q + 1] += __uint_as_float(wh[q] & 0xFFFF0000u);
+                    }
+                    if (PL == 2) {
+                        const uint4 rl4 = *reinterpret_cast<const uint4*>(R + g + 32);
+                        const unsigned wl[4] = {rl4.x, rl4.y, rl4.z, rl4.w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            o[2 * q] += __uint_as_float(wl[q] << 16);
+                            o[2 * q + 1] += __uint_as_float(wl[q] & 0xFFFF0000u);
+                        }
+                    }
+                }
+                if (RELU) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) o[q] = o[q] > 0.f ? o[q] : 0.f;
+                }
+                if (OUTF32) {
+                    float* Y = reinterpret_cast<float*>(Yv) + (size_t)m * N + nc;
+                    *reinterpret_cast<float4*>(Y) = make_float4(o[0], o[1], o[2], o[3]);
+                    *reinterpret_cast<float4*>(Y + 4) = make_float4(o[4], o[5], o[6], o[7]);
+                } else {
+                    unsigned short* Y = reinterpret_cast<unsigned short*>(Yv) + ig_elem<PL>((size_t)m, nc, N);
+                    unsigned ph[4], pl_[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        unsigned short h0, l0, h1, l1;
+                        ig_split(o[2 * q], h0, l0);
+                        ig_split(o[2 * q + 1], h1, l1);
+                        ph[q] = (unsigned)h0 | ((unsigned)h1 << 16);
+                        pl_[q] = (unsigned)l0 | ((unsigned)l1 << 16);
+                    }
+                    *reinterpret_cast<uint4*>(Y) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+                    if (PL == 2) *reinterpret_cast<uint4*>(Y + 32) = make_uint4(pl_[0], pl_[1], pl_[2], pl_[3]);
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// fp32 conv weight [N][K][taps] (torch layout; taps = kh*kw) -> Wp[N][taps][slabs of 128 B] bf16
+template <int PL>
+__global__ __launch_bounds__(256) void pack_conv_weight_kernel(const float* __restrict__ w,
+                                                               unsigned short* __restrict__ wp, int N, int K, int taps)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)N * taps * K) return;
+    const int k = (int)(idx % K);
+    const int t = (int)((idx / K) % taps);
+    const int n = (int)(idx / ((long long)K * taps));
+    const float v = w[((size_t)n * K + k) * taps + t];
+    unsigned short h, l;
+    ig_split(v, h, l);
+    unsigned short* row = wp + ((size_t)n * taps + t) * PL * K;
+    if (PL == 2) {
+        unsigned short* dst = row + (size_t)(k >> 5) * 64 + (k & 31);
+        dst[0] = h;
+        dst[32] = l;
+    } else {
+        row[k] = h;
+    }
+}
+
+// fp32 [M][C] -> split planes (and back: v = hi + lo, exact in fp32)
+__global__ __launch_bounds__(256) void to_planes_kernel(const float* __restrict__ x, unsigned short* __restrict__ p,
+                                                        long long M, int C)
+{
+    const long long total8 = M * C / 8;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long long)gridDim.x * 256) {
+        const long long m = (i * 8) / C;
+        const int c = (int)((i * 8) - m * C);
+        const float4 a = reinterpret_cast<const float4*>(x)[2 * i], b = reinterpret_cast<const float4*>(x)[2 * i + 1];
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        unsigned ph[4], pl_[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned short h0, l0, h1, l1;
+            ig_split(v[2 * q], h0, l0);
+            ig_split(v[2 * q + 1], h1, l1);
+            ph[q] = (unsigned)h0 | ((unsigned)h1 << 16);
+            pl_[q] = (unsigned)l0 | ((unsigned)l1 << 16);
+        }
+        unsigned short* dst = p + ig_elem<2>((size_t)m, c, C);
+        *reinterpret_cast<uint4*>(dst) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+        *reinterpret_cast<uint4*>(dst + 32) = make_uint4(pl_[0], pl_[1], pl_[2], pl_[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void from_planes_kernel(const unsigned short* __restrict__ p, float* __restrict__ x,
+                                                          long long M, int C)
+{
+    const long long total8 = M * C / 8;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long long)gridDim.x * 256) {
+        const long long m = (i * 8) / C;
+        const int c = (int)((i * 8) - m * C);
+        const unsigned short* src = p + ig_elem<2>((size_t)m, c, C);
+        const uint4 h = *reinterpret_cast<const uint4*>(src), l = *reinterpret_cast<const uint4*>(src + 32);
+        const unsigned wh[4] = {h.x, h.y, h.z, h.w}, wl[4] = {l.x, l.y, l.z, l.w};
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            v[2 * q] = __uint_as_float(wh[q] << 16) + __uint_as_float(wl[q] << 16);
+            v[2 * q + 1] = __uint_as_float(wh[q] & 0xFFFF0000u) + __uint_as_float(wl[q] & 0xFFFF0000u);
+        }
+        reinterpret_cast<float4*>(x)[2 * i] = make_float4(v[0], v[1], v[2], v[3]);
+        reinterpret_cast<float4*>(x)[2 * i + 1] = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
+
+}  // namespace hiast
+
+template <int PL, bool OUTF32>
+static int launch_igemm_t(const void* x, const void* wp, const float* gamma, const float* beta, const float* mean,
+                          const float* var, float eps, const void* res, int relu, void* y, int64_t M, int K, int N,
+                          int taps, hiast::IGeo geo, hipStream_t st)
+{
+    int BN = (N % 256 == 0) ? 256 : ((N % 128 == 0) ? 128 : 64);
+    if (const char* env = getenv("HIAST_IGEMM_BN")) {          // tuning override
+        const int v = atoi(env);
+        if ((v == 64 || v == 128 || v == 256) && N % v == 0) BN = v;
+    }
+    dim3 grid((unsigned)((M + hiast::IG_BM - 1) / hiast::IG_BM), N / BN);
+#define L(BNV, T, RES, RELU)                                                                                         \
+    hipLaunchKernelGGL((hiast::igemm_bn_act_kernel<PL, OUTF32, BNV, T, RES, RELU>), grid, dim3(512), 0, st,           \
+                       (const unsigned short*)x, (const unsigned short*)wp, gamma, beta, mean, var, eps,              \
+                       (const unsigned short*)res, y, (int)M, K, N, geo)
+#define LL(BNV, T)                                                              \
+    if (res) { if (relu) L(BNV, T, true, true); else L(BNV, T, true, false); }  \
+    else { if (relu) L(BNV, T, false, true); else L(BNV, T, false, false); }
+    if (taps == 1) { if (BN == 256) { LL(256, 1) } else if (BN == 128) { LL(128, 1) } else { LL(64, 1) } }
+    else { if (BN == 256) { LL(256, 9) } else if (BN == 128) { LL(128, 9) } else { LL(64, 9) } }
+#undef LL
+#undef L
+    HIAST_CHECK_LAUNCH();
+    return 0;
+}
+
+// shared launcher (also used by aspp2.hip for the ASPP tap GEMM)
+int hiast_igemm_launch(const void* x, const void* wp, const float* gamma, const float* beta, const float* mean,
+                       const float* var, float eps, const void* res, int relu, void* y, int64_t M, int K, int N,
+                       int taps, int H, int W, int stride, int dil, int planes, int out_f32, hipStream_t st)
+{
+    if (!x || !wp || !y || (mean && !var)) return HIAST_E_ARG;
+    if (M <= 0 || K <= 0 || N <= 0) return HIAST_E_ARG;
+    if ((planes != 1 && planes != 2) || (taps != 1 && taps != 9)) return HIAST_E_RANGE;
+    if ((K * planes) % 64 != 0 || N % 64 != 0 || M > (1ll << 31) - 512) return HIAST_E_RANGE;
+    if (out_f32 && res) return HIAST_E_RANGE;
+    if ((((uintptr_t)x) | ((uintptr_t)wp) | ((uintptr_t)y) | ((uintptr_t)res)) & 15) return HIAST_E_RANGE;
+    hiast::IGeo geo = {0, 0, 0, 0, 1, 1};
+    size_t in_pix = (size_t)M;
+    if (taps != 1) {
+        if (H <= 0 || W <= 0 || stride <= 0 || dil <= 0) return HIAST_E_ARG;
+        const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+        if (M % ((int64_t)Ho * Wo) != 0) return HIAST_E_ARG;
+        geo = {H, W, Ho, Wo, stride, dil};
+        in_pix = (size_t)(M / ((int64_t)Ho * Wo)) * H * W;
+    }
+    // buffer-descriptor addressing: byte offsets and the out-of-range marker need 31 bits
+    if (in_pix * planes * K * 2 >= (1ull << 31) || (size_t)N * taps * planes * K * 2 >= (1ull << 31)) return HIAST_E_RANGE;
+    if (planes == 2) {
+        if (out_f32) return launch_igemm_t<2, true>(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, st);
+        return launch_igemm_t<2, false>(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, st);
+    }
+    if (out_f32) return launch_igemm_t<1, true>(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, st);
+    return launch_igemm_t<1, false>(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, st);
+}
+
+extern "C" int hiast_igemm_bn_act(const void* x, const void* wp, const float* gamma, const float* beta,
+                                  const float* mean, const float* var, float eps, const void* res, int relu, void* y,
+                                  int B, int H, int W, int Cin, int Cout, int taps, int stride, int dil, int planes,
+                                  int out_f32, hiast_stream_t stream)
+{
+    if (B <= 0 || H <= 0 || W <= 0) return HIAST_E_ARG;
+    if (taps == 1 && stride != 1) return HIAST_E_RANGE;       // strided 1x1: subsample the input first
+    const int Ho = taps == 1 ? H : (H - 1) / stride + 1, Wo = taps == 1 ? W : (W - 1) / stride + 1;
+    return hiast_igemm_launch(x, wp, gamma, beta, mean, var, eps, res, relu, y, (int64_t)B * Ho * Wo, Cin, Cout, taps, H,
+                              W, stride, dil, planes, out_f32, (hipStream_t)stream);
+}
+
+extern "C" int hiast_pack_conv_weight(const float* w, int N, int K, int taps, int planes, void* wp,
+                                      hiast_stream_t stream)
+{
+    if (!w || !wp) return HIAST_E_ARG;
+    if (N <= 0 || K <= 0 || taps <= 0) return HIAST_E_ARG;
+    if (planes != 1 && planes != 2) return HIAST_E_RANGE;
+    const long long total = (long long)N * K * taps;
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (planes == 2)
+        hipLaunchKernelGGL(hiast::pack_conv_weight_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, w,
+                           (unsigned short*)wp, N, K, taps);
+    else
+        hipLaunchKernelGGL(hiast::pack_conv_weight_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, w,
+                           (unsigned short*)wp, N, K, taps);
+    HIAST_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int hiast_split_planes(float* x, void* planes, int64_t M, int C, int inverse, hiast_stream_t stream)
+{
+    if (!x || !planes) return HIAST_E_ARG;
+    if (M <= 0 || C <= 0) return HIAST_E_ARG;
+    if (C % 32 != 0 || ((((uintptr_t)x) | ((uintptr_t)planes)) & 15)) return HIAST_E_RANGE;
+    const long long total8 = (long long)M * C / 8;
+    long long nb = (total8 + 255) / 256;
+    const int grid = (int)(nb < 1 ? 1 : (nb > 8192 ? 8192 : nb));
+    if (inverse)
+        hipLaunchKernelGGL(hiast::from_planes_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                           (const unsigned short*)planes, x, (long long)M, C);
+    else
+        hipLaunchKernelGGL(hiast::to_planes_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x,
+                           (unsigned short*)planes, (long long)M, C);
+    HIAST_CHECK_LAUNCH();
+    return 0;
+}

@@ -257,25 +257,33 @@ def aspp2_workspace(B, Cin, h, w, Cout, backward, device):
     return torch.empty((n + 15) // 16 * 4, dtype=torch.float32, device=device)
 
 
-def aspp2_fwd(x, wt, bias, dil, workspace=None):
-    """x: logical [B,Cin,h,w], channels-last memory, fp32 (split-bf16 arithmetic) or bf16 -> y [B,Cout,h,w] fp32 NCHW"""
-    xv, dt = _nhwc_view(x)
-    B, h, w, Cin = xv.shape
+def aspp2_fwd(x, wt, bias, dil, workspace=None, planes=None):
+    """x: logical [B,Cin,h,w] with channels-last memory, fp32 (split-bf16 arithmetic) or bf16; or, with planes=2,
+    a split-plane tensor [B,h,w,2*Cin] (K9c format).  wt: fp32 [NP,Cin] from aspp2_pack_weights.
+    -> y [B,Cout,h,w] fp32 NCHW"""
     _req(wt, torch.float32, 2, "wt")
     _req(bias, torch.float32, 1, "bias")
+    if planes == 2:
+        _req(x, torch.bfloat16, 4, "x (split planes)")
+        B, h, w, C2 = x.shape
+        xv, dt, Cin = x, 2, C2 // 2
+    else:
+        xv, dt = _nhwc_view(x)
+        B, h, w, Cin = xv.shape
     Cout = bias.numel()
     lib = _lib.load()
     assert tuple(wt.shape) == (lib.hiast_aspp2_np(Cout), Cin), "wt does not match (Cin, Cout)"
+    wsrc = wt if dt == 0 else pack_conv_weight(wt, dt)       # bf16 rows / split planes: LDS-DMA kernel operand format
     ws = workspace if workspace is not None else aspp2_workspace(B, Cin, h, w, Cout, False, x.device)
     y = torch.empty((B, Cout, h, w), dtype=torch.float32, device=x.device)
-    check(lib.hiast_aspp2_fwd(_ptr(xv), dt, _ptr(wt), _ptr(bias), _ptr(y), B, Cin, h, w, Cout, _dil(dil), _ptr(ws),
+    check(lib.hiast_aspp2_fwd(_ptr(xv), dt, _ptr(wsrc), _ptr(bias), _ptr(y), B, Cin, h, w, Cout, _dil(dil), _ptr(ws),
                               ws.numel() * 4, _stream()), "hiast_aspp2_fwd")
     return y
 
 
 def aspp2_bwd(x, dy, wd, dil, want_dx=True, want_dw=True, workspace=None):
-    """x bf16 channels-last (logical [B,Cin,h,w]); dy [B,Cout,h,w] fp32 -> (dx bf16 channels-last or None,
-    [dW_i fp32 [Cout,Cin,3,3]] or None, db or None)"""
+    """x bf16 channels-last (logical [B,Cin,h,w]); dy [B,Cout,h,w] fp32; wd fp32 [Cin,NP] from aspp2_pack_weights
+    -> (dx bf16 channels-last or None, [dW_i fp32 [Cout,Cin,3,3]] or None, db or None)"""
     xv, dt = _nhwc_view(x)
     if dt != 1:
         raise TypeError("aspp2_bwd is the mixed-precision backward: x must be bfloat16")
@@ -285,14 +293,16 @@ def aspp2_bwd(x, dy, wd, dil, want_dx=True, want_dw=True, workspace=None):
     assert tuple(dy.shape) == (B, Cout, h, w)
     lib = _lib.load()
     NP = lib.hiast_aspp2_np(Cout)
+    wdp = None
     if want_dx:
         _req(wd, torch.float32, 2, "wd")
         assert tuple(wd.shape) == (Cin, NP)
+        wdp = pack_conv_weight(wd, 1)
     ws = workspace if workspace is not None else aspp2_workspace(B, Cin, h, w, Cout, True, x.device)
     dx = torch.empty((B, h, w, Cin), dtype=torch.bfloat16, device=x.device) if want_dx else None
     dws = [torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=x.device) for _ in range(4)] if want_dw else [None] * 4
     db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_dw else None
-    check(lib.hiast_aspp2_bwd(_ptr(xv), _ptr(dy), _ptr(wd) if want_dx else _ptr(None), _ptr(dx),
+    check(lib.hiast_aspp2_bwd(_ptr(xv), _ptr(dy), _ptr(wdp), _ptr(dx),
                               *[_ptr(t) for t in dws], _ptr(db), B, Cin, h, w, Cout, _dil(dil), _ptr(ws),
                               ws.numel() * 4, _stream()), "hiast_aspp2_bwd")
     return (dx.permute(0, 3, 1, 2) if want_dx else None), (dws if want_dw else None), db
@@ -481,4 +491,73 @@ def bn_act_nhwc_infer(x2d, bn, relu=True):
     g, b, mu, var, eps = _bn_params(bn)
     check(_lib.load().hiast_bn_act_nhwc_infer(_ptr(x2d), _ptr(y), g, b, mu, var, eps, int(bool(relu)), M, C, dt,
                                               _stream()), "hiast_bn_act_nhwc_infer")
+    return y
+
+
+# ------------------------------------------------------------------------------- K9c LDS-DMA implicit GEMM on split planes
+# A "split-plane" activation is an opaque bf16 tensor [B,H,W,2*C] holding hi = bf16(v) and lo = bf16(v - hi) of an
+# fp32-class value (layout inside the last axis: include/hiast_hip.h, K9c); plain bf16 activations are [B,H,W,C].
+def split_planes(x2d):
+    """fp32 [M,C] (channels-last rows) -> bf16 [M,2*C] split planes"""
+    _req(x2d, torch.float32, 2, "x2d")
+    M, C = x2d.shape
+    p = torch.empty((M, 2 * C), dtype=torch.bfloat16, device=x2d.device)
+    check(_lib.load().hiast_split_planes(_ptr(x2d), _ptr(p), M, C, 0, _stream()), "hiast_split_planes")
+    return p
+
+
+def merge_planes(p):
+    """bf16 [M,2*C] split planes -> fp32 [M,C] (hi + lo, exact)"""
+    _req(p, torch.bfloat16, 2, "planes")
+    M, C2 = p.shape
+    x = torch.empty((M, C2 // 2), dtype=torch.float32, device=p.device)
+    check(_lib.load().hiast_split_planes(_ptr(x), _ptr(p), M, C2 // 2, 1, _stream()), "hiast_split_planes")
+    return x
+
+
+def pack_conv_weight(weight, planes):
+    """fp32 conv weight [N,K,kh,kw] (torch layout) -> packed bf16 [N, kh*kw, planes*K]"""
+    w = weight.detach()
+    if w.dim() == 2:
+        w = w.reshape(w.shape[0], w.shape[1], 1, 1)
+    _req(w, torch.float32, 4, "weight")
+    N, K_, kh, kw = w.shape
+    wp = torch.empty((N, kh * kw, planes * K_), dtype=torch.bfloat16, device=w.device)
+    check(_lib.load().hiast_pack_conv_weight(_ptr(w), N, K_, kh * kw, planes, _ptr(wp), _stream()),
+          "hiast_pack_conv_weight")
+    return wp
+
+
+def igemm_bn_act(x, wp, planes, bn, res, relu, stride=1, dil=1, out_f32=False):
+    """x: bf16 [B,H,W,planes*Cin] (planes = 2 split planes | 1 plain bf16); wp from pack_conv_weight (same planes);
+    bn: BatchNorm2d in eval mode or None (plain GEMM); res: like the output or None
+    -> y bf16 [B,Ho,Wo,planes*Cout], or fp32 [B,Ho,Wo,Cout] if out_f32"""
+    _req(x, torch.bfloat16, 4, "x")
+    _req(wp, torch.bfloat16, 3, "wp")
+    PL = int(planes)
+    B, H, W, CC = x.shape
+    Cin = CC // PL
+    N, taps, KK = wp.shape
+    assert PL in (1, 2) and KK == PL * Cin and CC == PL * Cin and taps in (1, 9), (tuple(x.shape), tuple(wp.shape), PL)
+    if taps == 1:
+        assert stride == 1
+        Ho, Wo = H, W
+    else:
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    if out_f32:
+        y = torch.empty((B, Ho, Wo, N), dtype=torch.float32, device=x.device)
+        assert res is None
+    else:
+        y = torch.empty((B, Ho, Wo, PL * N), dtype=torch.bfloat16, device=x.device)
+    if res is not None:
+        _req(res, torch.bfloat16, 4, "res")
+        assert tuple(res.shape) == tuple(y.shape)
+    if bn is not None:
+        g, b, mu, var, eps = _bn_params(bn)
+    else:
+        g = b = mu = var = ctypes.c_void_p(0)
+        eps = 0.0
+    check(_lib.load().hiast_igemm_bn_act(_ptr(x), _ptr(wp), g, b, mu, var, eps, _ptr(res), int(bool(relu)), _ptr(y),
+                                         B, H, W, Cin, N, taps, int(stride), int(dil), PL, int(bool(out_f32)),
+                                         _stream()), "hiast_igemm_bn_act")
     return y

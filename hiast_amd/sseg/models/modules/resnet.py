@@ -1,8 +1,9 @@
 """ResNet-101 trunk without avgpool/fc, parameter names identical to the reference
 (sseg/models/modules/resnet.py:58-98,101-190 — torchvision naming: conv1/bn1/layer{1..4}.{i}.
 conv{1,2,3}/bn{1,2,3}/downsample.{0,1}) so released checkpoints load key-for-key.
-Round 1: convolutions/BN run on PyTorch-ROCm (MIOpen); hand-written MFMA kernels for the
-layer3/4 bottlenecks are the next row of the scope table."""
+Inference forwards (pseudo-label pass in fp32-class split planes, teacher forward in bf16) run every bottleneck
+convolution on the hand-written LDS-DMA implicit-GEMM kernels (hiast_igemm_bn_act); the training forward /
+backward convolutions run on PyTorch-ROCm (MIOpen) around the fused BatchNorm kernels (hiast_bn_*)."""
 import os
 
 import torch
@@ -33,6 +34,20 @@ def _from2d(y2d, B, H, W):
     return y2d.view(B, H, W, y2d.shape[1]).permute(0, 3, 1, 2)
 
 
+def packed_weight(conv, PL):
+    """the conv's weight in the LDS-DMA kernels' operand format (hiast_pack_conv_weight), cached on the module until
+    the parameter is modified (its version counter or storage changes)"""
+    from hiast_amd import kernels as K
+    w = conv.weight
+    cache = conv.__dict__.setdefault("_hiast_packed", {})
+    ent = cache.get(PL)
+    if ent is not None and ent[0] == w._version and ent[1] == w.data_ptr():
+        return ent[2]
+    wp = K.pack_conv_weight(w, PL)
+    cache[PL] = (w._version, w.data_ptr(), wp)
+    return wp
+
+
 class Bottleneck(nn.Module):
     expansion = 4
 
@@ -53,26 +68,21 @@ class Bottleneck(nn.Module):
         o = bn_act(self.bn2, self.conv2(o))
         return bn_act(self.bn3, self.conv3(o), res=idt)        # += identity, ReLU
 
-    def forward_eval_nhwc(self, x):
-        """fp32 inference on channels-last activations (pseudo-label forward): all three convs run as fused
-        split-bf16 (implicit) GEMM + BN + (residual) + ReLU kernels (hiast_conv1x1_/conv3x3_bn_act_nhwc)."""
+    def forward_eval_planes(self, x, PL):
+        """inference on channels-last 16-bit activations [B,H,W,PL*C] (PL = 2: split planes, fp32-class — the
+        pseudo-label forward; PL = 1: bf16 — the teacher forward under autocast): every conv runs as one LDS-DMA
+        implicit-GEMM kernel fused with BN(eval) + (residual) + ReLU (hiast_igemm_bn_act)."""
         from hiast_amd import kernels as K
-        B, _, H, W = x.shape
-        x2d = _nhwc2d(x)
-        o = K.conv1x1_bn_act_nhwc(x2d, self.conv1.weight, self.bn1, None, True)
-        o = K.conv3x3_bn_act_nhwc(o.view(B, H, W, -1), self.conv2.weight, self.bn2, self.conv2.stride[0],
-                                  self.conv2.dilation[0], True)
-        Ho, Wo = o.shape[1:3]
-        o = o.view(B * Ho * Wo, -1)
+        o = K.igemm_bn_act(x, packed_weight(self.conv1, PL), PL, self.bn1, None, True)
+        o = K.igemm_bn_act(o, packed_weight(self.conv2, PL), PL, self.bn2, None, True, self.conv2.stride[0],
+                           self.conv2.dilation[0])
         if self.downsample is None:
-            idt = x2d
+            idt = x
         else:
             dconv, dbn = self.downsample[0], self.downsample[1]
-            xs = x if dconv.stride == (1, 1) else x[:, :, ::dconv.stride[0], ::dconv.stride[1]].contiguous(
-                memory_format=torch.channels_last)
-            idt = K.conv1x1_bn_act_nhwc(_nhwc2d(xs), dconv.weight, dbn, None, False)
-        out = K.conv1x1_bn_act_nhwc(o, self.conv3.weight, self.bn3, idt, True)
-        return _from2d(out, B, Ho, Wo)
+            xs = x if dconv.stride == (1, 1) else x[:, ::dconv.stride[0], ::dconv.stride[1]].contiguous()
+            idt = K.igemm_bn_act(xs, packed_weight(dconv, PL), PL, dbn, None, False)
+        return K.igemm_bn_act(o, packed_weight(self.conv3, PL), PL, self.bn3, idt, True)
 
 
 class ResNet(nn.Module):
@@ -107,17 +117,20 @@ class ResNet(nn.Module):
         blocks += [Bottleneck(self.inplanes, planes, 1, dil[1]) for _ in range(1, n)]
         return nn.Sequential(*blocks)
 
-    def _fast_eval_ok(self, x):
-        """inference without autograd on the device: fp32 (pseudo-label forward) or, under bf16 autocast,
-        the teacher forward — both run on the channels-last fused kernels"""
+    def fast_eval_planes(self, x):
+        """-> 2 / 1 / 0: inference without autograd on the device runs on the 16-bit channels-last kernels: split
+        planes (fp32-class) for an fp32 forward — the pseudo-label pass —, plain bf16 under bf16 autocast — the
+        teacher forward of the mixed-precision step; 0 = use the module path"""
         if self.training or not x.is_cuda or torch.is_grad_enabled() or x.dtype != torch.float32:
-            return False
+            return 0
+        if os.environ.get("HIAST_NO_FAST_EVAL", "0") == "1":
+            return 0
         if not torch.is_autocast_enabled():
-            return True
-        # bf16 flavour: measured equal to the library path (14.4 vs 14.1 ms, bs 8) -> opt-in until it is faster
-        return os.environ.get("HIAST_BF16_NHWC", "0") == "1" and torch.get_autocast_dtype("cuda") == torch.bfloat16
+            return 2
+        return 1 if torch.get_autocast_dtype("cuda") == torch.bfloat16 else 0
 
-    def forward_eval_nhwc(self, x):
+    def forward_eval_planes(self, x, PL):
+        """-> trunk feature as a 16-bit channels-last tensor [B,h,w,PL*2048]"""
         from hiast_amd import kernels as K
         x = x.contiguous(memory_format=torch.channels_last)
         o = self.conv1(x)                 # library 7x7 stem (bf16 output under autocast)
@@ -125,14 +138,31 @@ class ResNet(nn.Module):
         B, _, H, W = o.shape
         o = _from2d(K.bn_act_nhwc_infer(_nhwc2d(o), self.bn1, True), B, H, W)
         o = self.maxpool(o)
+        B, C, H, W = o.shape
+        o2d = _nhwc2d(o.contiguous(memory_format=torch.channels_last))
+        if PL == 2:
+            o = K.split_planes(o2d.float()).view(B, H, W, 2 * C)
+        else:
+            o = o2d.to(torch.bfloat16).view(B, H, W, C)
         for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
             for blk in stage:
-                o = blk.forward_eval_nhwc(o)
-        return o      # logical NCHW, channels-last memory: the ASPP head (hiast_aspp2_fwd) reads it as is
+                o = blk.forward_eval_planes(o, PL)
+        return o
+
+    @staticmethod
+    def planes_to_feature(p, PL):
+        """16-bit channels-last trunk output -> logical [B,C,h,w] tensor (channels-last memory)"""
+        from hiast_amd import kernels as K
+        B, h, w, CC = p.shape
+        if PL == 2:
+            return _from2d(K.merge_planes(p.view(B * h * w, CC)), B, h, w)
+        return p.permute(0, 3, 1, 2)
 
     def forward(self, x, is_return_low=False):
-        if not is_return_low and self._fast_eval_ok(x):
-            return self.forward_eval_nhwc(x)
+        if not is_return_low:
+            PL = self.fast_eval_planes(x)
+            if PL:
+                return self.planes_to_feature(self.forward_eval_planes(x, PL), PL)
         x = self.maxpool(bn_act(self.bn1, self.conv1(x)))
         low = self.layer1(x)
         x = self.layer4(self.layer3(self.layer2(low)))

@@ -25,16 +25,32 @@ class ASPP_V2(nn.Module):
         for m in self.conv2d_list:
             m.weight.data.normal_(0, 0.01)      # deeplab_v2.py:17-18
 
+    def _wb(self):
+        return [m.weight for m in self.conv2d_list], [m.bias for m in self.conv2d_list]
+
+    def planes_ok(self):
+        return self.conv2d_list[0].weight.shape[0] <= 32 and self.conv2d_list[0].weight.shape[1] % 128 == 0
+
+    def forward_planes(self, p, PL):
+        """inference on the trunk's 16-bit channels-last output [B,h,w,PL*2048] (no autograd)"""
+        from hiast_amd import kernels as K
+        ws, bs = self._wb()
+        wt, _, bias = K.aspp2_pack_weights([w.detach().float().contiguous() for w in ws],
+                                           [b.detach().float().contiguous() for b in bs], need_dgrad=False)
+        if PL == 2:
+            return K.aspp2_fwd(p, wt, bias, self.dilations, planes=2)
+        return K.aspp2_fwd(p.permute(0, 3, 1, 2), wt, bias, self.dilations)
+
     def forward(self, x):
         if x.is_cuda:
-            ws, bs = [m.weight for m in self.conv2d_list], [m.bias for m in self.conv2d_list]
-            gemm_ok = x.shape[1] % 128 == 0 and ws[0].shape[0] <= 32
+            ws, bs = self._wb()
+            gemm_ok = self.planes_ok()
             if gemm_ok and x.dtype == torch.bfloat16:
                 # mixed-precision step (teacher / student under autocast): channels-last GEMM + shift-add, bf16 MFMA
                 return HF.aspp_nhwc(x.contiguous(memory_format=torch.channels_last), ws, bs, self.dilations)
             if (gemm_ok and x.dtype == torch.float32 and not torch.is_grad_enabled()
                     and x.permute(0, 2, 3, 1).is_contiguous()):
-                # fp32 inference on the channels-last trunk output (pseudo-label forward): split-bf16 GEMM
+                # fp32 inference on a channels-last feature: split-bf16 GEMM
                 return HF.aspp_nhwc(x, ws, bs, self.dilations)
             return HF.aspp(x, ws, bs, self.dilations)   # exact-fp32 direct form (fp32 training, NCHW inference)
         out = self.conv2d_list[0](x)
@@ -57,7 +73,14 @@ class DeepLab_V2(nn.Module):
         for p in self.representation.parameters():
             p.requires_grad = False
 
-    def forward(self, x):
+    def forward(self, x, need_feat=True):
+        """-> (prediction [B,C,H/8,W/8], feature [B,2048,H/8,W/8]); need_feat=False (internal fast path of this
+        package's generator / trainers, which drop the feature) skips materialising the feature tensor"""
+        PL = self.backbone.fast_eval_planes(x) if x.shape[1] == 3 else 0
+        if PL and self.aspp.planes_ok():
+            p = self.backbone.forward_eval_planes(x, PL)
+            pred = self.aspp.forward_planes(p, PL)
+            return pred, (self.backbone.planes_to_feature(p, PL) if need_feat else None)
         feat = self.backbone(x)            # [B, 2048, H/8, W/8]
         return self.aspp(feat), feat       # [B, C, H/8, W/8]
 

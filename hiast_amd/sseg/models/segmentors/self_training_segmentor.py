@@ -32,7 +32,7 @@ class SelfTrainingSegmentor(nn.Module):
             self.cst_loss_fun = LOSS[cfg.cst_training.cst_loss.type]
 
     def forward(self, t_img, lowres=False):
-        t_logits, backbone = self.seg_model(t_img)
+        t_logits, backbone = self.seg_model(t_img, need_feat=not lowres)
         if lowres:
             return {"logits_lowres": t_logits, "backbone": backbone, "size": tuple(t_img.shape[2:])}
         return {"logits": upsample_logits(t_logits, t_img.shape[2:]), "backbone": backbone}

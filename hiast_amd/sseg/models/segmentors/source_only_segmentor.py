@@ -17,7 +17,7 @@ class SourceOnlySegmentor(nn.Module):
         self.seg_loss_fun = LOSS[cfg.model.predictor.seg_loss.type]
 
     def forward(self, img, lbl=None, lowres=False):
-        logits, feat = self.seg_model(img)
+        logits, feat = self.seg_model(img, need_feat=not lowres)
         if lowres:
             return {"logits_lowres": logits, "backbone": feat, "size": tuple(img.shape[2:])}
         logits = upsample_logits(logits, img.shape[2:])

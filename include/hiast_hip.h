@@ -136,10 +136,12 @@ int hiast_aspp_bwd_weight(const float* x, const float* dy, float* dw0, float* dw
  * (deeplab_v2.py:20-24 + autograd, as K1).  T[p][tap*Cout+co] = Σ_ci x[p][ci]*W[tap][co][ci] is a plain
  * [B*h*w x Cin] x [Cin x NP] GEMM on the bf16 matrix cores (NP = hiast_aspp2_np(Cout) = 33*Cout rounded up to
  * 128), y[co][q] = bias[co] + Σ_tap T[q+off(tap)][tap*Cout+co]: the feature map is read once instead of 33x.
- * x_nhwc [B,h,w,Cin]; dtype 0 = fp32 (split-bf16 arithmetic, fp32-class: the pseudo-label forward),
- * 1 = bf16 (training step under mixed precision; the reference trains under apex O1). y [B,Cout,h,w] fp32 (NCHW,
- * what the loss / pseudo-label kernels read).  Cin % 128 == 0, Cout <= 32.
- * pack: wt [NP][Cin] fp32 (forward / wgrad layout), wd [Cin][NP] fp32 (dgrad layout; may be NULL), bias [Cout].
+ * x_nhwc [B,h,w,Cin]; dtype 0 = fp32 rows (split-bf16 arithmetic on the fly), 2 = split planes (K9c format; both
+ * fp32-class: the pseudo-label forward), 1 = bf16 (training step under mixed precision; the reference trains under
+ * apex O1).  y [B,Cout,h,w] fp32 (NCHW, what the loss / pseudo-label kernels read).  Cin % 128 == 0, Cout <= 32.
+ * pack: wt [NP][Cin] fp32, wd [Cin][NP] fp32 (its transpose; may be NULL), bias [Cout].  fwd takes wt itself for
+ * dtype 0 and hiast_pack_conv_weight(wt, NP, Cin, 1, planes = dtype) for dtype 1 | 2; bwd takes
+ * hiast_pack_conv_weight(wd, Cin, NP, 1, 1).
  * bwd (bf16 x only): dy [B,Cout,h,w] fp32 -> dx_nhwc [B,h,w,Cin] bf16 (NULL = skip), dW_i [Cout,Cin,3,3] fp32 and
  * db [Cout] (all NULL = skip); fp32 accumulation, pixel-range split with a fixed-order reduce (bitwise
  * reproducible, no float atomics).  workspace: hiast_aspp2_workspace_bytes(..., backward) bytes. */
@@ -148,10 +150,10 @@ size_t hiast_aspp2_workspace_bytes(int B, int Cin, int h, int w, int Cout, int b
 int hiast_aspp2_pack_weights(const float* w0, const float* w1, const float* w2, const float* w3,
                              const float* b0, const float* b1, const float* b2, const float* b3, int Cin,
                              int Cout, float* wt, float* wd, float* bias, hiast_stream_t stream);
-int hiast_aspp2_fwd(const void* x_nhwc, int dtype, const float* wt, const float* bias, float* y, int B, int Cin,
+int hiast_aspp2_fwd(const void* x_nhwc, int dtype, const void* wt, const float* bias, float* y, int B, int Cin,
                     int h, int w, int Cout, const int* dil, void* workspace, size_t workspace_bytes,
                     hiast_stream_t stream);
-int hiast_aspp2_bwd(const void* x_nhwc, const float* dy, const float* wd, void* dx_nhwc, float* dw0, float* dw1,
+int hiast_aspp2_bwd(const void* x_nhwc, const float* dy, const void* wd, void* dx_nhwc, float* dw0, float* dw1,
                     float* dw2, float* dw3, float* db, int B, int Cin, int h, int w, int Cout, const int* dil,
                     void* workspace, size_t workspace_bytes, hiast_stream_t stream);
 
@@ -209,6 +211,21 @@ int hiast_conv3x3_bn_act_nhwc(const void* x, const float* w, const float* gamma,
 int hiast_bn_act_nhwc_infer(const void* x, void* y, const float* gamma, const float* beta, const float* mean,
                             const float* var, float eps, int relu, int64_t M, int C, int dtype,
                             hiast_stream_t stream);
+
+/* ---- K9c: the same fused trunk convolutions with operands pre-split into bf16 planes and staged by LDS-DMA ------
+ * (resnet.py:78-98 as K9).  An fp32-class activation row of C values is stored as [hi_0..hi_{C-1} | lo_0..lo_{C-1}]
+ * bf16 (hi = bf16(v), lo = bf16(v - hi); 4 bytes per value like fp32): x [B,H,W,planes,Cin], y [B,Ho,Wo,planes,Cout],
+ * res like y.  planes = 2: hi*hi + lo*hi + hi*lo on the bf16 matrix cores (fp32-class, the pseudo-label forward);
+ * planes = 1: plain bf16.  The split is done once by the producer's epilogue instead of by every consumer block.
+ * wp: [Cout][taps][planes][Cin] bf16 from hiast_pack_conv_weight (w: torch layout [Cout][Cin][taps], taps = 1 | 9).
+ * taps = 9: padding = dilation, stride 1 | 2.  out_f32 = 1: y is fp32 [B,Ho,Wo,Cout] (no residual).  mean == NULL: no
+ * BatchNorm (plain GEMM).  Cin % 32 == 0, Cout % 64 == 0, every tensor < 2 GiB, 16-byte aligned.
+ * hiast_split_planes: fp32 [M][C] <-> planes [M][2][C] (inverse = 1: x is written; hi + lo is exact in fp32). */
+int hiast_igemm_bn_act(const void* x, const void* wp, const float* gamma, const float* beta, const float* mean,
+                       const float* var, float eps, const void* res, int relu, void* y, int B, int H, int W, int Cin,
+                       int Cout, int taps, int stride, int dil, int planes, int out_f32, hiast_stream_t stream);
+int hiast_pack_conv_weight(const float* w, int N, int K, int taps, int planes, void* wp, hiast_stream_t stream);
+int hiast_split_planes(float* x, void* planes, int64_t M, int C, int inverse, hiast_stream_t stream);
 
 /* ---- K11: EMA teacher update ---------------------------------------------------------
  * utils/utils.py:115-123 update_ema_model: ema = ema*gamma + p*(1-gamma) over a list of

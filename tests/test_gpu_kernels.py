@@ -284,6 +284,19 @@ def test_aspp2_fwd_fp32_split(K, shape, dil):
 
 
 @pytest.mark.parametrize("shape", ASPP2_SHAPES)
+def test_aspp2_fwd_split_planes(K, shape):
+    """the same head fed with the trunk's split-plane output (LDS-DMA GEMM kernel)"""
+    B, Cin, h, w, C = shape
+    dil = (6, 12, 18, 24)
+    x, ws, bs = _aspp_inputs(145, B, Cin, h, w, C)
+    wt, _, bias = K.aspp2_pack_weights([dev(t) for t in ws], [dev(t) for t in bs], need_dgrad=False)
+    xp = K.split_planes(dev(x).permute(0, 2, 3, 1).reshape(-1, Cin).contiguous()).view(B, h, w, 2 * Cin)
+    y = K.aspp2_fwd(xp, wt, bias, dil, planes=2).cpu().numpy()
+    want = cref.aspp_fwd(x, ws, bs, dil)
+    assert np.abs(y - want).max() <= 3e-5 * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize("shape", ASPP2_SHAPES)
 def test_aspp2_fwd_bf16(K, shape):
     """bf16 operands, fp32 accumulation: exact reference = the oracle on the bf16-rounded operands"""
     B, Cin, h, w, C = shape
@@ -350,6 +363,121 @@ def test_aspp_nhwc_autograd_matches_direct_form(K):
         assert (a - b).abs().max() <= 2e-2 * a.abs().max()
     for a, b in zip(gb0, gb1):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-5)
+
+
+def _planes_ref(a):
+    """numpy fp32 -> (hi, lo) as fp32 arrays, the split the kernels use"""
+    hi = _bf16r(a)
+    lo = _bf16r(a - hi)
+    return hi, lo
+
+
+def test_split_planes_roundtrip(K):
+    x = synth.normal_f32(300, (1000, 64), 3.0)
+    x[0, :8] = [0.0, -0.0, 1.0, -1.0, 1e-30, 65504.0, 3.0e38, -2.5e-20]
+    p = K.split_planes(dev(x))
+    hi, lo = _planes_ref(x)
+    assert tuple(p.shape) == (1000, 128) and p.dtype == torch.bfloat16
+    got = np.sort(p.float().cpu().numpy(), axis=1)
+    assert np.array_equal(got, np.sort(np.concatenate([hi, lo], 1), axis=1))      # same values, layout opaque
+    back = K.merge_planes(p).cpu().numpy()
+    assert np.array_equal(back, hi + lo)
+    assert (np.abs(back - x) <= 2.0 ** -16 * np.abs(x)).all()
+
+
+IGEMM_CASES = [  # B, H, W, Cin, Cout, taps, stride, dil, res
+    (2, 9, 17, 64, 64, 1, 1, 1, False),
+    (1, 16, 32, 256, 128, 1, 1, 1, True),
+    (1, 8, 16, 1024, 256, 1, 1, 1, False),
+    (2, 12, 20, 64, 64, 9, 1, 2, False),
+    (1, 17, 23, 128, 256, 9, 2, 1, False),
+    (1, 10, 40, 96, 128, 9, 1, 4, False),
+    (3, 16, 16, 32, 192, 9, 1, 1, False),
+]
+
+
+def _igemm_ref(xf, wf, bn, resf, relu, stride, dil, taps):
+    """float64 torch-CPU reference on the operand values the kernel multiplies"""
+    xt = torch.from_numpy(xf).double().permute(0, 3, 1, 2)
+    wt = torch.from_numpy(wf).double()
+    y = torch.nn.functional.conv2d(xt, wt, None, stride if taps == 9 else 1, dil if taps == 9 else 0, dil if taps == 9 else 1)
+    if bn is not None:
+        g, b, mu, var, eps = bn
+        sc = g / np.sqrt(var + eps)
+        y = y * torch.from_numpy(sc).view(1, -1, 1, 1) + torch.from_numpy(b - mu * sc).view(1, -1, 1, 1)
+    y = y.permute(0, 2, 3, 1)
+    if resf is not None:
+        y = y + torch.from_numpy(resf).double()
+    if relu:
+        y = y.clamp_min(0)
+    return y.numpy()
+
+
+def _mk_bn(seed, C):
+    bn = torch.nn.BatchNorm2d(C).cuda().eval()
+    with torch.no_grad():
+        bn.weight.copy_(dev(1.0 + 0.2 * synth.normal_f32(seed, (C,))))
+        bn.bias.copy_(dev(0.1 * synth.normal_f32(seed + 1, (C,))))
+        bn.running_mean.copy_(dev(0.1 * synth.normal_f32(seed + 2, (C,))))
+        bn.running_var.copy_(dev(np.abs(synth.normal_f32(seed + 3, (C,))) + 0.5))
+    ref = tuple(t.detach().double().cpu().numpy() for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)) + (bn.eps,)
+    return bn, ref
+
+
+@pytest.mark.parametrize("case", IGEMM_CASES)
+def test_igemm_split_planes(K, case):
+    """fused conv + BN(eval) (+res) + ReLU on split planes (LDS-DMA staged, hi*hi + lo*hi + hi*lo): fp32-class"""
+    B, H, W, Cin, Cout, taps, stride, dil, has_res = case
+    kk = 3 if taps == 9 else 1
+    x = synth.normal_f32(310, (B, H, W, Cin))
+    w = synth.normal_f32(311, (Cout, Cin, kk, kk), (2.0 / (Cin * taps)) ** 0.5)
+    bn, bnref = _mk_bn(312, Cout)
+    xp = K.split_planes(dev(x).view(-1, Cin)).view(B, H, W, 2 * Cin)
+    wp = K.pack_conv_weight(dev(w), 2)
+    Ho, Wo = (H, W) if taps == 1 else ((H - 1) // stride + 1, (W - 1) // stride + 1)
+    res = resp = None
+    if has_res:
+        res = synth.normal_f32(313, (B, Ho, Wo, Cout))
+        resp = K.split_planes(dev(res).view(-1, Cout)).view(B, Ho, Wo, 2 * Cout)
+    for relu in (True, False):
+        y = K.igemm_bn_act(xp, wp, 2, bn, resp, relu, stride, dil)
+        assert tuple(y.shape) == (B, Ho, Wo, 2 * Cout)
+        got = K.merge_planes(y.view(-1, 2 * Cout)).view(B, Ho, Wo, Cout).cpu().numpy()
+        xh, xl = _planes_ref(x)
+        wh, wl = _planes_ref(w)
+        rr = None if res is None else sum(_planes_ref(res))
+        want = _igemm_ref(xh + xl, wh + wl, bnref, rr, relu, stride, dil, taps)
+        tol = 3e-5 * max(1.0, np.abs(want).max())
+        assert np.abs(got - want).max() <= tol, (np.abs(got - want).max(), tol)
+        # the stored planes are a split of the fp32 value they merge to (same value after a re-split)
+        v = K.merge_planes(y.view(-1, 2 * Cout))
+        assert torch.equal(K.merge_planes(K.split_planes(v)), v)
+    # fp32 output, no BN (the ASPP tap GEMM flavour)
+    if not has_res:
+        yf = K.igemm_bn_act(xp, wp, 2, None, None, False, stride, dil, out_f32=True).cpu().numpy()
+        want = _igemm_ref(sum(_planes_ref(x)), sum(_planes_ref(w)), None, None, False, stride, dil, taps)
+        assert np.abs(yf - want).max() <= 3e-5 * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize("case", IGEMM_CASES[1:5])
+def test_igemm_bf16(K, case):
+    """the same kernel on plain bf16 operands (one plane): exact reference = fp64 on the bf16-rounded operands,
+    output rounded to bf16"""
+    B, H, W, Cin, Cout, taps, stride, dil, has_res = case
+    kk = 3 if taps == 9 else 1
+    x = _bf16r(synth.normal_f32(320, (B, H, W, Cin)))
+    w = synth.normal_f32(321, (Cout, Cin, kk, kk), (2.0 / (Cin * taps)) ** 0.5)
+    bn, bnref = _mk_bn(322, Cout)
+    xp = dev(x).bfloat16()
+    wp = K.pack_conv_weight(dev(w), 1)
+    Ho, Wo = (H, W) if taps == 1 else ((H - 1) // stride + 1, (W - 1) // stride + 1)
+    res = resp = None
+    if has_res:
+        res = _bf16r(synth.normal_f32(323, (B, Ho, Wo, Cout)))
+        resp = dev(res).bfloat16()
+    y = K.igemm_bn_act(xp, wp, 1, bn, resp, True, stride, dil).float().cpu().numpy()
+    want = _igemm_ref(x, _bf16r(w), bnref, res, True, stride, dil, taps)
+    assert (np.abs(y - want) <= 2.0 ** -8 * np.abs(want) + 3e-5 * np.abs(want).max()).all()
 
 
 def test_ema_bit_exact(K):
@@ -585,13 +713,18 @@ def test_teacher_bf16_fast_path_close_to_library_path(K):
     m = m.cuda().eval()
     x = torch.from_numpy(synth.normal_f32(903, (2, 3, 129, 257))).cuda()
     import os
-    os.environ["HIAST_BF16_NHWC"] = "1"
-    try:
-        with torch.no_grad():
-            ref, _ = m(x)                                    # fp32 fast path
-            with torch.autocast("cuda", dtype=torch.bfloat16):
-                fast, _ = m(x)                               # bf16 fast path
-    finally:
-        os.environ.pop("HIAST_BF16_NHWC", None)
+    with torch.no_grad():
+        ref, feat = m(x)                                 # fp32-class fast path (split planes)
+        assert feat.shape[1] == 2048 and feat.dtype == torch.float32
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            fast, featb = m(x)                           # bf16 fast path
+            assert featb.dtype == torch.bfloat16 and featb.shape == feat.shape
+        os.environ["HIAST_NO_FAST_EVAL"] = "1"
+        try:
+            slow, feat_slow = m(x)                       # module path: library convs + fused BN kernels, fp32
+        finally:
+            os.environ.pop("HIAST_NO_FAST_EVAL", None)
+    assert (ref - slow).abs().max() <= 1e-3 * slow.abs().max()           # the logits contract
+    assert (feat - feat_slow).abs().max() <= 1e-3 * feat_slow.abs().max()
     rel = (fast.float() - ref).abs().max() / ref.abs().max()
     assert rel < 5e-2, float(rel)                        # bf16 through ~100 layers

@@ -69,6 +69,41 @@ def main():
             print("%-20s B=%d  median %8.3f ms  best %8.3f ms  %7.2f TFLOP/s (algorithmic)" %
                   (name, B, med, best, gf / med * (2 if "both" in name else 1) if "pack" not in name else 0), flush=True)
         del x32, x16, dy
+    if "igemm" in which:
+        Bn, Hh, Ww = B, 64, 128
+        cases = [("l3.conv2 3x3 d2", 256, 256, 9, 2, False), ("l3.conv1 1x1", 1024, 256, 1, 1, False),
+                 ("l3.conv3 1x1+res", 256, 1024, 1, 1, True), ("l4.conv2 3x3 d4", 512, 512, 9, 4, False),
+                 ("l4.conv1 1x1", 2048, 512, 1, 1, False), ("l4.conv3 1x1+res", 512, 2048, 1, 1, True),
+                 ("l2.conv2 3x3", 128, 128, 9, 1, False), ("l2.conv3 1x1+res", 128, 512, 1, 1, True)]
+        for name, Cin_, Cout_, taps, dl, has_res in cases:
+            kk = 3 if taps == 9 else 1
+            wt_ = torch.randn(Cout_, Cin_, kk, kk, device=dev) * (2.0 / (Cin_ * taps)) ** 0.5
+            bn = torch.nn.BatchNorm2d(Cout_).to(dev).eval()
+            x32 = torch.randn(Bn, Hh, Ww, Cin_, device=dev)
+            gf = 2.0 * Bn * Hh * Ww * Cin_ * Cout_ * taps / 1e9
+            row = "%-18s %6.1f GFLOP |" % (name, gf)
+            for PL in (2, 1):
+                xp = (K.split_planes(x32.view(-1, Cin_)).view(Bn, Hh, Ww, 2 * Cin_) if PL == 2 else x32.bfloat16())
+                wp = K.pack_conv_weight(wt_, PL)
+                res = torch.randn(Bn, Hh, Ww, PL * Cout_, device=dev).bfloat16() if has_res else None
+                med, best = timeit(lambda: K.igemm_bn_act(xp, wp, PL, bn, res, True, 1, dl), n=20, warm=5)
+                row += " PL%d %7.3f ms %6.0f TF/s(alg) |" % (PL, med, gf / med)
+            # the earlier register-staged kernels on fp32 / bf16 channels-last activations
+            for dt in (torch.float32, torch.bfloat16):
+                xx = x32.to(dt)
+                if taps == 1:
+                    r2 = torch.randn(Bn * Hh * Ww, Cout_, device=dev).to(dt) if has_res else None
+                    fn = lambda: K.conv1x1_bn_act_nhwc(xx.view(-1, Cin_), wt_, bn, r2, True)
+                else:
+                    fn = lambda: K.conv3x3_bn_act_nhwc(xx, wt_, bn, 1, dl, True)
+                med, best = timeit(fn, n=20, warm=5)
+                row += " old %s %7.3f ms |" % ("f32" if dt == torch.float32 else "bf16", med)
+            # library: torch conv2d bf16 (MIOpen), NCHW
+            xn = x32.permute(0, 3, 1, 2).contiguous().bfloat16()
+            wb = wt_.bfloat16()
+            med, best = timeit(lambda: torch.nn.functional.conv2d(xn, wb, None, 1, dl if taps == 9 else 0, dl), n=20, warm=5)
+            row += " miopen bf16 conv only %7.3f ms" % med
+            print(row, flush=True)
     if "plabel" in which:
         z = torch.randn(B, C, h, w, device=dev) * 3
         med, best = timeit(lambda: K.plabel_pass1(z, H, W))
