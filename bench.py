@@ -96,15 +96,15 @@ class KernelTimer:
 
     def install(self):
         from hiast_amd import kernels as K
-        ws = {}
 
         def aspp_key(x, wpack, Cout, dil, workspace=None):
             return ("aspp_fwd", tuple(x.shape), Cout)
 
-        def c3_key(x_nhwc, weight, bn, stride, dil, relu=True):
-            return ("conv3x3", tuple(x_nhwc.shape), weight.shape[0], stride, dil, str(x_nhwc.dtype))
+        def ig_key(x, wp, planes, bn, res, relu, stride=1, dil=1, out_f32=False):
+            return ("igemm", tuple(x.shape), tuple(wp.shape), int(planes), int(stride), int(dil), res is not None,
+                    bool(out_f32))
         self.wrap(K, "aspp_fwd", aspp_key)
-        self.wrap(K, "conv3x3_bn_act_nhwc", c3_key)
+        self.wrap(K, "igemm_bn_act", ig_key)
 
     def summary(self):
         out = []
@@ -133,22 +133,35 @@ def roofline_of(key, avg_ms, n, steps):
                           "algorithmic %.0f MB" % (pj["source"], pj["hbm_bytes_uncorrected"] / 1e6,
                                                    pj["algorithmic_bytes"] / 1e6))
         return d
-    B, Hh, Ww, Cin = key[1]
-    Cout, stride = key[2], key[3]
-    M = B * ((Hh - 1) // stride + 1) * ((Ww - 1) // stride + 1)
-    flop = 2.0 * M * 9 * Cin * Cout
+    # ("igemm", x [B,H,W,PL*Cin], wp [Cout,taps,PL*Cin], PL, stride, dil, has_res, out_f32)
+    B, Hh, Ww, CC = key[1]
+    Cout, taps, _ = key[2]
+    PL, stride, dil, has_res, out_f32 = key[3:8]
+    Cin = CC // PL
+    Ho, Wo = (Hh, Ww) if taps == 1 else ((Hh - 1) // stride + 1, (Ww - 1) // stride + 1)
+    M = B * Ho * Wo
+    flop = 2.0 * M * taps * Cin * Cout
     ach = flop / (avg_ms * 1e-3) / 1e12
-    peak = 2500.0 / 3.0
+    peak = 2500.0 / 3.0 if PL == 2 else 2500.0
+    alg_bytes = (B * Hh * Ww * CC + Cout * taps * CC) * 2 + M * Cout * (4 if out_f32 else 2 * PL) * (2 if has_res else 1)
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv3x3.json")
-    if os.path.exists(pmc) and (B, Hh, Ww, Cin, Cout) == (8, 64, 128, 256, 256):
-        traffic = json.load(open(pmc))["hbm_bytes_x2_fetch"]     # (2*FETCH_SIZE + WRITE_SIZE)*1024, see the file
-    return {"kernel": "hiast::conv1x1_bn_act_kernel<float,128,9,false,true> (3x3 split-bf16 implicit GEMM + BN + ReLU)",
-            "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
-            "avg_launch_ms": avg_ms, "launches_per_step": n / steps,
-            "note": "algorithmic (fp32-equivalent) %.1f GFLOP per launch: B=%d %dx%d Cin=%d Cout=%d dil=%d; the kernel "
-                    "issues 3 bf16 MFMA flops per algorithmic flop (hi*hi + hi*lo + lo*hi), so its ceiling is the dense "
-                    "bf16 MFMA peak 2500/3 TFLOP/s" % (flop / 1e9, B, Hh, Ww, Cin, Cout, key[4])}
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_igemm.json")
+    if os.path.exists(pmc):
+        for ent in json.load(open(pmc)).get("kernels", []):
+            if ent.get("key") == [B, Hh, Ww, Cin, Cout, taps, PL, dil]:
+                traffic = ent["hbm_bytes_per_launch"]
+    name = "hiast::igemm_bn_act_kernel<PL=%d,%s,taps=%d> (%s LDS-DMA implicit GEMM + BN%s + ReLU)" % (
+        PL, "f32out" if out_f32 else "16-bit out", taps, "split-bf16" if PL == 2 else "bf16", " + residual" if has_res else "")
+    return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+            "traffic": traffic, "avg_launch_ms": avg_ms, "launches_per_step": n / steps,
+            "note": "algorithmic %.1f GFLOP per launch (B=%d %dx%d Cin=%d Cout=%d taps=%d dil=%d); %s; algorithmic "
+                    "HBM bytes per launch %.0f MB -> %.2f TB/s (HBM time at 8 TB/s = %.0f%% of the launch: the MFMA "
+                    "bound is the binding one unless that nears 100%%)"
+                    % (flop / 1e9, B, Hh, Ww, Cin, Cout, taps, dil,
+                       "fp32-equivalent flops: the kernel issues 3 bf16 MFMA flops per algorithmic flop (hi*hi + lo*hi + "
+                       "hi*lo), ceiling = dense bf16 MFMA peak 2500/3 TFLOP/s" if PL == 2 else
+                       "plain bf16 MFMA, ceiling 2500 TFLOP/s dense",
+                       alg_bytes / 1e6, alg_bytes / (avg_ms * 1e-3) / 1e12, 100.0 * alg_bytes / 8e12 / (avg_ms * 1e-3))}
 
 
 class HotPath:
@@ -340,8 +353,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "dtype_detail": "bf16 MFMA with fp32 accumulate everywhere: plain bf16 in the training step (the reference "
-                            "trains under apex O1), split-bf16 (hi*hi+hi*lo+lo*hi, fp32-class) in the pseudo-label "
-                            "forward; ASPP head exact fp32 MFMA; losses / softmax / thresholds fp32 + integer",
+                            "trains under apex O1), split-bf16 planes (hi*hi+lo*hi+hi*lo, fp32-class) in the "
+                            "pseudo-label forward incl. its ASPP head; losses / softmax / thresholds fp32 + integer",
             "data": "synthetic",
             "config": {"workload": "configs[2] self-training round (%s, region-adaptive reg on) bs=%d/GPU @1024x512 "
                                    "+ configs[1] IAS pseudo-label pass on the same batch" % (args.trainer, args.batch),

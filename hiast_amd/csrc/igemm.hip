@@ -76,7 +76,7 @@ template <int PL, bool OUTF32, int BN, int TAPS, bool RES, bool RELU>
 __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
     const unsigned short* __restrict__ X, const unsigned short* __restrict__ Wp, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ var, float eps,
-    const unsigned short* __restrict__ R, void* __restrict__ Yv, int M, int K, int N, IGeo geo)
+    const unsigned short* __restrict__ R, void* __restrict__ Yv, int M, int K, int N, IGeo geo, int dbg)
 {
     constexpr int WN = BN / 64, WM = 8 / WN;
     constexpr int TM = IG_BM / WM / 32;                 // 32-row tiles per wave (4 | 2 | 1)
@@ -174,6 +174,7 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
 
 #pragma unroll
     for (int p = 0; p < NPIECE; ++p) piece(0, 0, p);
+    if ((dbg & 8) && wave >= 4) __builtin_amdgcn_s_setprio(1);
     const int frow = lane & 31, fh = lane >> 5;
     constexpr int NSLOT = KK * TM;                      // MFMA groups per k-step; the DMA pieces of the NEXT k-step
                                                         // are issued between them, not in one burst after the barrier
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
         const int buf = kt & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's share of tile kt has landed
         __syncthreads();                                          // everyone's has; everyone left buffer buf^1
-        const bool more = kt + 1 < nk;
+        const bool more = kt + 1 < nk && !(dbg & 2);     // dbg: tuning experiments only (HIAST_IGEMM_DEBUG)
         const unsigned char* ta = smem + buf * BUF_BYTES;
         const unsigned char* tb = ta + A_BYTES;
 #pragma unroll
@@ -209,6 +210,8 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
                     for (int p = 0; p < NPIECE; ++p)
                         if (p >= slot * NPIECE / NSLOT && p < (slot + 1) * NPIECE / NSLOT) piece(kt + 1, buf ^ 1, p);
                 }
+                if (dbg & 1) continue;
+                if (dbg & 4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int b = 0; b < TN; ++b) {
                     if (PL == 2) {
@@ -217,6 +220,7 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
                     }
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
                 }
+                if (dbg & 4) __builtin_amdgcn_s_setprio(0);
             }
         }
     }
@@ -385,6 +389,8 @@ static int launch_igemm_t(const void* x, const void* wp, const float* gamma, con
                           const float* var, float eps, const void* res, int relu, void* y, int64_t M, int K, int N,
                           int taps, hiast::IGeo geo, hipStream_t st)
 {
+    int dbg = 0;
+    if (const char* env = getenv("HIAST_IGEMM_DEBUG")) dbg = atoi(env);
     int BN = (N % 256 == 0) ? 256 : ((N % 128 == 0) ? 128 : 64);
     if (const char* env = getenv("HIAST_IGEMM_BN")) {          // tuning override
         const int v = atoi(env);
@@ -394,7 +400,7 @@ static int launch_igemm_t(const void* x, const void* wp, const float* gamma, con
 #define L(BNV, T, RES, RELU)                                                                                         \
     hipLaunchKernelGGL((hiast::igemm_bn_act_kernel<PL, OUTF32, BNV, T, RES, RELU>), grid, dim3(512), 0, st,           \
                        (const unsigned short*)x, (const unsigned short*)wp, gamma, beta, mean, var, eps,              \
-                       (const unsigned short*)res, y, (int)M, K, N, geo)
+                       (const unsigned short*)res, y, (int)M, K, N, geo, dbg)
 #define LL(BNV, T)                                                              \
     if (res) { if (relu) L(BNV, T, true, true); else L(BNV, T, true, false); }  \
     else { if (relu) L(BNV, T, false, true); else L(BNV, T, false, false); }
