@@ -1,0 +1,337 @@
+// K10b — BatchNorm2d (+ residual add) (+ ReLU), training mode, on CHANNELS-LAST bf16 activations [M = B*H*W][C]
+// (reference: Bottleneck.forward, sseg/models/modules/resnet.py:78-98; "frozen" BN still normalises with BATCH
+// statistics in train() mode, utils/utils.py:60-65).  Same arithmetic and the same four passes as the NCHW kernels
+// of bn_act.hip; this layout is the one the hand-written convolution kernels (igemm.hip) produce and consume, so
+// the student forward / backward needs no layout transposes.  gfx950, HBM-bound: every pass moves whole 16-byte
+// channel groups, a thread keeps ONE group of 8 channels for all its rows (its scale / shift / statistics live in
+// registers), rows are dealt block-cyclically.
+//
+//   stats      : Σx, Σx² per channel                   -> sums[C][2] (double)           (1 read)
+//   apply      : y = relu(x*scale_c + shift_c (+ res))                                   (1 read (+1), 1 write)
+//   bwd_stats  : g = dy * (y > 0);  Σg, Σ g*xhat       -> sums[C][2]
+//   bwd_apply  : dx = gamma*invstd*(g - Σg/n - xhat*Σ(g*xhat)/n);  dres = g
+// Partial sums: fp32 per thread (<= a few hundred rows), then double, reduced in a fixed order (no atomics: bitwise
+// reproducible).  Between stats and apply the caller may all-reduce sums[C][2] across ranks (SyncBN).
+#include <hip/hip_bf16.h>
+
+#include "common.h"
+
+namespace hiast {
+
+constexpr int BNH_MAXBLK = 512;
+
+__device__ __forceinline__ void bnh_load8(const unsigned short* p, float (&v)[8])
+{
+    const uint4 r = *reinterpret_cast<const uint4*>(p);
+    const unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = __uint_as_float(w[i] << 16);
+        v[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
+    }
+}
+
+__device__ __forceinline__ void bnh_store8(unsigned short* p, const float (&v)[8])
+{
+    unsigned w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        w[i] = (unsigned)__bfloat16_as_ushort(__float2bfloat16(v[2 * i])) |
+               ((unsigned)__bfloat16_as_ushort(__float2bfloat16(v[2 * i + 1])) << 16);
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// Thread t of a 256-thread block owns channel group cg = t % G (G = C/8, a power of two <= 256) and rows
+// r0 + (t / G) + k * RPP, RPP = 256 / G rows per pass.
+// BWD = false: (Σx, Σx²) of x;  BWD = true: (Σg, Σ g*xhat) with g = dy * (y > 0 | all).
+template <bool BWD, bool RELU>
+__global__ __launch_bounds__(256) void bnh_partial_kernel(const unsigned short* __restrict__ a,    // x | dy
+                                                          const unsigned short* __restrict__ y,
+                                                          const unsigned short* __restrict__ x,
+                                                          const float* __restrict__ save_mean,
+                                                          const float* __restrict__ save_invstd, long long M, int C,
+                                                          float* __restrict__ partial)          // [nblk][C][2]
+{
+    __shared__ float s_red[256 * 16];
+    const int G = C >> 3, RPP = 256 / G;
+    const int cg = threadIdx.x % G, rsub = threadIdx.x / G;
+    float s1[8], s2[8], mean[8], invstd[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        s1[k] = 0.f; s2[k] = 0.f;
+        mean[k] = BWD ? save_mean[cg * 8 + k] : 0.f;
+        invstd[k] = BWD ? save_invstd[cg * 8 + k] : 0.f;
+    }
+    for (long long r = (long long)blockIdx.x * RPP + rsub; r < M; r += (long long)gridDim.x * RPP) {
+        const size_t off = (size_t)r * C + cg * 8;
+        float v[8];
+        bnh_load8(a + off, v);
+        if (!BWD) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { s1[k] += v[k]; s2[k] = fmaf(v[k], v[k], s2[k]); }
+        } else {
+            float yy[8], xx[8];
+            if (RELU) bnh_load8(y + off, yy);
+            bnh_load8(x + off, xx);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float g = (!RELU || yy[k] > 0.f) ? v[k] : 0.f;
+                s1[k] += g;
+                s2[k] = fmaf(g, (xx[k] - mean[k]) * invstd[k], s2[k]);
+            }
+        }
+    }
+    // fold the RPP row-subsets of each channel group (fixed order)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        s_red[threadIdx.x * 16 + k] = s1[k];
+        s_red[threadIdx.x * 16 + 8 + k] = s2[k];
+    }
+    __syncthreads();
+    if (rsub == 0) {
+        float* dst = partial + ((size_t)blockIdx.x * C + cg * 8) * 2;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float t1 = 0.f, t2 = 0.f;
+            for (int j = 0; j < RPP; ++j) {
+                t1 += s_red[(j * G + cg) * 16 + k];
+                t2 += s_red[(j * G + cg) * 16 + 8 + k];
+            }
+            dst[2 * k] = t1;
+            dst[2 * k + 1] = t2;
+        }
+    }
+}
+
+// sums[i] = Σ_blk partial[blk][i] (i over C*2) in double, fixed order: a block owns 16 consecutive entries, its
+// 16 thread rows take blk = j, j+16, ... and are folded in ascending j.
+__global__ __launch_bounds__(256) void bnh_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
+                                                           double* __restrict__ sums)
+{
+    __shared__ double s[16][17];
+    const int e = threadIdx.x & 15, j = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + e;                   // C*2 is a multiple of 16
+    double acc = 0.0;
+#pragma unroll 4
+    for (int b = j; b < nblk; b += 16) acc += (double)partial[(size_t)b * C * 2 + i];
+    s[j][e] = acc;
+    __syncthreads();
+    if (j == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += s[q][e];
+        sums[i] = t;
+    }
+}
+
+// mean / invstd of the batch (double arithmetic, once per channel — not once per thread) + running statistics
+__global__ __launch_bounds__(256) void bnh_prep_fwd_kernel(const double* __restrict__ sums, double count, float momentum,
+                                                           float eps, float* __restrict__ run_mean,
+                                                           float* __restrict__ run_var, float* __restrict__ save_mean,
+                                                           float* __restrict__ save_invstd, int C)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const double m = sums[2 * c] / count;
+    double var = sums[2 * c + 1] / count - m * m;
+    var = var < 0.0 ? 0.0 : var;
+    const float mean = (float)m;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    save_mean[c] = mean;
+    save_invstd[c] = invstd;
+    if (run_mean) {           // torch: running = (1-m)*running + m*batch; unbiased variance
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * mean;
+        run_var[c] = (1.0f - momentum) * run_var[c] + momentum * (float)unb;
+    }
+}
+
+template <bool RES, bool RELU>
+__global__ __launch_bounds__(256) void bnh_apply_kernel(const unsigned short* __restrict__ x,
+                                                        const unsigned short* __restrict__ res,
+                                                        unsigned short* __restrict__ y, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta,
+                                                        const float* __restrict__ save_mean,
+                                                        const float* __restrict__ save_invstd, long long M, int C)
+{
+    const int G = C >> 3, RPP = 256 / G;
+    const int cg = threadIdx.x % G, rsub = threadIdx.x / G;
+    float scale[8], shift[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = cg * 8 + k;
+        scale[k] = (gamma ? gamma[c] : 1.0f) * save_invstd[c];
+        shift[k] = fmaf(-save_mean[c], scale[k], beta ? beta[c] : 0.0f);
+    }
+    for (long long r = (long long)blockIdx.x * RPP + rsub; r < M; r += (long long)gridDim.x * RPP) {
+        const size_t off = (size_t)r * C + cg * 8;
+        float v[8], rr[8];
+        bnh_load8(x + off, v);
+        if (RES) bnh_load8(res + off, rr);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float o = fmaf(v[k], scale[k], shift[k]);
+            if (RES) o += rr[k];
+            if (RELU) o = o > 0.f ? o : 0.f;
+            v[k] = o;
+        }
+        bnh_store8(y + off, v);
+    }
+}
+
+template <bool RELU, bool DRES>
+__global__ __launch_bounds__(256) void bnh_bwd_apply_kernel(
+    const unsigned short* __restrict__ dy, const unsigned short* __restrict__ y, const unsigned short* __restrict__ x,
+    const float* __restrict__ gamma, const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
+    const double* __restrict__ sums, double inv_count, unsigned short* __restrict__ dx,
+    unsigned short* __restrict__ dres, float* __restrict__ dgamma, float* __restrict__ dbeta, long long M, int C)
+{
+    const int G = C >> 3, RPP = 256 / G;
+    const int cg = threadIdx.x % G, rsub = threadIdx.x / G;
+    float mean[8], invstd[8], k0[8], mg[8], mgx[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = cg * 8 + k;
+        const double s1 = sums[2 * c], s2 = sums[2 * c + 1];
+        if (blockIdx.x == 0 && rsub == 0) {
+            if (dbeta) dbeta[c] = (float)s1;
+            if (dgamma) dgamma[c] = (float)s2;
+        }
+        mean[k] = save_mean[c];
+        invstd[k] = save_invstd[c];
+        k0[k] = (gamma ? gamma[c] : 1.0f) * invstd[k];
+        mg[k] = (float)(s1 * inv_count);
+        mgx[k] = (float)(s2 * inv_count);
+    }
+    for (long long r = (long long)blockIdx.x * RPP + rsub; r < M; r += (long long)gridDim.x * RPP) {
+        const size_t off = (size_t)r * C + cg * 8;
+        float g[8], yy[8], xx[8];
+        bnh_load8(dy + off, g);
+        if (RELU) bnh_load8(y + off, yy);
+        bnh_load8(x + off, xx);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float gg = (!RELU || yy[k] > 0.f) ? g[k] : 0.f;
+            g[k] = gg;
+            xx[k] = k0[k] * (gg - mg[k] - (xx[k] - mean[k]) * invstd[k] * mgx[k]);
+        }
+        bnh_store8(dx + off, xx);
+        if (DRES) bnh_store8(dres + off, g);
+    }
+}
+
+static int bnh_nblk(long long M, int C)
+{
+    const int rpp = 256 / (C / 8);
+    long long nb = (M + (long long)rpp * 16 - 1) / ((long long)rpp * 16);      // >= 16 passes per block
+    nb = nb < 1 ? 1 : (nb > BNH_MAXBLK ? BNH_MAXBLK : nb);
+    return (int)nb;
+}
+
+}  // namespace hiast
+
+static int bnh_check(const void* x, long long M, int C)
+{
+    if (!x) return HIAST_E_ARG;
+    if (M <= 0 || C <= 0) return HIAST_E_ARG;
+    if (C < 8 || C > 2048 || (C & (C - 1)) != 0 || (((uintptr_t)x) & 15)) return HIAST_E_RANGE;
+    return 0;
+}
+
+extern "C" size_t hiast_bn_nhwc_workspace_bytes(int C) { return (size_t)hiast::BNH_MAXBLK * C * 2 * sizeof(float); }
+
+extern "C" int hiast_bn_nhwc_stats(const void* x, int64_t M, int C, double* sums, void* workspace,
+                                   size_t workspace_bytes, hiast_stream_t stream)
+{
+    int e = bnh_check(x, M, C);
+    if (e) return e;
+    if (!sums || !workspace) return HIAST_E_ARG;
+    const int nblk = hiast::bnh_nblk(M, C);
+    if (workspace_bytes < (size_t)nblk * C * 2 * sizeof(float)) return HIAST_E_WS;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL((hiast::bnh_partial_kernel<false, false>), dim3(nblk), dim3(256), 0, st,
+                       (const unsigned short*)x, nullptr, nullptr, nullptr, nullptr, (long long)M, C, (float*)workspace);
+    HIAST_CHECK_LAUNCH();
+    hipLaunchKernelGGL(hiast::bnh_finalize_kernel, dim3(C * 2 / 16), dim3(256), 0, st, (const float*)workspace, nblk, C,
+                       sums);
+    HIAST_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int hiast_bn_nhwc_apply(const void* x, const void* res, void* y, const float* gamma, const float* beta,
+                                   float* running_mean, float* running_var, const double* sums, double count,
+                                   float momentum, float eps, int relu, float* save_mean, float* save_invstd,
+                                   int64_t M, int C, hiast_stream_t stream)
+{
+    int e = bnh_check(x, M, C);
+    if (e) return e;
+    if (!y || !sums || !save_mean || !save_invstd || count <= 0) return HIAST_E_ARG;
+    if ((((uintptr_t)y) | ((uintptr_t)res)) & 15) return HIAST_E_RANGE;
+    const int rpp = 256 / (C / 8);
+    long long nb = (M + (long long)rpp * 8 - 1) / ((long long)rpp * 8);      // >= 8 rows per thread
+    nb = nb < 1 ? 1 : (nb > 2048 ? 2048 : nb);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(hiast::bnh_prep_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, count, momentum, eps,
+                       running_mean, running_var, save_mean, save_invstd, C);
+    HIAST_CHECK_LAUNCH();
+#define L(RES, RELU)                                                                                              \
+    hipLaunchKernelGGL((hiast::bnh_apply_kernel<RES, RELU>), dim3((unsigned)nb), dim3(256), 0, st,                 \
+                       (const unsigned short*)x, (const unsigned short*)res, (unsigned short*)y, gamma, beta,      \
+                       save_mean, save_invstd, (long long)M, C)
+    if (res) { if (relu) L(true, true); else L(true, false); }
+    else { if (relu) L(false, true); else L(false, false); }
+#undef L
+    HIAST_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int hiast_bn_nhwc_bwd_stats(const void* dy, const void* y, const void* x, const float* save_mean,
+                                       const float* save_invstd, int relu, int64_t M, int C, double* sums,
+                                       void* workspace, size_t workspace_bytes, hiast_stream_t stream)
+{
+    int e = bnh_check(x, M, C);
+    if (e) return e;
+    if (!dy || !save_mean || !save_invstd || !sums || !workspace || (relu && !y)) return HIAST_E_ARG;
+    if ((((uintptr_t)dy) | ((uintptr_t)y)) & 15) return HIAST_E_RANGE;
+    const int nblk = hiast::bnh_nblk(M, C);
+    if (workspace_bytes < (size_t)nblk * C * 2 * sizeof(float)) return HIAST_E_WS;
+    hipStream_t st = (hipStream_t)stream;
+    if (relu)
+        hipLaunchKernelGGL((hiast::bnh_partial_kernel<true, true>), dim3(nblk), dim3(256), 0, st,
+                           (const unsigned short*)dy, (const unsigned short*)y, (const unsigned short*)x, save_mean,
+                           save_invstd, (long long)M, C, (float*)workspace);
+    else
+        hipLaunchKernelGGL((hiast::bnh_partial_kernel<true, false>), dim3(nblk), dim3(256), 0, st,
+                           (const unsigned short*)dy, (const unsigned short*)y, (const unsigned short*)x, save_mean,
+                           save_invstd, (long long)M, C, (float*)workspace);
+    HIAST_CHECK_LAUNCH();
+    hipLaunchKernelGGL(hiast::bnh_finalize_kernel, dim3(C * 2 / 16), dim3(256), 0, st, (const float*)workspace, nblk, C,
+                       sums);
+    HIAST_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int hiast_bn_nhwc_bwd_apply(const void* dy, const void* y, const void* x, const float* gamma,
+                                       const float* save_mean, const float* save_invstd, const double* sums,
+                                       double count, int relu, void* dx, void* dres, float* dgamma, float* dbeta,
+                                       int64_t M, int C, hiast_stream_t stream)
+{
+    int e = bnh_check(x, M, C);
+    if (e) return e;
+    if (!dy || !save_mean || !save_invstd || !sums || !dx || (relu && !y) || count <= 0) return HIAST_E_ARG;
+    if ((((uintptr_t)dy) | ((uintptr_t)y) | ((uintptr_t)dx) | ((uintptr_t)dres)) & 15) return HIAST_E_RANGE;
+    const int rpp = 256 / (C / 8);
+    long long nb = (M + (long long)rpp * 8 - 1) / ((long long)rpp * 8);
+    nb = nb < 1 ? 1 : (nb > 2048 ? 2048 : nb);
+    hipStream_t st = (hipStream_t)stream;
+#define L(RELU, DRES)                                                                                              \
+    hipLaunchKernelGGL((hiast::bnh_bwd_apply_kernel<RELU, DRES>), dim3((unsigned)nb), dim3(256), 0, st,             \
+                       (const unsigned short*)dy, (const unsigned short*)y, (const unsigned short*)x, gamma,        \
+                       save_mean, save_invstd, sums, 1.0 / count, (unsigned short*)dx, (unsigned short*)dres, dgamma, \
+                       dbeta, (long long)M, C)
+    if (relu) { if (dres) L(true, true); else L(true, false); }
+    else { if (dres) L(false, true); else L(false, false); }
+#undef L
+    HIAST_CHECK_LAUNCH();
+    return 0;
+}

@@ -313,20 +313,26 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
     }
 }
 
-// fp32 conv weight [N][K][taps] (torch layout; taps = kh*kw) -> Wp[N][taps][slabs of 128 B] bf16
+// fp32 conv weight [N][K][taps] (torch layout; taps = kh*kw) -> Wp[N][taps][slabs of 128 B] bf16.
+// transpose: pack the weight of the ADJOINT convolution instead (the data-gradient of a stride-1 conv is a conv of
+// dY with the channel-transposed, spatially flipped kernel): Wp[k][taps-1-t][.. n ..] = w[n][k][t]; the output then
+// has N_out = K rows and K_out = N reduction channels.
 template <int PL>
 __global__ __launch_bounds__(256) void pack_conv_weight_kernel(const float* __restrict__ w,
-                                                               unsigned short* __restrict__ wp, int N, int K, int taps)
+                                                               unsigned short* __restrict__ wp, int N, int K, int taps,
+                                                               int transpose)
 {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long long)N * taps * K) return;
-    const int k = (int)(idx % K);
-    const int t = (int)((idx / K) % taps);
-    const int n = (int)(idx / ((long long)K * taps));
-    const float v = w[((size_t)n * K + k) * taps + t];
+    const int NO = transpose ? K : N, KO = transpose ? N : K;       // rows / reduction length of the packed matrix
+    const int k = (int)(idx % KO);
+    const int t = (int)((idx / KO) % taps);
+    const int n = (int)(idx / ((long long)KO * taps));
+    (void)NO;
+    const float v = transpose ? w[((size_t)k * K + n) * taps + (taps - 1 - t)] : w[((size_t)n * K + k) * taps + t];
     unsigned short h, l;
     ig_split(v, h, l);
-    unsigned short* row = wp + ((size_t)n * taps + t) * PL * K;
+    unsigned short* row = wp + ((size_t)n * taps + t) * PL * KO;
     if (PL == 2) {
         unsigned short* dst = row + (size_t)(k >> 5) * 64 + (k & 31);
         dst[0] = h;
@@ -454,7 +460,7 @@ extern "C" int hiast_igemm_bn_act(const void* x, const void* wp, const float* ga
                               W, stride, dil, planes, out_f32, (hipStream_t)stream);
 }
 
-extern "C" int hiast_pack_conv_weight(const float* w, int N, int K, int taps, int planes, void* wp,
+extern "C" int hiast_pack_conv_weight(const float* w, int N, int K, int taps, int planes, int transpose, void* wp,
                                       hiast_stream_t stream)
 {
     if (!w || !wp) return HIAST_E_ARG;
@@ -464,10 +470,10 @@ extern "C" int hiast_pack_conv_weight(const float* w, int N, int K, int taps, in
     const dim3 grid((unsigned)((total + 255) / 256));
     if (planes == 2)
         hipLaunchKernelGGL(hiast::pack_conv_weight_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, w,
-                           (unsigned short*)wp, N, K, taps);
+                           (unsigned short*)wp, N, K, taps, transpose);
     else
         hipLaunchKernelGGL(hiast::pack_conv_weight_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, w,
-                           (unsigned short*)wp, N, K, taps);
+                           (unsigned short*)wp, N, K, taps, transpose);
     HIAST_CHECK_LAUNCH();
     return 0;
 }

@@ -194,6 +194,108 @@ class _BnActFn(torch.autograd.Function):
                 None, None, None, None, None, None, None)
 
 
+def _is_cl(t):
+    """4-d tensor whose memory is channels-last contiguous (and not merely a degenerate NCHW view)"""
+    return t.dim() == 4 and t.permute(0, 2, 3, 1).is_contiguous()
+
+
+class _BnActNhwcFn(torch.autograd.Function):
+    """_BnActFn on channels-last bf16 activations (hiast_bn_nhwc_*): the layout of the hand-written convolution
+    kernels, so the student forward / backward needs no NCHW<->NHWC transposes."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, running_mean, running_var, momentum, eps, relu, world):
+        sums = K.bn_nhwc_stats(x)
+        count = float(x.shape[0] * x.shape[2] * x.shape[3])
+        if world > 1:      # SyncBN: one all-reduce of [C,2] double sums
+            import torch.distributed as dist
+            dist.all_reduce(sums)
+            count *= world
+        y, sm, si = K.bn_nhwc_apply(x, res, gamma, beta, running_mean, running_var, sums, count, momentum, eps, relu)
+        ctx.save_for_backward(x, y, gamma, sm, si)
+        ctx.relu, ctx.has_res, ctx.world, ctx.count = relu, res is not None, world, count
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, sm, si = ctx.saved_tensors
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        sums = K.bn_nhwc_bwd_stats(dy, y, x, sm, si, ctx.relu)
+        if ctx.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(sums)
+        want_p = gamma is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3])
+        dx, dres, dg, db = K.bn_nhwc_bwd_apply(dy, y, x, gamma, sm, si, sums, ctx.count, ctx.relu,
+                                               ctx.has_res and ctx.needs_input_grad[1], want_p)
+        return (dx, dres, dg if ctx.needs_input_grad[2] else None, db if ctx.needs_input_grad[3] else None,
+                None, None, None, None, None, None)
+
+
+class _ConvNhwcFn(torch.autograd.Function):
+    """bias-free 1x1 / 3x3 ("same" padding = dilation) convolution of the ResNet trunk on channels-last bf16
+    activations under mixed precision (the reference trains under apex O1: half-precision convolutions, fp32
+    master weights): forward and data gradient on the LDS-DMA implicit-GEMM kernel (hiast_igemm_bn_act with the
+    weight / its adjoint packed to bf16), weight gradient by the library (MIOpen) on the same channels-last
+    tensors."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, x, weight, stride, dil):
+        xv = x.permute(0, 2, 3, 1)
+        wp = K.pack_conv_weight(weight, 1)
+        y = K.igemm_bn_act(xv, wp, 1, None, None, False, stride, dil)
+        ctx.save_for_backward(x, weight)
+        ctx.geo = (stride, dil)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        stride, dil = ctx.geo
+        if dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        k = weight.shape[2]
+        pad = dil if k == 3 else 0
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dx = dw = None
+        lib_x = need_x and stride != 1
+        if need_x and stride == 1:
+            wpt = K.pack_conv_weight(weight, 1, transpose=True)
+            dx = K.igemm_bn_act(dy.permute(0, 2, 3, 1), wpt, 1, None, None, False, 1, dil).permute(0, 3, 1, 2)
+        if need_w or lib_x:
+            wl = torch.empty(weight.shape, dtype=torch.bfloat16, device=weight.device)
+            if lib_x:
+                wl = weight.to(torch.bfloat16)
+            gx, gw, _ = torch.ops.aten.convolution_backward(dy, x, wl, None, (stride, stride), (pad, pad), (dil, dil),
+                                                            False, (0, 0), 1, (lib_x, need_w, False))
+            if lib_x:
+                dx = gx
+            if need_w:
+                dw = gw.to(weight.dtype)
+        return dx, dw, None, None
+
+
+def conv_nhwc_ok(x, conv):
+    """the trunk convolutions this path covers: bf16 channels-last input, bias-free 1x1 (stride 1) or 3x3 with
+    padding == dilation, channel counts the kernel tiles (multiples of 64)"""
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and _is_cl(x)) or conv.bias is not None or conv.groups != 1:
+        return False
+    k = conv.kernel_size
+    if k not in ((1, 1), (3, 3)) or conv.stride[0] != conv.stride[1] or conv.in_channels % 64 or conv.out_channels % 64:
+        return False
+    if k == (1, 1):
+        return conv.stride == (1, 1) and conv.padding == (0, 0)
+    return conv.padding == conv.dilation and conv.dilation[0] == conv.dilation[1] and conv.stride[0] in (1, 2)
+
+
+def conv_nhwc(x, conv):
+    return _ConvNhwcFn.apply(x, conv.weight, conv.stride[0], conv.dilation[0])
+
+
 def bn_act(x, bn, res=None, relu=True):
     """Fused replacement of `relu(bn(x) [+ res])` for a torch BatchNorm2d / SyncBatchNorm module `bn`
     (which keeps owning the parameters and running statistics)."""
@@ -201,5 +303,9 @@ def bn_act(x, bn, res=None, relu=True):
     if training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     momentum = 0.1 if bn.momentum is None else bn.momentum
+    if (training and x.dtype == torch.bfloat16 and _is_cl(x) and not x.is_contiguous()
+            and K.bn_nhwc_supported(x.shape[1]) and (res is None or (res.dtype == x.dtype and _is_cl(res)))):
+        return _BnActNhwcFn.apply(x, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, momentum, bn.eps, relu,
+                                  _sync_world(bn))
     return _BnActFn.apply(x, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum,
                           bn.eps, relu, _sync_world(bn) if training else 1)

@@ -515,15 +515,17 @@ def merge_planes(p):
     return x
 
 
-def pack_conv_weight(weight, planes):
-    """fp32 conv weight [N,K,kh,kw] (torch layout) -> packed bf16 [N, kh*kw, planes*K]"""
+def pack_conv_weight(weight, planes, transpose=False):
+    """fp32 conv weight [N,K,kh,kw] (torch layout) -> packed bf16 [N, kh*kw, planes*K]; transpose=True packs the
+    adjoint (data-gradient) convolution's weight [K, kh*kw (flipped), planes*N]"""
     w = weight.detach()
     if w.dim() == 2:
         w = w.reshape(w.shape[0], w.shape[1], 1, 1)
     _req(w, torch.float32, 4, "weight")
     N, K_, kh, kw = w.shape
-    wp = torch.empty((N, kh * kw, planes * K_), dtype=torch.bfloat16, device=w.device)
-    check(_lib.load().hiast_pack_conv_weight(_ptr(w), N, K_, kh * kw, planes, _ptr(wp), _stream()),
+    shape = (K_, kh * kw, planes * N) if transpose else (N, kh * kw, planes * K_)
+    wp = torch.empty(shape, dtype=torch.bfloat16, device=w.device)
+    check(_lib.load().hiast_pack_conv_weight(_ptr(w), N, K_, kh * kw, planes, int(bool(transpose)), _ptr(wp), _stream()),
           "hiast_pack_conv_weight")
     return wp
 
@@ -561,3 +563,88 @@ def igemm_bn_act(x, wp, planes, bn, res, relu, stride=1, dil=1, out_f32=False):
                                          B, H, W, Cin, N, taps, int(stride), int(dil), PL, int(bool(out_f32)),
                                          _stream()), "hiast_igemm_bn_act")
     return y
+
+
+# ------------------------------------------------------------------------------- K10b BN (train) on channels-last bf16
+def _bnh_view(t, name):
+    """logical [B,C,H,W] bf16 tensor with channels-last memory -> ([M,C] view, M, C)"""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.HiastLibraryError("%s must be a CUDA(HIP) tensor: the HIP path has no CPU fallback" % name)
+    if t.dtype != torch.bfloat16 or t.dim() != 4:
+        raise TypeError("%s must be a 4-d bfloat16 tensor" % name)
+    v = t.permute(0, 2, 3, 1)
+    if not v.is_contiguous():
+        raise ValueError("%s must be channels-last contiguous" % name)
+    B, H, W, C = v.shape
+    return v, B * H * W, C
+
+
+_bnh_ws = {}
+
+
+def _bnh_workspace(C, device):
+    key = (C, device)
+    ws = _bnh_ws.get(key)
+    if ws is None:
+        n = _lib.load().hiast_bn_nhwc_workspace_bytes(C)
+        ws = torch.empty(n // 4, dtype=torch.float32, device=device)
+        _bnh_ws[key] = ws
+    return ws
+
+
+def bn_nhwc_supported(C):
+    return 8 <= C <= 2048 and (C & (C - 1)) == 0
+
+
+def bn_nhwc_stats(x):
+    """-> sums f64 [C,2] = (Σx, Σx²)"""
+    xv, M, C = _bnh_view(x, "x")
+    sums = torch.empty((C, 2), dtype=torch.float64, device=x.device)
+    ws = _bnh_workspace(C, x.device)
+    check(_lib.load().hiast_bn_nhwc_stats(_ptr(xv), M, C, _ptr(sums), _ptr(ws), ws.numel() * 4, _stream()),
+          "hiast_bn_nhwc_stats")
+    return sums
+
+
+def bn_nhwc_apply(x, res, gamma, beta, running_mean, running_var, sums, count, momentum, eps, relu):
+    xv, M, C = _bnh_view(x, "x")
+    y = torch.empty_like(x, memory_format=torch.channels_last)
+    rv = None
+    if res is not None:
+        rv, M2, C2 = _bnh_view(res, "res")
+        assert (M2, C2) == (M, C)
+    assert sums.dtype == torch.float64 and tuple(sums.shape) == (C, 2) and sums.is_contiguous()
+    sm = torch.empty(C, dtype=torch.float32, device=x.device)
+    si = torch.empty(C, dtype=torch.float32, device=x.device)
+    check(_lib.load().hiast_bn_nhwc_apply(_ptr(xv), _ptr(rv), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(running_mean),
+                                          _ptr(running_var), _ptr(sums), float(count), float(momentum), float(eps),
+                                          int(bool(relu)), _ptr(sm), _ptr(si), M, C, _stream()), "hiast_bn_nhwc_apply")
+    return y, sm, si
+
+
+def bn_nhwc_bwd_stats(dy, y, x, save_mean, save_invstd, relu):
+    xv, M, C = _bnh_view(x, "x")
+    dv, M2, C2 = _bnh_view(dy, "dy")
+    assert (M2, C2) == (M, C)
+    yv = _bnh_view(y, "y")[0] if relu else None
+    sums = torch.empty((C, 2), dtype=torch.float64, device=x.device)
+    ws = _bnh_workspace(C, x.device)
+    check(_lib.load().hiast_bn_nhwc_bwd_stats(_ptr(dv), _ptr(yv), _ptr(xv), _ptr(save_mean), _ptr(save_invstd),
+                                              int(bool(relu)), M, C, _ptr(sums), _ptr(ws), ws.numel() * 4, _stream()),
+          "hiast_bn_nhwc_bwd_stats")
+    return sums
+
+
+def bn_nhwc_bwd_apply(dy, y, x, gamma, save_mean, save_invstd, sums, count, relu, want_dres, want_dparam):
+    xv, M, C = _bnh_view(x, "x")
+    dv = _bnh_view(dy, "dy")[0]
+    yv = _bnh_view(y, "y")[0] if relu else None
+    dx = torch.empty_like(x, memory_format=torch.channels_last)
+    dres = torch.empty_like(x, memory_format=torch.channels_last) if want_dres else None
+    dg = torch.empty(C, dtype=torch.float32, device=x.device) if want_dparam else None
+    db = torch.empty(C, dtype=torch.float32, device=x.device) if want_dparam else None
+    check(_lib.load().hiast_bn_nhwc_bwd_apply(_ptr(dv), _ptr(yv), _ptr(xv), _ptr(gamma), _ptr(save_mean),
+                                              _ptr(save_invstd), _ptr(sums), float(count), int(bool(relu)), _ptr(dx),
+                                              _ptr(dres), _ptr(dg), _ptr(db), M, C, _stream()),
+          "hiast_bn_nhwc_bwd_apply")
+    return dx, dres, dg, db

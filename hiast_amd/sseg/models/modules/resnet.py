@@ -23,6 +23,14 @@ def bn_act(bn, x, res=None, relu=True):
     return F.relu(y) if relu else y
 
 
+def conv(m, x):
+    """a trunk nn.Conv2d: on channels-last bf16 device activations (the mixed-precision training step) it runs on
+    the hand-written implicit-GEMM kernel, otherwise as the plain torch module"""
+    if x.is_cuda and x.dtype == torch.bfloat16 and HF.conv_nhwc_ok(x, m):
+        return HF.conv_nhwc(x, m)
+    return m(x)
+
+
 def _nhwc2d(t):
     """logical NCHW tensor with channels-last strides -> zero-copy [B*H*W, C] view"""
     B, C, H, W = t.shape
@@ -63,10 +71,10 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        idt = x if self.downsample is None else bn_act(self.downsample[1], self.downsample[0](x), relu=False)
-        o = bn_act(self.bn1, self.conv1(x))
-        o = bn_act(self.bn2, self.conv2(o))
-        return bn_act(self.bn3, self.conv3(o), res=idt)        # += identity, ReLU
+        idt = x if self.downsample is None else bn_act(self.downsample[1], conv(self.downsample[0], x), relu=False)
+        o = bn_act(self.bn1, conv(self.conv1, x))
+        o = bn_act(self.bn2, conv(self.conv2, o))
+        return bn_act(self.bn3, conv(self.conv3, o), res=idt)        # += identity, ReLU
 
     def forward_eval_planes(self, x, PL):
         """inference on channels-last 16-bit activations [B,H,W,PL*C] (PL = 2: split planes, fp32-class — the
@@ -163,7 +171,14 @@ class ResNet(nn.Module):
             PL = self.fast_eval_planes(x)
             if PL:
                 return self.planes_to_feature(self.forward_eval_planes(x, PL), PL)
-        x = self.maxpool(bn_act(self.bn1, self.conv1(x)))
+        if (x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
+                and os.environ.get("HIAST_TRAIN_NCHW", "0") != "1"):
+            # mixed-precision step: the whole trunk runs channels-last (library stem -> bf16 NHWC activations)
+            x = x.contiguous(memory_format=torch.channels_last)
+            x = self.conv1(x).contiguous(memory_format=torch.channels_last)
+        else:
+            x = self.conv1(x)
+        x = self.maxpool(bn_act(self.bn1, x))
         low = self.layer1(x)
         x = self.layer4(self.layer3(self.layer2(low)))
         return (x, low) if is_return_low else x

@@ -217,15 +217,37 @@ int hiast_bn_act_nhwc_infer(const void* x, void* y, const float* gamma, const fl
  * bf16 (hi = bf16(v), lo = bf16(v - hi); 4 bytes per value like fp32): x [B,H,W,planes,Cin], y [B,Ho,Wo,planes,Cout],
  * res like y.  planes = 2: hi*hi + lo*hi + hi*lo on the bf16 matrix cores (fp32-class, the pseudo-label forward);
  * planes = 1: plain bf16.  The split is done once by the producer's epilogue instead of by every consumer block.
- * wp: [Cout][taps][planes][Cin] bf16 from hiast_pack_conv_weight (w: torch layout [Cout][Cin][taps], taps = 1 | 9).
+ * wp: packed bf16 [Cout][taps][planes*Cin] from hiast_pack_conv_weight (w: torch layout [Cout][Cin][taps], taps = 1 | 9;
+ * transpose = 1 packs the ADJOINT convolution's weight [Cin][taps flipped][planes*Cout]: running the same kernel on dY
+ * with it is the data gradient of a stride-1 convolution — autograd of nn.Conv2d in resnet.py:78-98).
  * taps = 9: padding = dilation, stride 1 | 2.  out_f32 = 1: y is fp32 [B,Ho,Wo,Cout] (no residual).  mean == NULL: no
  * BatchNorm (plain GEMM).  Cin % 32 == 0, Cout % 64 == 0, every tensor < 2 GiB, 16-byte aligned.
  * hiast_split_planes: fp32 [M][C] <-> planes [M][2][C] (inverse = 1: x is written; hi + lo is exact in fp32). */
 int hiast_igemm_bn_act(const void* x, const void* wp, const float* gamma, const float* beta, const float* mean,
                        const float* var, float eps, const void* res, int relu, void* y, int B, int H, int W, int Cin,
                        int Cout, int taps, int stride, int dil, int planes, int out_f32, hiast_stream_t stream);
-int hiast_pack_conv_weight(const float* w, int N, int K, int taps, int planes, void* wp, hiast_stream_t stream);
+int hiast_pack_conv_weight(const float* w, int N, int K, int taps, int planes, int transpose, void* wp,
+                           hiast_stream_t stream);
 int hiast_split_planes(float* x, void* planes, int64_t M, int C, int inverse, hiast_stream_t stream);
+
+/* ---- K10b: BatchNorm2d (+ residual) (+ ReLU), TRAINING mode, on channels-last bf16 activations [M = B*H*W][C] ------
+ * Same arithmetic and passes as K10 (resnet.py:78-98 in train(): batch statistics even with frozen affine
+ * parameters, utils/utils.py:60-65) in the layout the convolution kernels of K9c produce / consume.
+ * C a power of two in [8, 2048].  sums [C][2] double: (Σx, Σx²) forward, (Σg, Σ g*xhat) backward — all-reduce them
+ * across ranks between the stats and the apply call for SyncBN.  workspace: hiast_bn_nhwc_workspace_bytes(C). */
+size_t hiast_bn_nhwc_workspace_bytes(int C);
+int hiast_bn_nhwc_stats(const void* x, int64_t M, int C, double* sums, void* workspace, size_t workspace_bytes,
+                        hiast_stream_t stream);
+int hiast_bn_nhwc_apply(const void* x, const void* res, void* y, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, const double* sums, double count, float momentum,
+                        float eps, int relu, float* save_mean, float* save_invstd, int64_t M, int C,
+                        hiast_stream_t stream);
+int hiast_bn_nhwc_bwd_stats(const void* dy, const void* y, const void* x, const float* save_mean,
+                            const float* save_invstd, int relu, int64_t M, int C, double* sums, void* workspace,
+                            size_t workspace_bytes, hiast_stream_t stream);
+int hiast_bn_nhwc_bwd_apply(const void* dy, const void* y, const void* x, const float* gamma, const float* save_mean,
+                            const float* save_invstd, const double* sums, double count, int relu, void* dx, void* dres,
+                            float* dgamma, float* dbeta, int64_t M, int C, hiast_stream_t stream);
 
 /* ---- K11: EMA teacher update ---------------------------------------------------------
  * utils/utils.py:115-123 update_ema_model: ema = ema*gamma + p*(1-gamma) over a list of

@@ -480,6 +480,126 @@ def test_igemm_bf16(K, case):
     assert (np.abs(y - want) <= 2.0 ** -8 * np.abs(want) + 3e-5 * np.abs(want).max()).all()
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 9, 17), (3, 256, 16, 24), (1, 2048, 8, 12), (2, 1024, 5, 7)])
+@pytest.mark.parametrize("res,relu", [(False, True), (True, True), (False, False)])
+def test_bn_nhwc_matches_fp64(K, shape, res, relu):
+    """training-mode BN (+res)(+ReLU) on channels-last bf16, forward and backward, vs float64 torch autograd on the
+    same bf16-rounded inputs (outputs are bf16: 2^-9 relative rounding)"""
+    from hiast_amd import functional as HF
+    B, C, H, W = shape
+    x = _bf16r(synth.normal_f32(400, shape, 2.0) + 0.3)
+    r = _bf16r(synth.normal_f32(401, shape)) if res else None
+    gy = _bf16r(synth.normal_f32(402, shape))
+    bn = torch.nn.BatchNorm2d(C).cuda().train()
+    with torch.no_grad():
+        bn.weight.copy_(dev(1.0 + 0.2 * synth.normal_f32(403, (C,))))
+        bn.bias.copy_(dev(0.1 * synth.normal_f32(404, (C,))))
+    xt = _cl(dev(x).bfloat16()).requires_grad_(True)
+    rt = _cl(dev(r).bfloat16()).requires_grad_(True) if res else None
+    y = HF.bn_act(xt, bn, rt, relu)
+    assert y.dtype == torch.bfloat16 and y.permute(0, 2, 3, 1).is_contiguous()
+    y.backward(_cl(dev(gy).bfloat16()))
+    # reference
+    xd = torch.from_numpy(x).double().requires_grad_(True)
+    rd = torch.from_numpy(r).double().requires_grad_(True) if res else None
+    g, b = bn.weight.detach().double().cpu(), bn.bias.detach().double().cpu()
+    mu = xd.mean((0, 2, 3), keepdim=True)
+    var = xd.var((0, 2, 3), unbiased=False, keepdim=True)
+    yd = (xd - mu) / torch.sqrt(var + bn.eps) * g.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)
+    if res:
+        yd = yd + rd
+    if relu:
+        yd = torch.relu(yd)
+    yd.backward(torch.from_numpy(gy).double())
+    tol = lambda ref: 2.0 ** -7 * ref.abs() + 2e-3 * ref.abs().max()
+    assert ((y.double().cpu() - yd.detach()).abs() <= tol(yd.detach())).all()
+    assert ((xt.grad.double().cpu() - xd.grad).abs() <= tol(xd.grad)).all()
+    if res:
+        assert ((rt.grad.double().cpu() - rd.grad).abs() <= tol(rd.grad)).all()
+    # running statistics follow torch's update rule
+    n = B * H * W
+    assert torch.allclose(bn.running_mean.double().cpu(), 0.1 * mu.detach().flatten(), atol=1e-5)
+    assert torch.allclose(bn.running_var.double().cpu(), 0.9 + 0.1 * var.detach().flatten() * n / (n - 1), rtol=1e-5)
+
+
+@pytest.mark.parametrize("cfg", [(2, 64, 64, 10, 18, 1, 1, 1), (1, 256, 128, 12, 20, 3, 1, 2), (2, 128, 128, 16, 16, 3, 2, 1),
+                                 (1, 512, 256, 9, 11, 3, 1, 4), (1, 1024, 256, 8, 8, 1, 1, 1)])
+def test_conv_nhwc_autograd_vs_fp64(K, cfg):
+    """_ConvNhwcFn (igemm forward / data gradient, library weight gradient) vs float64 autograd on bf16-rounded data"""
+    from hiast_amd import functional as HF
+    B, Cin, Cout, H, W, k, stride, dil = cfg
+    conv = torch.nn.Conv2d(Cin, Cout, k, stride=stride, padding=dil if k == 3 else 0, dilation=dil if k == 3 else 1,
+                           bias=False).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(dev(synth.normal_f32(410, tuple(conv.weight.shape), (2.0 / (Cin * k * k)) ** 0.5)))
+    x = _bf16r(synth.normal_f32(411, (B, Cin, H, W)))
+    xt = _cl(dev(x).bfloat16()).requires_grad_(True)
+    assert HF.conv_nhwc_ok(xt, conv)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = HF.conv_nhwc(xt, conv)
+    gy = _bf16r(synth.normal_f32(412, tuple(y.shape)))
+    y.backward(_cl(dev(gy).bfloat16()))
+    xd = torch.from_numpy(x).double().requires_grad_(True)
+    wd = torch.from_numpy(_bf16r(conv.weight.detach().cpu().numpy())).double().requires_grad_(True)
+    yd = torch.nn.functional.conv2d(xd, wd, None, stride, dil if k == 3 else 0, dil if k == 3 else 1)
+    yd.backward(torch.from_numpy(gy).double())
+    tol = lambda ref: 2.0 ** -7 * ref.abs() + 2e-3 * ref.abs().max()
+    assert ((y.double().cpu() - yd.detach()).abs() <= tol(yd.detach())).all()
+    assert ((xt.grad.double().cpu() - xd.grad).abs() <= tol(xd.grad)).all()
+    assert conv.weight.grad.dtype == torch.float32
+    assert ((conv.weight.grad.double().cpu() - wd.grad).abs() <= tol(wd.grad)).all()
+
+
+def test_training_trunk_channels_last_as_accurate_as_nchw_path(K):
+    """mixed-precision training forward/backward of the whole DeepLab.  A random-init train-mode ResNet-101 amplifies
+    bf16 rounding noise layer by layer (both bf16 paths end ~0.8 of max away from the fp32 forward), so the
+    channels-last path (own conv + BN kernels) is checked to be AS CLOSE to the fp32 path as the NCHW path
+    (library convs + NCHW BN kernels) is, at every stage, and to agree with it while the noise is still small."""
+    import os
+    from hiast_amd.utils.registry import register  # noqa: F401
+    from hiast_amd.utils.registry.registries import SEG_MODEL
+    from make_golden import seeded_state_dict
+    x = torch.from_numpy(synth.normal_f32(905, (2, 3, 97, 129))).cuda()
+    res = {}
+    for mode in ("fp32", "nchw", "nhwc"):
+        m = SEG_MODEL["DeepLab_V2"](19, 256)
+        m.load_state_dict(seeded_state_dict(m, 9100))
+        m = m.cuda().train()
+        acts = {}
+
+        def hook(name, acts=acts):
+            return lambda mod, i, o: acts.__setitem__(name, o.detach().float().contiguous())
+        for n in ("layer1", "layer2", "layer3", "layer4"):
+            getattr(m.backbone, n).register_forward_hook(hook(n))
+        os.environ["HIAST_TRAIN_NCHW"] = "0" if mode == "nhwc" else "1"
+        try:
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=mode != "fp32"):
+                pred, feat = m(x)
+            if mode == "nhwc":
+                assert feat.dtype == torch.bfloat16 and feat.permute(0, 2, 3, 1).is_contiguous()
+            pred.float().square().mean().backward()
+        finally:
+            os.environ.pop("HIAST_TRAIN_NCHW", None)
+        acts["pred"] = pred.detach().float()
+        acts["g_aspp"] = m.aspp.conv2d_list[1].weight.grad.clone()
+        acts["g_l4"] = m.backbone.layer4[2].conv3.weight.grad.clone()
+        acts["rv"] = m.backbone.layer2[3].bn3.running_var.clone()
+        res[mode] = acts
+
+    def d(u, v):
+        return float((u - v).abs().max() / u.abs().max())
+    for k in ("layer1", "layer2", "layer3", "layer4", "pred"):
+        e_nchw, e_nhwc = d(res["fp32"][k], res["nchw"][k]), d(res["fp32"][k], res["nhwc"][k])
+        assert e_nhwc <= 1.3 * e_nchw + 2e-3, (k, e_nchw, e_nhwc)
+    assert d(res["nchw"]["layer1"], res["nhwc"]["layer1"]) < 2e-2
+    assert d(res["nchw"]["layer2"], res["nhwc"]["layer2"]) < 5e-2
+    assert torch.allclose(res["nchw"]["rv"], res["nhwc"]["rv"], rtol=5e-2, atol=1e-4)
+    for k in ("g_aspp", "g_l4"):       # gradients next to the loss: as aligned with fp32 as the NCHW path's
+        cos = lambda a, b: float(torch.nn.functional.cosine_similarity(a.flatten().double(), b.flatten().double(), dim=0))
+        assert torch.isfinite(res["nhwc"][k]).all()
+        assert cos(res["fp32"][k], res["nhwc"][k]) >= cos(res["fp32"][k], res["nchw"][k]) - 0.1, k
+
+
 def test_ema_bit_exact(K):
     shapes = [(7, 5), (70001,), (3, 2, 3, 3), (64, 2048, 1, 1)]
     e = [synth.normal_f32(70 + i, s) for i, s in enumerate(shapes)]
