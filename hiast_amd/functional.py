@@ -275,7 +275,8 @@ class _ConvNhwcFn(torch.autograd.Function):
             if lib_x:
                 dx = gx
             if need_w:
-                dw = gw.to(weight.dtype)
+                # fp32, NCHW-contiguous like the parameter (DDP's gradient-layout contract): one cast+layout kernel
+                dw = gw.to(dtype=weight.dtype, memory_format=torch.contiguous_format)
         return dx, dw, None, None
 
 

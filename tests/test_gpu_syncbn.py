@@ -42,6 +42,16 @@ def _worker(rank, world, port, out):
     y.backward(torch.from_numpy(g[half]).cuda())
     res = {"y": y.detach().cpu().numpy(), "gx": xd.grad.cpu().numpy(), "gr": rd.grad.cpu().numpy(),
            "rm": bn.running_mean.cpu().numpy(), "rv": bn.running_var.cpu().numpy()}
+    # the channels-last bf16 flavour (mixed-precision training trunk): one all-reduce of [C,2] double sums per pass
+    bn2 = torch.nn.SyncBatchNorm(C).cuda().train()
+    cl = lambda a: torch.from_numpy(a).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+    xb, rb = cl(x[half]).requires_grad_(True), cl(r[half]).requires_grad_(True)
+    yb = HF.bn_act(xb, bn2, rb, True)
+    assert yb.dtype == torch.bfloat16 and yb.permute(0, 2, 3, 1).is_contiguous()
+    yb.backward(cl(g[half]))
+    res.update({"yb": yb.detach().float().cpu().numpy(), "gxb": xb.grad.float().cpu().numpy(),
+                "grb": rb.grad.float().cpu().numpy(), "rmb": bn2.running_mean.cpu().numpy(),
+                "rvb": bn2.running_var.cpu().numpy()})
     np.savez(out % rank, **res)
     dist.barrier()
     dist.destroy_process_group()
@@ -68,3 +78,17 @@ def test_syncbn_two_ranks_equal_full_batch(tmp_path):
     for p in parts:       # both ranks hold the GLOBAL running statistics
         assert np.allclose(p["rm"], bn.running_mean.numpy(), rtol=1e-5, atol=1e-6)
         assert np.allclose(p["rv"], bn.running_var.numpy(), rtol=1e-5, atol=1e-6)
+    # channels-last bf16 flavour: same semantics on the bf16-rounded inputs, outputs rounded to bf16
+    bf = lambda a: torch.from_numpy(a).bfloat16().double()
+    xq = bf(synth.normal_f32(301, (B, C, H, W), 2.0) + 0.3).requires_grad_(True)
+    rq = bf(synth.normal_f32(302, (B, C, H, W), 1.0)).requires_grad_(True)
+    bnq = torch.nn.BatchNorm2d(C).double().train()
+    yq = torch.relu(bnq(xq) + rq)
+    yq.backward(bf(synth.normal_f32(303, (B, C, H, W), 1.0)))
+    tol = lambda ref: 2.0 ** -7 * np.abs(ref) + 2e-3 * np.abs(ref).max()
+    for key, ref in (("yb", yq.detach().numpy()), ("gxb", xq.grad.numpy()), ("grb", rq.grad.numpy())):
+        got = np.concatenate([p[key] for p in parts])
+        assert (np.abs(got - ref) <= tol(ref)).all(), key
+    for p in parts:
+        assert np.allclose(p["rmb"], bnq.running_mean.numpy(), rtol=1e-4, atol=1e-5)
+        assert np.allclose(p["rvb"], bnq.running_var.numpy(), rtol=1e-4, atol=1e-5)
