@@ -1,0 +1,42 @@
+"""Launch ONE trunk-conv shape of the LDS-DMA implicit-GEMM kernel a few times (for rocprofv3 --pmc passes).
+    python tools/pmc_igemm.py <name>     name in SHAPES"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from hiast_amd import kernels as K  # noqa: E402
+
+# name: (B, H, W, Cin, Cout, taps, dil, PL, has_res)
+SHAPES = {
+    "l3conv2_pl2": (8, 64, 128, 256, 256, 9, 2, 2, False),
+    "l4conv2_pl2": (8, 64, 128, 512, 512, 9, 4, 2, False),
+    "l3conv3_pl2": (8, 64, 128, 256, 1024, 1, 1, 2, True),
+    "l3conv1_pl2": (8, 64, 128, 1024, 256, 1, 1, 2, False),
+    "l3conv2_pl1": (8, 64, 128, 256, 256, 9, 2, 1, False),
+}
+
+
+def main():
+    name = sys.argv[1]
+    B, H, W, Cin, Cout, taps, dil, PL, has_res = SHAPES[name]
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    kk = 3 if taps == 9 else 1
+    w = torch.randn(Cout, Cin, kk, kk, device=dev) * (2.0 / (Cin * taps)) ** 0.5
+    bn = torch.nn.BatchNorm2d(Cout).to(dev).eval()
+    x32 = torch.randn(B, H, W, Cin, device=dev)
+    xp = K.split_planes(x32.view(-1, Cin)).view(B, H, W, 2 * Cin) if PL == 2 else x32.bfloat16()
+    wp = K.pack_conv_weight(w, PL)
+    res = torch.randn(B, H, W, PL * Cout, device=dev).bfloat16() if has_res else None
+    for _ in range(6):
+        K.igemm_bn_act(xp, wp, PL, bn, res, True, 1, dil)
+    torch.cuda.synchronize()
+    alg = (B * H * W * PL * Cin + Cout * taps * PL * Cin) * 2 + B * H * W * Cout * 2 * PL * (2 if has_res else 1)
+    print("shape %s algorithmic_bytes %d flop %d" % (name, alg, 2 * B * H * W * taps * Cin * Cout))
+
+
+if __name__ == "__main__":
+    main()
