@@ -248,6 +248,18 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
     const int nc = n0 + wn * 64 + ec8 * 8;
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
+        // residual rows of this 32-row chunk: all 4 passes' loads are issued BEFORE the LDS round trip, so their
+        // HBM latency overlaps it (with one 8-wave block per CU nothing else would hide it)
+        uint4 rh[4], rl4[4];
+        if (RES) {
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int m = m0 + wm * (TM * 32) + a * 32 + ps * 8 + erow;
+                const size_t g = ig_elem<PL>((size_t)(m < M ? m : 0), nc, N);
+                rh[ps] = *reinterpret_cast<const uint4*>(R + g);
+                if (PL == 2) rl4[ps] = *reinterpret_cast<const uint4*>(R + g + 32);
+            }
+        }
 #pragma unroll
         for (int b = 0; b < TN; ++b)
 #pragma unroll
@@ -268,17 +280,14 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
             o[0] = o0.x; o[1] = o0.y; o[2] = o0.z; o[3] = o0.w; o[4] = o1.x; o[5] = o1.y; o[6] = o1.z; o[7] = o1.w;
             if (m < M) {
                 if (RES) {
-                    const size_t g = ig_elem<PL>((size_t)m, nc, N);
-                    const uint4 rh = *reinterpret_cast<const uint4*>(R + g);
-                    const unsigned wh[4] = {rh.x, rh.y, rh.z, rh.w};
+                    const unsigned wh[4] = {rh[ps].x, rh[ps].y, rh[ps].z, rh[ps].w};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         o[2 * q] += __uint_as_float(wh[q] << 16);
                         o[2 * q + 1] += __uint_as_float(wh[q] & 0xFFFF0000u);
                     }
                     if (PL == 2) {
-                        const uint4 rl4 = *reinterpret_cast<const uint4*>(R + g + 32);
-                        const unsigned wl[4] = {rl4.x, rl4.y, rl4.z, rl4.w};
+                        const unsigned wl[4] = {rl4[ps].x, rl4[ps].y, rl4[ps].z, rl4[ps].w};
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             o[2 * q] += __uint_as_float(wl[q] << 16);
