@@ -35,6 +35,47 @@ __global__ __launch_bounds__(256) void ema_kernel(const hiast_ema_rec* __restric
     }
 }
 
+// K13 — Adam step over the whole parameter list in ONE launch (reference: torch.optim.Adam(weight_decay=5e-4) built
+// in utils/utils.py:135-154 and stepped by BaseTrainer.update_model, workflows/trainer/base_trainer.py:127-141;
+// there a per-tensor loop of ~10 elementwise kernels).  torch's single-tensor formulas, in its operation order:
+//   g' = g + wd*p;  m = m + (g' - m)*(1 - b1);  v = v*b2 + (1 - b2)*g'*g';
+//   p  = p - (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
+// 64Ki-element chunks like the EMA kernel; lr and the bias corrections travel per tensor in the record.
+__global__ __launch_bounds__(256) void adam_kernel(const hiast_adam_rec* __restrict__ table,
+                                                   const int32_t* __restrict__ chunk_tensor,
+                                                   const int64_t* __restrict__ chunk_start, float beta1, float beta2,
+                                                   float eps, float wd)
+{
+    const hiast_adam_rec r = table[chunk_tensor[blockIdx.x]];
+    const int64_t s = chunk_start[blockIdx.x];
+    const int64_t e = (s + 65536 < r.n) ? s + 65536 : r.n;
+    const float step_size = r.lr / r.bc1, omb1 = 1.0f - beta1, omb2 = 1.0f - beta2;
+    auto upd = [&](float& p, float g, float& m, float& v) {
+        if (wd != 0.f) g = g + wd * p;
+        m = m + (g - m) * omb1;
+        v = v * beta2 + omb2 * g * g;
+        const float denom = sqrtf(v) / r.bc2_sqrt + eps;
+        p = p - step_size * (m / denom);
+    };
+    const bool vec = ((((uintptr_t)r.p) | ((uintptr_t)r.g) | ((uintptr_t)r.m) | ((uintptr_t)r.v)) & 15) == 0;
+    if (vec) {
+        const int64_t nv = (e - s) / 4;
+        float4* p4 = reinterpret_cast<float4*>(r.p + s);
+        const float4* g4 = reinterpret_cast<const float4*>(r.g + s);
+        float4* m4 = reinterpret_cast<float4*>(r.m + s);
+        float4* v4 = reinterpret_cast<float4*>(r.v + s);
+        for (int64_t i = threadIdx.x; i < nv; i += 256) {
+            float4 p = p4[i], m = m4[i], v = v4[i];
+            const float4 g = g4[i];
+            upd(p.x, g.x, m.x, v.x); upd(p.y, g.y, m.y, v.y); upd(p.z, g.z, m.z, v.z); upd(p.w, g.w, m.w, v.w);
+            p4[i] = p; m4[i] = m; v4[i] = v;
+        }
+        for (int64_t i = s + nv * 4 + threadIdx.x; i < e; i += 256) upd(r.p[i], r.g[i], r.m[i], r.v[i]);
+    } else {
+        for (int64_t i = s + threadIdx.x; i < e; i += 256) upd(r.p[i], r.g[i], r.m[i], r.v[i]);
+    }
+}
+
 // utils/metrics.py:6-19: pred[target==255] = 255; inter = hist(pred[pred==target]);
 // area_pred = hist(pred); area_tgt = hist(target) over K bins.  Per-thread pixels -> LDS integer
 // histograms (3*K counters) -> one global integer atomic per non-empty counter per block.
@@ -103,6 +144,18 @@ extern "C" int hiast_confusion_hist(const int64_t* pred, const int64_t* target, 
     hipLaunchKernelGGL(hiast::confusion_kernel, dim3(grid), dim3(256), 3 * K * sizeof(unsigned),
                        (hipStream_t)stream, pred, target, N, K, (unsigned long long*)inter,
                        (unsigned long long*)area_pred, (unsigned long long*)area_tgt);
+    HIAST_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int hiast_adam_step(const hiast_adam_rec* table, const int32_t* chunk_tensor, const int64_t* chunk_start,
+                               int n_chunks, float beta1, float beta2, float eps, float weight_decay,
+                               hiast_stream_t stream)
+{
+    if (!table || !chunk_tensor || !chunk_start) return HIAST_E_ARG;
+    if (n_chunks <= 0) return HIAST_E_ARG;
+    hipLaunchKernelGGL(hiast::adam_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, table, chunk_tensor,
+                       chunk_start, beta1, beta2, eps, weight_decay);
     HIAST_CHECK_LAUNCH();
     return 0;
 }

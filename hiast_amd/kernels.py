@@ -345,6 +345,43 @@ def ema_update(plan, gamma):
                                        _stream()), "hiast_ema_update")
 
 
+# ------------------------------------------------------------------------------- K13 Adam
+class AdamPlan:
+    """chunk tables for one list of parameter sizes (static); the pointer / lr records are rebuilt per step because
+    gradient tensors are re-created by autograd after zero_grad(set_to_none=True)"""
+    CHUNK = 65536
+    REC = np.dtype([("p", np.int64), ("g", np.int64), ("m", np.int64), ("v", np.int64), ("n", np.int64),
+                    ("lr", np.float32), ("bc1", np.float32), ("bc2s", np.float32), ("pad", np.float32)])
+
+    def __init__(self, numels, device):
+        ct, cs = [], []
+        for i, n in enumerate(numels):
+            for s0 in range(0, n, self.CHUNK):
+                ct.append(i)
+                cs.append(s0)
+        self.numels = tuple(numels)
+        self.chunk_tensor = torch.tensor(ct, dtype=torch.int32, device=device)
+        self.chunk_start = torch.tensor(cs, dtype=torch.int64, device=device)
+        self.n_chunks = len(ct)
+        self.host = np.zeros(len(numels), dtype=self.REC)
+        self.table = torch.empty(len(numels) * self.REC.itemsize, dtype=torch.uint8, device=device)
+
+
+def adam_step(plan, params, grads, exp_avgs, exp_avg_sqs, lrs, bc1s, bc2_sqrts, beta1, beta2, eps, weight_decay):
+    """one launch over all tensors; p/m/v updated in place"""
+    h = plan.host
+    for i, (p, g, m, v) in enumerate(zip(params, grads, exp_avgs, exp_avg_sqs)):
+        for t, nm in ((p, "param"), (g, "grad"), (m, "exp_avg"), (v, "exp_avg_sq")):
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == plan.numels[i]):
+                raise ValueError("adam_step: %s %d must be a contiguous float32 HIP tensor of %d elements"
+                                 % (nm, i, plan.numels[i]))
+        h[i] = (p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lrs[i], bc1s[i], bc2_sqrts[i], 0.0)
+    plan.table.copy_(torch.from_numpy(h.view(np.uint8).reshape(-1)), non_blocking=True)
+    check(_lib.load().hiast_adam_step(_ptr(plan.table), _ptr(plan.chunk_tensor), _ptr(plan.chunk_start), plan.n_chunks,
+                                      float(beta1), float(beta2), float(eps), float(weight_decay), _stream()),
+          "hiast_adam_step")
+
+
 # ------------------------------------------------------------------------------- K12 IoU
 def confusion_hist(pred, target, K, inter=None, area_pred=None, area_tgt=None):
     _req(pred, torch.int64, None, "pred")

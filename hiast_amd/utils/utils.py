@@ -120,6 +120,51 @@ def update_ema_model(ema_model, model, gamma):
     return _default_ema(ema_model, model, gamma)
 
 
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam (L2 weight decay, no amsgrad) whose step is ONE HIP launch over every parameter
+    (hiast_adam_step) instead of a per-tensor / foreach sequence of elementwise kernels.  Same param_groups /
+    state layout ('step', 'exp_avg', 'exp_avg_sq'), so LR schedulers and checkpoints are interchangeable."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._plan = None
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        from hiast_amd import kernels as K
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        by_hyper = {}
+        for group in self.param_groups:
+            key = (group["betas"], group["eps"], group["weight_decay"])
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["step"] = torch.tensor(0.0)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                by_hyper.setdefault(key, []).append((p, group["lr"], st))
+        for (betas, eps, wd), items in by_hyper.items():
+            ps = [p for p, _, _ in items]
+            t = [float(st["step"]) for _, _, st in items]
+            plan = self._plan.get(len(ps)) if isinstance(self._plan, dict) else None
+            numels = tuple(p.numel() for p in ps)
+            if plan is None or plan.numels != numels:
+                plan = K.AdamPlan(numels, ps[0].device)
+                self._plan = dict(self._plan or {})
+                self._plan[len(ps)] = plan
+            K.adam_step(plan, [p.data for p in ps], [p.grad.contiguous() for p in ps], [st["exp_avg"] for _, _, st in items],
+                        [st["exp_avg_sq"] for _, _, st in items], [lr for _, lr, _ in items],
+                        [1.0 - betas[0] ** k for k in t], [(1.0 - betas[1] ** k) ** 0.5 for k in t], betas[0], betas[1],
+                        eps, wd)
+        return loss
+
+
 def init_optimizers(cfg, model):
     """utils.py:135-154 (generator optimiser only: no discriminator in the self-training stage)"""
     groups = _unwrap(model).seg_model.get_optimizer_params(cfg.train.lr)
@@ -128,7 +173,8 @@ def init_optimizers(cfg, model):
     if kind == "SGD":
         opt = torch.optim.SGD(groups, momentum=0.9, weight_decay=0.0005)
     elif kind == "Adam":
-        opt = torch.optim.Adam(groups, betas=(0.9, 0.999), weight_decay=0.0005)
+        on_device = all(p.is_cuda for g in groups for p in g["params"])
+        opt = (FusedAdam if on_device else torch.optim.Adam)(groups, betas=(0.9, 0.999), weight_decay=0.0005)
     elif kind == "AdamW":
         opt = torch.optim.AdamW(groups, betas=(0.9, 0.999), weight_decay=0.0005)
     else:

@@ -260,6 +260,16 @@ int hiast_ema_update(const hiast_ema_rec* table, const int32_t* chunk_tensor,
                      const int64_t* chunk_start, int n_chunks, float gamma,
                      float one_minus_gamma, hiast_stream_t stream);
 
+/* ---- K13: Adam step ---------------------------------------------------------------------
+ * torch.optim.Adam(betas, weight_decay) as built by utils/utils.py:135-154 and stepped by BaseTrainer.update_model
+ * (workflows/trainer/base_trainer.py:127-141): every parameter tensor in ONE launch, torch's single-tensor
+ * formulas in its operation order (L2 weight decay folded into the gradient, bias-corrected step).
+ * table: device array of records {p, g, m (exp_avg), v (exp_avg_sq), n, lr, bc1 = 1-b1^t, bc2_sqrt = sqrt(1-b2^t)};
+ * chunk tables as for K11. */
+typedef struct { float* p; const float* g; float* m; float* v; int64_t n; float lr; float bc1; float bc2_sqrt; float pad; } hiast_adam_rec;
+int hiast_adam_step(const hiast_adam_rec* table, const int32_t* chunk_tensor, const int64_t* chunk_start,
+                    int n_chunks, float beta1, float beta2, float eps, float weight_decay, hiast_stream_t stream);
+
 /* ---- K12: IoU histograms --------------------------------------------------------------
  * utils/metrics.py:6-19 intersectionAndUnionGPU: pred/target int64 [N]; target==255 is
  * ignored; inter/area_pred/area_tgt i64 [K] ACCUMULATED (caller zeroes). */

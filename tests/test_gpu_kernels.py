@@ -600,6 +600,60 @@ def test_training_trunk_channels_last_as_accurate_as_nchw_path(K):
         assert cos(res["fp32"][k], res["nhwc"][k]) >= cos(res["fp32"][k], res["nchw"][k]) - 0.1, k
 
 
+def test_fused_adam_ema_cosine_vs_reference_golden(K, golden):
+    """the trajectory the reference's Adam(wd) + update_ema_model + cosine schedule produce (fixture G10), with the
+    one-launch HIP Adam step, the HIP EMA kernel and this package's scheduler"""
+    from types import SimpleNamespace as ns
+    from hiast_amd.utils import utils
+    from hiast_amd.sseg.models.modules.schedulers import build_scheduler
+    g = golden("ema_optim")
+    shapes = [(7, 5), (11,), (3, 2, 3, 3)]
+    p = [torch.nn.Parameter(dev(synth.normal_f32(1200 + i, s))) for i, s in enumerate(shapes)]
+    e = [q.detach().clone() for q in p]
+    opt = utils.FusedAdam([{"params": p[:2], "lr": 3e-6}, {"params": p[2:], "lr": 3e-5}], betas=(0.9, 0.999),
+                          weight_decay=0.0005)
+    cfg = ns(train=ns(total_iter=10, lr=3e-6, lr_scheduler=ns(type="Cosine")))
+    sc = build_scheduler(cfg, opt)
+    plan = K.EmaPlan(e, [q.data for q in p])
+    for step in range(3):
+        opt.zero_grad()
+        for i, q in enumerate(p):
+            q.grad = dev(synth.normal_f32(1300 + 10 * step + i, shapes[i]))
+        opt.step()
+        K.ema_update(plan, 0.999)
+        sc.step()
+        got_p = np.concatenate([q.detach().cpu().numpy().ravel() for q in p])
+        got_e = np.concatenate([k.cpu().numpy().ravel() for k in e])
+        assert np.allclose(got_p, g["p"][step], rtol=1e-6, atol=1e-9)
+        assert np.allclose(got_e, g["e"][step], rtol=1e-6, atol=1e-9)
+        assert np.allclose([opt.param_groups[0]["lr"], opt.param_groups[1]["lr"]], g["lr"][step], rtol=1e-9)
+
+
+def test_fused_adam_matches_torch_adam(K):
+    from hiast_amd.utils import utils
+    shapes = [(70001,), (64, 256, 3, 3), (19,), (5, 7)]
+    pa = [torch.nn.Parameter(dev(synth.normal_f32(1400 + i, s))) for i, s in enumerate(shapes)]
+    pb = [torch.nn.Parameter(q.detach().clone()) for q in pa]
+    oa = utils.FusedAdam([{"params": pa[:2], "lr": 3e-4}, {"params": pa[2:], "lr": 3e-3}], weight_decay=0.0005)
+    ob = torch.optim.Adam([{"params": pb[:2], "lr": 3e-4}, {"params": pb[2:], "lr": 3e-3}], weight_decay=0.0005)
+    for step in range(4):
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            gr = dev(synth.normal_f32(1500 + 10 * step + i, shapes[i]))
+            a.grad = None if (step == 1 and i == 3) else gr.clone()       # a parameter that skips a step
+            b.grad = None if (step == 1 and i == 3) else gr.clone()
+        oa.step()
+        ob.step()
+        for a, b in zip(pa, pb):
+            assert torch.allclose(a, b, rtol=2e-6, atol=1e-8)
+    sa, sb = oa.state_dict()["state"], ob.state_dict()["state"]
+    for k in sb:
+        assert float(sa[k]["step"]) == float(sb[k]["step"])
+        # (torch's foreach path forms m by lerp / mul+add in another association: a few ulps of the LARGER term)
+        assert torch.allclose(sa[k]["exp_avg"], sb[k]["exp_avg"], rtol=2e-6, atol=2e-7 * float(sb[k]["exp_avg"].abs().max()))
+        assert torch.allclose(sa[k]["exp_avg_sq"], sb[k]["exp_avg_sq"], rtol=2e-6,
+                              atol=2e-7 * float(sb[k]["exp_avg_sq"].abs().max()))
+
+
 def test_ema_bit_exact(K):
     shapes = [(7, 5), (70001,), (3, 2, 3, 3), (64, 2048, 1, 1)]
     e = [synth.normal_f32(70 + i, s) for i, s in enumerate(shapes)]
