@@ -8,7 +8,8 @@
 //
 //   stats      : Σx, Σx² per channel                   -> sums[C][2] (double)           (1 read)
 //   apply      : y = relu(x*scale_c + shift_c (+ res))                                   (1 read (+1), 1 write)
-//   bwd_stats  : g = dy * (y > 0);  Σg, Σ g*xhat       -> sums[C][2]
+//   bwd_stats  : g = dy * (y > 0);  Σg, Σ g*xhat       -> sums[C][2]   (the gate y > 0 is recomputed from x when the
+//                forward had no residual input: relu = 2, y is not read)
 //   bwd_apply  : dx = gamma*invstd*(g - Σg/n - xhat*Σ(g*xhat)/n);  dres = g
 // Partial sums: fp32 per thread (<= a few hundred rows), then double, reduced in a fixed order (no atomics: bitwise
 // reproducible).  Between stats and apply the caller may all-reduce sums[C][2] across ranks (SyncBN).
@@ -44,10 +45,14 @@ __device__ __forceinline__ void bnh_store8(unsigned short* p, const float (&v)[8
 // Thread t of a 256-thread block owns channel group cg = t % G (G = C/8, a power of two <= 256) and rows
 // r0 + (t / G) + k * RPP, RPP = 256 / G rows per pass.
 // BWD = false: (Σx, Σx²) of x;  BWD = true: (Σg, Σ g*xhat) with g = dy * (y > 0 | all).
-template <bool BWD, bool RELU>
+// GATE (ReLU gate of the backward passes): 0 = none, 1 = y > 0 (y is read), 2 = recomputed from x as
+// x*scale + shift > 0 — valid when the forward had no residual input, and saves reading y in both backward passes.
+template <bool BWD, int GATE>
 __global__ __launch_bounds__(256) void bnh_partial_kernel(const unsigned short* __restrict__ a,    // x | dy
                                                           const unsigned short* __restrict__ y,
                                                           const unsigned short* __restrict__ x,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta,
                                                           const float* __restrict__ save_mean,
                                                           const float* __restrict__ save_invstd, long long M, int C,
                                                           float* __restrict__ partial)          // [nblk][C][2]
@@ -55,12 +60,14 @@ __global__ __launch_bounds__(256) void bnh_partial_kernel(const unsigned short* 
     __shared__ float s_red[256 * 16];
     const int G = C >> 3, RPP = 256 / G;
     const int cg = threadIdx.x % G, rsub = threadIdx.x / G;
-    float s1[8], s2[8], mean[8], invstd[8];
+    float s1[8], s2[8], mean[8], invstd[8], gsc[8], gsh[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         s1[k] = 0.f; s2[k] = 0.f;
         mean[k] = BWD ? save_mean[cg * 8 + k] : 0.f;
         invstd[k] = BWD ? save_invstd[cg * 8 + k] : 0.f;
+        gsc[k] = GATE == 2 ? (gamma ? gamma[cg * 8 + k] : 1.0f) * invstd[k] : 0.f;
+        gsh[k] = GATE == 2 ? fmaf(-mean[k], gsc[k], beta ? beta[cg * 8 + k] : 0.0f) : 0.f;
     }
     for (long long r = (long long)blockIdx.x * RPP + rsub; r < M; r += (long long)gridDim.x * RPP) {
         const size_t off = (size_t)r * C + cg * 8;
@@ -71,11 +78,12 @@ __global__ __launch_bounds__(256) void bnh_partial_kernel(const unsigned short* 
             for (int k = 0; k < 8; ++k) { s1[k] += v[k]; s2[k] = fmaf(v[k], v[k], s2[k]); }
         } else {
             float yy[8], xx[8];
-            if (RELU) bnh_load8(y + off, yy);
+            if (GATE == 1) bnh_load8(y + off, yy);
             bnh_load8(x + off, xx);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const float g = (!RELU || yy[k] > 0.f) ? v[k] : 0.f;
+                const bool open = GATE == 0 || (GATE == 1 ? yy[k] > 0.f : fmaf(xx[k], gsc[k], gsh[k]) > 0.f);
+                const float g = open ? v[k] : 0.f;
                 s1[k] += g;
                 s2[k] = fmaf(g, (xx[k] - mean[k]) * invstd[k], s2[k]);
             }
@@ -179,16 +187,17 @@ __global__ __launch_bounds__(256) void bnh_apply_kernel(const unsigned short* __
     }
 }
 
-template <bool RELU, bool DRES>
+template <int GATE, bool DRES>
 __global__ __launch_bounds__(256) void bnh_bwd_apply_kernel(
     const unsigned short* __restrict__ dy, const unsigned short* __restrict__ y, const unsigned short* __restrict__ x,
-    const float* __restrict__ gamma, const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ save_mean,
+    const float* __restrict__ save_invstd,
     const double* __restrict__ sums, double inv_count, unsigned short* __restrict__ dx,
     unsigned short* __restrict__ dres, float* __restrict__ dgamma, float* __restrict__ dbeta, long long M, int C)
 {
     const int G = C >> 3, RPP = 256 / G;
     const int cg = threadIdx.x % G, rsub = threadIdx.x / G;
-    float mean[8], invstd[8], k0[8], mg[8], mgx[8];
+    float mean[8], invstd[8], k0[8], mg[8], mgx[8], gsh[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int c = cg * 8 + k;
@@ -200,6 +209,7 @@ __global__ __launch_bounds__(256) void bnh_bwd_apply_kernel(
         mean[k] = save_mean[c];
         invstd[k] = save_invstd[c];
         k0[k] = (gamma ? gamma[c] : 1.0f) * invstd[k];
+        gsh[k] = GATE == 2 ? fmaf(-mean[k], k0[k], beta ? beta[c] : 0.0f) : 0.f;
         mg[k] = (float)(s1 * inv_count);
         mgx[k] = (float)(s2 * inv_count);
     }
@@ -207,11 +217,12 @@ __global__ __launch_bounds__(256) void bnh_bwd_apply_kernel(
         const size_t off = (size_t)r * C + cg * 8;
         float g[8], yy[8], xx[8];
         bnh_load8(dy + off, g);
-        if (RELU) bnh_load8(y + off, yy);
+        if (GATE == 1) bnh_load8(y + off, yy);
         bnh_load8(x + off, xx);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const float gg = (!RELU || yy[k] > 0.f) ? g[k] : 0.f;
+            const bool open = GATE == 0 || (GATE == 1 ? yy[k] > 0.f : fmaf(xx[k], k0[k], gsh[k]) > 0.f);
+            const float gg = open ? g[k] : 0.f;
             g[k] = gg;
             xx[k] = k0[k] * (gg - mg[k] - (xx[k] - mean[k]) * invstd[k] * mgx[k]);
         }
@@ -249,8 +260,8 @@ extern "C" int hiast_bn_nhwc_stats(const void* x, int64_t M, int C, double* sums
     const int nblk = hiast::bnh_nblk(M, C);
     if (workspace_bytes < (size_t)nblk * C * 2 * sizeof(float)) return HIAST_E_WS;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL((hiast::bnh_partial_kernel<false, false>), dim3(nblk), dim3(256), 0, st,
-                       (const unsigned short*)x, nullptr, nullptr, nullptr, nullptr, (long long)M, C, (float*)workspace);
+    hipLaunchKernelGGL((hiast::bnh_partial_kernel<false, 0>), dim3(nblk), dim3(256), 0, st, (const unsigned short*)x,
+                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (long long)M, C, (float*)workspace);
     HIAST_CHECK_LAUNCH();
     hipLaunchKernelGGL(hiast::bnh_finalize_kernel, dim3(C * 2 / 16), dim3(256), 0, st, (const float*)workspace, nblk, C,
                        sums);
@@ -285,25 +296,24 @@ extern "C" int hiast_bn_nhwc_apply(const void* x, const void* res, void* y, cons
     return 0;
 }
 
-extern "C" int hiast_bn_nhwc_bwd_stats(const void* dy, const void* y, const void* x, const float* save_mean,
-                                       const float* save_invstd, int relu, int64_t M, int C, double* sums,
-                                       void* workspace, size_t workspace_bytes, hiast_stream_t stream)
+extern "C" int hiast_bn_nhwc_bwd_stats(const void* dy, const void* y, const void* x, const float* gamma,
+                                       const float* beta, const float* save_mean, const float* save_invstd, int relu,
+                                       int64_t M, int C, double* sums, void* workspace, size_t workspace_bytes,
+                                       hiast_stream_t stream)
 {
     int e = bnh_check(x, M, C);
     if (e) return e;
-    if (!dy || !save_mean || !save_invstd || !sums || !workspace || (relu && !y)) return HIAST_E_ARG;
-    if ((((uintptr_t)dy) | ((uintptr_t)y)) & 15) return HIAST_E_RANGE;
+    if (!dy || !save_mean || !save_invstd || !sums || !workspace || (relu == 1 && !y)) return HIAST_E_ARG;
+    if (relu < 0 || relu > 2 || ((((uintptr_t)dy) | ((uintptr_t)y)) & 15)) return HIAST_E_RANGE;
     const int nblk = hiast::bnh_nblk(M, C);
     if (workspace_bytes < (size_t)nblk * C * 2 * sizeof(float)) return HIAST_E_WS;
     hipStream_t st = (hipStream_t)stream;
-    if (relu)
-        hipLaunchKernelGGL((hiast::bnh_partial_kernel<true, true>), dim3(nblk), dim3(256), 0, st,
-                           (const unsigned short*)dy, (const unsigned short*)y, (const unsigned short*)x, save_mean,
-                           save_invstd, (long long)M, C, (float*)workspace);
-    else
-        hipLaunchKernelGGL((hiast::bnh_partial_kernel<true, false>), dim3(nblk), dim3(256), 0, st,
-                           (const unsigned short*)dy, (const unsigned short*)y, (const unsigned short*)x, save_mean,
-                           save_invstd, (long long)M, C, (float*)workspace);
+#define L(G)                                                                                                        \
+    hipLaunchKernelGGL((hiast::bnh_partial_kernel<true, G>), dim3(nblk), dim3(256), 0, st, (const unsigned short*)dy, \
+                       (const unsigned short*)y, (const unsigned short*)x, gamma, beta, save_mean, save_invstd,      \
+                       (long long)M, C, (float*)workspace)
+    if (relu == 1) L(1); else if (relu == 2) L(2); else L(0);
+#undef L
     HIAST_CHECK_LAUNCH();
     hipLaunchKernelGGL(hiast::bnh_finalize_kernel, dim3(C * 2 / 16), dim3(256), 0, st, (const float*)workspace, nblk, C,
                        sums);
@@ -312,25 +322,28 @@ extern "C" int hiast_bn_nhwc_bwd_stats(const void* dy, const void* y, const void
 }
 
 extern "C" int hiast_bn_nhwc_bwd_apply(const void* dy, const void* y, const void* x, const float* gamma,
-                                       const float* save_mean, const float* save_invstd, const double* sums,
+                                       const float* beta, const float* save_mean, const float* save_invstd,
+                                       const double* sums,
                                        double count, int relu, void* dx, void* dres, float* dgamma, float* dbeta,
                                        int64_t M, int C, hiast_stream_t stream)
 {
     int e = bnh_check(x, M, C);
     if (e) return e;
-    if (!dy || !save_mean || !save_invstd || !sums || !dx || (relu && !y) || count <= 0) return HIAST_E_ARG;
-    if ((((uintptr_t)dy) | ((uintptr_t)y) | ((uintptr_t)dx) | ((uintptr_t)dres)) & 15) return HIAST_E_RANGE;
+    if (!dy || !save_mean || !save_invstd || !sums || !dx || (relu == 1 && !y) || count <= 0) return HIAST_E_ARG;
+    if (relu < 0 || relu > 2 || ((((uintptr_t)dy) | ((uintptr_t)y) | ((uintptr_t)dx) | ((uintptr_t)dres)) & 15))
+        return HIAST_E_RANGE;
     const int rpp = 256 / (C / 8);
     long long nb = (M + (long long)rpp * 8 - 1) / ((long long)rpp * 8);
     nb = nb < 1 ? 1 : (nb > 2048 ? 2048 : nb);
     hipStream_t st = (hipStream_t)stream;
-#define L(RELU, DRES)                                                                                              \
-    hipLaunchKernelGGL((hiast::bnh_bwd_apply_kernel<RELU, DRES>), dim3((unsigned)nb), dim3(256), 0, st,             \
-                       (const unsigned short*)dy, (const unsigned short*)y, (const unsigned short*)x, gamma,        \
+#define L(G, DRES)                                                                                                 \
+    hipLaunchKernelGGL((hiast::bnh_bwd_apply_kernel<G, DRES>), dim3((unsigned)nb), dim3(256), 0, st,                \
+                       (const unsigned short*)dy, (const unsigned short*)y, (const unsigned short*)x, gamma, beta,  \
                        save_mean, save_invstd, sums, 1.0 / count, (unsigned short*)dx, (unsigned short*)dres, dgamma, \
                        dbeta, (long long)M, C)
-    if (relu) { if (dres) L(true, true); else L(true, false); }
-    else { if (dres) L(false, true); else L(false, false); }
+    if (relu == 1) { if (dres) L(1, true); else L(1, false); }
+    else if (relu == 2) { if (dres) L(2, true); else L(2, false); }
+    else { if (dres) L(0, true); else L(0, false); }
 #undef L
     HIAST_CHECK_LAUNCH();
     return 0;

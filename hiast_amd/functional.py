@@ -212,22 +212,24 @@ class _BnActNhwcFn(torch.autograd.Function):
             dist.all_reduce(sums)
             count *= world
         y, sm, si = K.bn_nhwc_apply(x, res, gamma, beta, running_mean, running_var, sums, count, momentum, eps, relu)
-        ctx.save_for_backward(x, y, gamma, sm, si)
-        ctx.relu, ctx.has_res, ctx.world, ctx.count = relu, res is not None, world, count
+        # ReLU gate of the backward: recomputed from x when there is no residual input (y is then not read again)
+        ctx.gate = 0 if not relu else (1 if res is not None else 2)
+        ctx.save_for_backward(x, y if ctx.gate == 1 else None, gamma, beta, sm, si)
+        ctx.has_res, ctx.world, ctx.count = res is not None, world, count
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, gamma, sm, si = ctx.saved_tensors
+        x, y, gamma, beta, sm, si = ctx.saved_tensors
         if dy.dtype != x.dtype:
             dy = dy.to(x.dtype)
         dy = dy.contiguous(memory_format=torch.channels_last)
-        sums = K.bn_nhwc_bwd_stats(dy, y, x, sm, si, ctx.relu)
+        sums = K.bn_nhwc_bwd_stats(dy, y, x, gamma, beta, sm, si, ctx.gate)
         if ctx.world > 1:
             import torch.distributed as dist
             dist.all_reduce(sums)
         want_p = gamma is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3])
-        dx, dres, dg, db = K.bn_nhwc_bwd_apply(dy, y, x, gamma, sm, si, sums, ctx.count, ctx.relu,
+        dx, dres, dg, db = K.bn_nhwc_bwd_apply(dy, y, x, gamma, beta, sm, si, sums, ctx.count, ctx.gate,
                                                ctx.has_res and ctx.needs_input_grad[1], want_p)
         return (dx, dres, dg if ctx.needs_input_grad[2] else None, db if ctx.needs_input_grad[3] else None,
                 None, None, None, None, None, None)

@@ -659,29 +659,30 @@ def bn_nhwc_apply(x, res, gamma, beta, running_mean, running_var, sums, count, m
     return y, sm, si
 
 
-def bn_nhwc_bwd_stats(dy, y, x, save_mean, save_invstd, relu):
+def bn_nhwc_bwd_stats(dy, y, x, gamma, beta, save_mean, save_invstd, gate):
+    """gate: 0 = no ReLU, 1 = y > 0 (reads y), 2 = recomputed from x (forward without residual; y unused)"""
     xv, M, C = _bnh_view(x, "x")
     dv, M2, C2 = _bnh_view(dy, "dy")
     assert (M2, C2) == (M, C)
-    yv = _bnh_view(y, "y")[0] if relu else None
+    yv = _bnh_view(y, "y")[0] if gate == 1 else None
     sums = torch.empty((C, 2), dtype=torch.float64, device=x.device)
     ws = _bnh_workspace(C, x.device)
-    check(_lib.load().hiast_bn_nhwc_bwd_stats(_ptr(dv), _ptr(yv), _ptr(xv), _ptr(save_mean), _ptr(save_invstd),
-                                              int(bool(relu)), M, C, _ptr(sums), _ptr(ws), ws.numel() * 4, _stream()),
-          "hiast_bn_nhwc_bwd_stats")
+    check(_lib.load().hiast_bn_nhwc_bwd_stats(_ptr(dv), _ptr(yv), _ptr(xv), _ptr(gamma), _ptr(beta), _ptr(save_mean),
+                                              _ptr(save_invstd), int(gate), M, C, _ptr(sums), _ptr(ws), ws.numel() * 4,
+                                              _stream()), "hiast_bn_nhwc_bwd_stats")
     return sums
 
 
-def bn_nhwc_bwd_apply(dy, y, x, gamma, save_mean, save_invstd, sums, count, relu, want_dres, want_dparam):
+def bn_nhwc_bwd_apply(dy, y, x, gamma, beta, save_mean, save_invstd, sums, count, gate, want_dres, want_dparam):
     xv, M, C = _bnh_view(x, "x")
     dv = _bnh_view(dy, "dy")[0]
-    yv = _bnh_view(y, "y")[0] if relu else None
+    yv = _bnh_view(y, "y")[0] if gate == 1 else None
     dx = torch.empty_like(x, memory_format=torch.channels_last)
     dres = torch.empty_like(x, memory_format=torch.channels_last) if want_dres else None
     dg = torch.empty(C, dtype=torch.float32, device=x.device) if want_dparam else None
     db = torch.empty(C, dtype=torch.float32, device=x.device) if want_dparam else None
-    check(_lib.load().hiast_bn_nhwc_bwd_apply(_ptr(dv), _ptr(yv), _ptr(xv), _ptr(gamma), _ptr(save_mean),
-                                              _ptr(save_invstd), _ptr(sums), float(count), int(bool(relu)), _ptr(dx),
+    check(_lib.load().hiast_bn_nhwc_bwd_apply(_ptr(dv), _ptr(yv), _ptr(xv), _ptr(gamma), _ptr(beta), _ptr(save_mean),
+                                              _ptr(save_invstd), _ptr(sums), float(count), int(gate), _ptr(dx),
                                               _ptr(dres), _ptr(dg), _ptr(db), M, C, _stream()),
           "hiast_bn_nhwc_bwd_apply")
     return dx, dres, dg, db

@@ -242,12 +242,14 @@ int hiast_bn_nhwc_apply(const void* x, const void* res, void* y, const float* ga
                         float* running_mean, float* running_var, const double* sums, double count, float momentum,
                         float eps, int relu, float* save_mean, float* save_invstd, int64_t M, int C,
                         hiast_stream_t stream);
-int hiast_bn_nhwc_bwd_stats(const void* dy, const void* y, const void* x, const float* save_mean,
-                            const float* save_invstd, int relu, int64_t M, int C, double* sums, void* workspace,
-                            size_t workspace_bytes, hiast_stream_t stream);
-int hiast_bn_nhwc_bwd_apply(const void* dy, const void* y, const void* x, const float* gamma, const float* save_mean,
-                            const float* save_invstd, const double* sums, double count, int relu, void* dx, void* dres,
-                            float* dgamma, float* dbeta, int64_t M, int C, hiast_stream_t stream);
+/* relu: 0 = no ReLU in the forward, 1 = gate y > 0 read from y, 2 = gate recomputed as x*scale + shift > 0 (only
+ * when the forward had NO residual input; y may be NULL and is not read) */
+int hiast_bn_nhwc_bwd_stats(const void* dy, const void* y, const void* x, const float* gamma, const float* beta,
+                            const float* save_mean, const float* save_invstd, int relu, int64_t M, int C, double* sums,
+                            void* workspace, size_t workspace_bytes, hiast_stream_t stream);
+int hiast_bn_nhwc_bwd_apply(const void* dy, const void* y, const void* x, const float* gamma, const float* beta,
+                            const float* save_mean, const float* save_invstd, const double* sums, double count, int relu,
+                            void* dx, void* dres, float* dgamma, float* dbeta, int64_t M, int C, hiast_stream_t stream);
 
 /* ---- K11: EMA teacher update ---------------------------------------------------------
  * utils/utils.py:115-123 update_ema_model: ema = ema*gamma + p*(1-gamma) over a list of
