@@ -100,7 +100,7 @@ class KernelTimer:
         def aspp_key(x, wpack, Cout, dil, workspace=None):
             return ("aspp_fwd", tuple(x.shape), Cout)
 
-        def ig_key(x, wp, planes, bn, res, relu, stride=1, dil=1, out_f32=False):
+        def ig_key(x, wp, planes, bn, res, relu, stride=1, dil=1, out_f32=False, want_stats=False):
             return ("igemm", tuple(x.shape), tuple(wp.shape), int(planes), int(stride), int(dil), res is not None,
                     bool(out_f32))
         self.wrap(K, "aspp_fwd", aspp_key)
@@ -110,7 +110,7 @@ class KernelTimer:
         out = []
         for key, pairs in self.groups.items():
             ms = [a.elapsed_time(b) for a, b in pairs]
-            out.append((key, float(np.mean(ms)), len(ms), float(np.sum(ms))))
+            out.append((key, float(np.mean(ms)), len(ms), float(np.sum(ms))))   # (launches are sampled: see main())
         return sorted(out, key=lambda t: -t[3])
 
 
@@ -325,19 +325,23 @@ def main():
         torch.cuda.synchronize()
     marker()
     timer.on = True
-    t_pl = t_tr = 0.0
+    # phases are timed with HIP events on the launch stream: no host synchronisation inside the timed region (the only
+    # blocking point is the histogram read-back the IAS threshold update needs), so consecutive steps pipeline
+    marks = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        a = time.perf_counter()
+    for it in range(args.steps):
+        timer.on = it % 3 == 0          # per-launch events cost ~5 us each (460 per step): sample every third step
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        e[0].record()
         plbl = hp.plabel_pass()
-        torch.cuda.synchronize()
-        b = time.perf_counter()
+        e[1].record()
         hp.train_step(plbl)
-        torch.cuda.synchronize()
-        t_pl += b - a
-        t_tr += time.perf_counter() - b
+        e[2].record()
+        marks.append(e)
     sync()
     elapsed = time.perf_counter() - t0
+    t_pl = sum(e[0].elapsed_time(e[1]) for e in marks) * 1e-3
+    t_tr = sum(e[1].elapsed_time(e[2]) for e in marks) * 1e-3
     timer.on = False
     marker()
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -364,9 +368,10 @@ def main():
         }
         groups = timer.summary()
         if groups:
+            sampled = len(range(0, args.steps, 3))      # steps on which launches were timed
             key, avg_ms, n, _tot = groups[0]            # dominant hand-written launch group of the step
-            out["roofline"] = roofline_of(key, avg_ms, n, args.steps)
-            others = [roofline_of(k, a, c, args.steps) for k, a, c, _ in groups[1:4]]
+            out["roofline"] = roofline_of(key, avg_ms, n, sampled)
+            others = [roofline_of(k, a, c, sampled) for k, a, c, _ in groups[1:4]]
             out["roofline_other"] = [{kk: o[kk] for kk in ("kernel", "bound", "achieved", "peak", "unit", "frac",
                                                             "traffic", "avg_launch_ms", "launches_per_step", "note")}
                                      for o in others]

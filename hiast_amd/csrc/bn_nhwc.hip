@@ -269,6 +269,19 @@ extern "C" int hiast_bn_nhwc_stats(const void* x, int64_t M, int C, double* sums
     return 0;
 }
 
+// sums from per-block partials produced elsewhere (the statistics epilogue of hiast_igemm_bn_act): [nblk][C][2] fp32
+extern "C" int hiast_bn_nhwc_stats_from_partial(const float* partial, int nblk, int C, double* sums,
+                                                hiast_stream_t stream)
+{
+    if (!partial || !sums) return HIAST_E_ARG;
+    if (nblk <= 0 || C <= 0) return HIAST_E_ARG;
+    if (C % 8 != 0) return HIAST_E_RANGE;
+    hipLaunchKernelGGL(hiast::bnh_finalize_kernel, dim3(C * 2 / 16), dim3(256), 0, (hipStream_t)stream, partial, nblk, C,
+                       sums);
+    HIAST_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int hiast_bn_nhwc_apply(const void* x, const void* res, void* y, const float* gamma, const float* beta,
                                    float* running_mean, float* running_var, const double* sums, double count,
                                    float momentum, float eps, int relu, float* save_mean, float* save_invstd,

@@ -76,7 +76,8 @@ template <int PL, bool OUTF32, int BN, int TAPS, bool RES, bool RELU>
 __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
     const unsigned short* __restrict__ X, const unsigned short* __restrict__ Wp, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ var, float eps,
-    const unsigned short* __restrict__ R, void* __restrict__ Yv, int M, int K, int N, IGeo geo, int dbg)
+    const unsigned short* __restrict__ R, void* __restrict__ Yv, int M, int K, int N, IGeo geo, int dbg,
+    float* __restrict__ stats)           // optional [gridDim m-blocks][N][2]: per-block Σy, Σy² of the STORED values
 {
     constexpr int WN = BN / 64, WM = 8 / WN;
     constexpr int TM = IG_BM / WM / 32;                 // 32-row tiles per wave (4 | 2 | 1)
@@ -246,6 +247,9 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
     }
     const int erow = lane >> 3, ec8 = lane & 7;
     const int nc = n0 + wn * 64 + ec8 * 8;
+    float st1[8], st2[8];                               // BatchNorm statistics of this lane's 8 channels (if asked for)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { st1[q] = 0.f; st2[q] = 0.f; }
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
         // residual rows of this 32-row chunk: all 4 passes' loads are issued BEFORE the LDS round trip, so their
@@ -313,6 +317,11 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
                         ig_split(o[2 * q + 1], h1, l1);
                         ph[q] = (unsigned)h0 | ((unsigned)h1 << 16);
                         pl_[q] = (unsigned)l0 | ((unsigned)l1 << 16);
+                        if (PL == 1 && stats) {          // statistics of what is stored (the bf16 roundings)
+                            const float v0 = __uint_as_float((unsigned)h0 << 16), v1 = __uint_as_float((unsigned)h1 << 16);
+                            st1[2 * q] += v0; st2[2 * q] = fmaf(v0, v0, st2[2 * q]);
+                            st1[2 * q + 1] += v1; st2[2 * q + 1] = fmaf(v1, v1, st2[2 * q + 1]);
+                        }
                     }
                     *reinterpret_cast<uint4*>(Y) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
                     if (PL == 2) *reinterpret_cast<uint4*>(Y + 32) = make_uint4(pl_[0], pl_[1], pl_[2], pl_[3]);
@@ -322,6 +331,36 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (PL == 1 && !OUTF32 && stats) {
+        // fold the 8 row-lanes of each channel group (lane bits 3..5), then the WM waves that share these columns
+        // (fixed order), and store this block's partial sums: the BN forward then needs no pass over Y for them
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+#pragma unroll
+            for (int o = 8; o < 64; o <<= 1) {
+                st1[q] += __shfl_xor(st1[q], o, 64);
+                st2[q] += __shfl_xor(st2[q], o, 64);
+            }
+        }
+        __syncthreads();                                // the private epilogue tiles are free now
+        float* sS = reinterpret_cast<float*>(smem);     // [8 waves][64 channels][2]
+        if (erow == 0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                sS[(wave * 64 + ec8 * 8 + q) * 2] = st1[q];
+                sS[(wave * 64 + ec8 * 8 + q) * 2 + 1] = st2[q];
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < BN * 2; e += 512) {
+            const int c = e >> 1, which = e & 1;        // column of the block tile
+            const int wnc = c >> 6, cl = c & 63;
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) t += sS[((w * WN + wnc) * 64 + cl) * 2 + which];
+            stats[((size_t)bm * N + n0 + c) * 2 + which] = t;
+        }
     }
 }
 
@@ -405,7 +444,7 @@ __global__ __launch_bounds__(256) void from_planes_kernel(const unsigned short* 
 template <int PL, bool OUTF32>
 static int launch_igemm_t(const void* x, const void* wp, const float* gamma, const float* beta, const float* mean,
                           const float* var, float eps, const void* res, int relu, void* y, int64_t M, int K, int N,
-                          int taps, hiast::IGeo geo, hipStream_t st)
+                          int taps, hiast::IGeo geo, float* stats, hipStream_t st)
 {
     int dbg = 0;
     if (const char* env = getenv("HIAST_IGEMM_DEBUG")) dbg = atoi(env);
@@ -418,7 +457,7 @@ static int launch_igemm_t(const void* x, const void* wp, const float* gamma, con
 #define L(BNV, T, RES, RELU)                                                                                         \
     hipLaunchKernelGGL((hiast::igemm_bn_act_kernel<PL, OUTF32, BNV, T, RES, RELU>), grid, dim3(512), 0, st,           \
                        (const unsigned short*)x, (const unsigned short*)wp, gamma, beta, mean, var, eps,              \
-                       (const unsigned short*)res, y, (int)M, K, N, geo, dbg)
+                       (const unsigned short*)res, y, (int)M, K, N, geo, dbg, stats)
 #define LL(BNV, T)                                                              \
     if (res) { if (relu) L(BNV, T, true, true); else L(BNV, T, true, false); }  \
     else { if (relu) L(BNV, T, false, true); else L(BNV, T, false, false); }
@@ -433,8 +472,10 @@ static int launch_igemm_t(const void* x, const void* wp, const float* gamma, con
 // shared launcher (also used by aspp2.hip for the ASPP tap GEMM)
 int hiast_igemm_launch(const void* x, const void* wp, const float* gamma, const float* beta, const float* mean,
                        const float* var, float eps, const void* res, int relu, void* y, int64_t M, int K, int N,
-                       int taps, int H, int W, int stride, int dil, int planes, int out_f32, hipStream_t st)
+                       int taps, int H, int W, int stride, int dil, int planes, int out_f32, hipStream_t st,
+                       float* stats)
 {
+    if (stats && (planes != 1 || out_f32)) return HIAST_E_RANGE;
     if (!x || !wp || !y || (mean && !var)) return HIAST_E_ARG;
     if (M <= 0 || K <= 0 || N <= 0) return HIAST_E_ARG;
     if ((planes != 1 && planes != 2) || (taps != 1 && taps != 9)) return HIAST_E_RANGE;
@@ -453,23 +494,23 @@ int hiast_igemm_launch(const void* x, const void* wp, const float* gamma, const 
     // buffer-descriptor addressing: byte offsets and the out-of-range marker need 31 bits
     if (in_pix * planes * K * 2 >= (1ull << 31) || (size_t)N * taps * planes * K * 2 >= (1ull << 31)) return HIAST_E_RANGE;
     if (planes == 2) {
-        if (out_f32) return launch_igemm_t<2, true>(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, st);
-        return launch_igemm_t<2, false>(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, st);
+        if (out_f32) return launch_igemm_t<2, true>(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, stats, st);
+        return launch_igemm_t<2, false>(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, stats, st);
     }
-    if (out_f32) return launch_igemm_t<1, true>(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, st);
-    return launch_igemm_t<1, false>(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, st);
+    if (out_f32) return launch_igemm_t<1, true>(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, stats, st);
+    return launch_igemm_t<1, false>(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, stats, st);
 }
 
 extern "C" int hiast_igemm_bn_act(const void* x, const void* wp, const float* gamma, const float* beta,
                                   const float* mean, const float* var, float eps, const void* res, int relu, void* y,
                                   int B, int H, int W, int Cin, int Cout, int taps, int stride, int dil, int planes,
-                                  int out_f32, hiast_stream_t stream)
+                                  int out_f32, float* stats, hiast_stream_t stream)
 {
     if (B <= 0 || H <= 0 || W <= 0) return HIAST_E_ARG;
     if (taps == 1 && stride != 1) return HIAST_E_RANGE;       // strided 1x1: subsample the input first
     const int Ho = taps == 1 ? H : (H - 1) / stride + 1, Wo = taps == 1 ? W : (W - 1) / stride + 1;
     return hiast_igemm_launch(x, wp, gamma, beta, mean, var, eps, res, relu, y, (int64_t)B * Ho * Wo, Cin, Cout, taps, H,
-                              W, stride, dil, planes, out_f32, (hipStream_t)stream);
+                              W, stride, dil, planes, out_f32, (hipStream_t)stream, stats);
 }
 
 extern "C" int hiast_pack_conv_weight(const float* w, int N, int K, int taps, int planes, int transpose, void* wp,

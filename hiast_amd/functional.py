@@ -204,8 +204,9 @@ class _BnActNhwcFn(torch.autograd.Function):
     kernels, so the student forward / backward needs no NCHW<->NHWC transposes."""
 
     @staticmethod
-    def forward(ctx, x, res, gamma, beta, running_mean, running_var, momentum, eps, relu, world):
-        sums = K.bn_nhwc_stats(x)
+    def forward(ctx, x, res, gamma, beta, running_mean, running_var, momentum, eps, relu, world, partial):
+        # batch statistics: from the producing convolution's epilogue when it delivered them, else one pass over x
+        sums = K.bn_nhwc_stats_from_partial(partial) if partial is not None else K.bn_nhwc_stats(x)
         count = float(x.shape[0] * x.shape[2] * x.shape[3])
         if world > 1:      # SyncBN: one all-reduce of [C,2] double sums
             import torch.distributed as dist
@@ -232,7 +233,7 @@ class _BnActNhwcFn(torch.autograd.Function):
         dx, dres, dg, db = K.bn_nhwc_bwd_apply(dy, y, x, gamma, beta, sm, si, sums, ctx.count, ctx.gate,
                                                ctx.has_res and ctx.needs_input_grad[1], want_p)
         return (dx, dres, dg if ctx.needs_input_grad[2] else None, db if ctx.needs_input_grad[3] else None,
-                None, None, None, None, None, None)
+                None, None, None, None, None, None, None)
 
 
 class _ConvNhwcFn(torch.autograd.Function):
@@ -244,17 +245,20 @@ class _ConvNhwcFn(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
-    def forward(ctx, x, weight, stride, dil):
+    def forward(ctx, x, weight, stride, dil, want_stats):
         xv = x.permute(0, 2, 3, 1)
         wp = K.pack_conv_weight(weight, 1)
-        y = K.igemm_bn_act(xv, wp, 1, None, None, False, stride, dil)
         ctx.save_for_backward(x, weight)
         ctx.geo = (stride, dil)
-        return y.permute(0, 3, 1, 2)
+        if want_stats:       # + per-block Σy, Σy² of the stored outputs for the BatchNorm that follows
+            y, partial = K.igemm_bn_act(xv, wp, 1, None, None, False, stride, dil, want_stats=True)
+            ctx.mark_non_differentiable(partial)
+            return y.permute(0, 3, 1, 2), partial
+        return K.igemm_bn_act(xv, wp, 1, None, None, False, stride, dil).permute(0, 3, 1, 2)
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dpartial=None):
         x, weight = ctx.saved_tensors
         stride, dil = ctx.geo
         if dy.dtype != torch.bfloat16:
@@ -279,7 +283,7 @@ class _ConvNhwcFn(torch.autograd.Function):
             if need_w:
                 # fp32, NCHW-contiguous like the parameter (DDP's gradient-layout contract): one cast+layout kernel
                 dw = gw.to(dtype=weight.dtype, memory_format=torch.contiguous_format)
-        return dx, dw, None, None
+        return dx, dw, None, None, None
 
 
 def conv_nhwc_ok(x, conv):
@@ -295,11 +299,12 @@ def conv_nhwc_ok(x, conv):
     return conv.padding == conv.dilation and conv.dilation[0] == conv.dilation[1] and conv.stride[0] in (1, 2)
 
 
-def conv_nhwc(x, conv):
-    return _ConvNhwcFn.apply(x, conv.weight, conv.stride[0], conv.dilation[0])
+def conv_nhwc(x, conv, want_stats=False):
+    """-> y, or (y, partial) with want_stats (see igemm_bn_act)"""
+    return _ConvNhwcFn.apply(x, conv.weight, conv.stride[0], conv.dilation[0], bool(want_stats))
 
 
-def bn_act(x, bn, res=None, relu=True):
+def bn_act(x, bn, res=None, relu=True, partial=None):
     """Fused replacement of `relu(bn(x) [+ res])` for a torch BatchNorm2d / SyncBatchNorm module `bn`
     (which keeps owning the parameters and running statistics)."""
     training = bn.training or (bn.running_mean is None)
@@ -309,6 +314,6 @@ def bn_act(x, bn, res=None, relu=True):
     if (training and x.dtype == torch.bfloat16 and _is_cl(x) and not x.is_contiguous()
             and K.bn_nhwc_supported(x.shape[1]) and (res is None or (res.dtype == x.dtype and _is_cl(res)))):
         return _BnActNhwcFn.apply(x, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, momentum, bn.eps, relu,
-                                  _sync_world(bn))
+                                  _sync_world(bn), partial)
     return _BnActFn.apply(x, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum,
                           bn.eps, relu, _sync_world(bn) if training else 1)

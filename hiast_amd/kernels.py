@@ -567,10 +567,11 @@ def pack_conv_weight(weight, planes, transpose=False):
     return wp
 
 
-def igemm_bn_act(x, wp, planes, bn, res, relu, stride=1, dil=1, out_f32=False):
+def igemm_bn_act(x, wp, planes, bn, res, relu, stride=1, dil=1, out_f32=False, want_stats=False):
     """x: bf16 [B,H,W,planes*Cin] (planes = 2 split planes | 1 plain bf16); wp from pack_conv_weight (same planes);
     bn: BatchNorm2d in eval mode or None (plain GEMM); res: like the output or None
-    -> y bf16 [B,Ho,Wo,planes*Cout], or fp32 [B,Ho,Wo,Cout] if out_f32"""
+    -> y bf16 [B,Ho,Wo,planes*Cout], or fp32 [B,Ho,Wo,Cout] if out_f32;
+    want_stats (planes = 1): -> (y, partial fp32 [ceil(M/256), Cout, 2]) per-block Σy, Σy² for a following BatchNorm"""
     _req(x, torch.bfloat16, 4, "x")
     _req(wp, torch.bfloat16, 3, "wp")
     PL = int(planes)
@@ -596,10 +597,14 @@ def igemm_bn_act(x, wp, planes, bn, res, relu, stride=1, dil=1, out_f32=False):
     else:
         g = b = mu = var = ctypes.c_void_p(0)
         eps = 0.0
+    partial = None
+    if want_stats:
+        assert PL == 1 and not out_f32
+        partial = torch.empty(((B * Ho * Wo + 255) // 256, N, 2), dtype=torch.float32, device=x.device)
     check(_lib.load().hiast_igemm_bn_act(_ptr(x), _ptr(wp), g, b, mu, var, eps, _ptr(res), int(bool(relu)), _ptr(y),
                                          B, H, W, Cin, N, taps, int(stride), int(dil), PL, int(bool(out_f32)),
-                                         _stream()), "hiast_igemm_bn_act")
-    return y
+                                         _ptr(partial), _stream()), "hiast_igemm_bn_act")
+    return (y, partial) if want_stats else y
 
 
 # ------------------------------------------------------------------------------- K10b BN (train) on channels-last bf16
@@ -640,6 +645,17 @@ def bn_nhwc_stats(x):
     ws = _bnh_workspace(C, x.device)
     check(_lib.load().hiast_bn_nhwc_stats(_ptr(xv), M, C, _ptr(sums), _ptr(ws), ws.numel() * 4, _stream()),
           "hiast_bn_nhwc_stats")
+    return sums
+
+
+def bn_nhwc_stats_from_partial(partial):
+    """per-block partial sums [nblk,C,2] fp32 (igemm_bn_act(..., want_stats=True)) -> sums f64 [C,2]"""
+    _req(partial, torch.float32, 3, "partial")
+    nblk, C, two = partial.shape
+    assert two == 2
+    sums = torch.empty((C, 2), dtype=torch.float64, device=partial.device)
+    check(_lib.load().hiast_bn_nhwc_stats_from_partial(_ptr(partial), nblk, C, _ptr(sums), _stream()),
+          "hiast_bn_nhwc_stats_from_partial")
     return sums
 
 

@@ -31,6 +31,15 @@ def conv(m, x):
     return m(x)
 
 
+def conv_bn_act(cv, bn, x, res=None, relu=True):
+    """relu?(bn(conv(x)) [+ res]).  On the channels-last bf16 training path the convolution's epilogue also
+    delivers the per-block sums the BatchNorm needs (one pass over the activation less)."""
+    if x.is_cuda and x.dtype == torch.bfloat16 and bn.training and HF.conv_nhwc_ok(x, cv):
+        y, partial = HF.conv_nhwc(x, cv, want_stats=True)
+        return HF.bn_act(y, bn, res, relu, partial=partial)
+    return bn_act(bn, conv(cv, x), res, relu)
+
+
 def _nhwc2d(t):
     """logical NCHW tensor with channels-last strides -> zero-copy [B*H*W, C] view"""
     B, C, H, W = t.shape
@@ -71,10 +80,10 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        idt = x if self.downsample is None else bn_act(self.downsample[1], conv(self.downsample[0], x), relu=False)
-        o = bn_act(self.bn1, conv(self.conv1, x))
-        o = bn_act(self.bn2, conv(self.conv2, o))
-        return bn_act(self.bn3, conv(self.conv3, o), res=idt)        # += identity, ReLU
+        idt = x if self.downsample is None else conv_bn_act(self.downsample[0], self.downsample[1], x, relu=False)
+        o = conv_bn_act(self.conv1, self.bn1, x)
+        o = conv_bn_act(self.conv2, self.bn2, o)
+        return conv_bn_act(self.conv3, self.bn3, o, res=idt)        # += identity, ReLU
 
     def forward_eval_planes(self, x, PL):
         """inference on channels-last 16-bit activations [B,H,W,PL*C] (PL = 2: split planes, fp32-class — the

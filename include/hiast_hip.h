@@ -222,10 +222,14 @@ int hiast_bn_act_nhwc_infer(const void* x, void* y, const float* gamma, const fl
  * with it is the data gradient of a stride-1 convolution — autograd of nn.Conv2d in resnet.py:78-98).
  * taps = 9: padding = dilation, stride 1 | 2.  out_f32 = 1: y is fp32 [B,Ho,Wo,Cout] (no residual).  mean == NULL: no
  * BatchNorm (plain GEMM).  Cin % 32 == 0, Cout % 64 == 0, every tensor < 2 GiB, 16-byte aligned.
- * hiast_split_planes: fp32 [M][C] <-> planes [M][2][C] (inverse = 1: x is written; hi + lo is exact in fp32). */
+ * hiast_split_planes: fp32 [M][C] <-> planes [M][2][C] (inverse = 1: x is written; hi + lo is exact in fp32).
+ * stats (planes = 1, 16-bit output only; may be NULL): [ceil(B*Ho*Wo/256)][Cout][2] fp32, per 256-row block the sums
+ * Σy and Σy² of the stored (bf16) outputs — the BatchNorm batch statistics of the training forward come out of the
+ * convolution's epilogue (hiast_bn_nhwc_stats_from_partial reduces them) instead of another pass over y. */
 int hiast_igemm_bn_act(const void* x, const void* wp, const float* gamma, const float* beta, const float* mean,
                        const float* var, float eps, const void* res, int relu, void* y, int B, int H, int W, int Cin,
-                       int Cout, int taps, int stride, int dil, int planes, int out_f32, hiast_stream_t stream);
+                       int Cout, int taps, int stride, int dil, int planes, int out_f32, float* stats,
+                       hiast_stream_t stream);
 int hiast_pack_conv_weight(const float* w, int N, int K, int taps, int planes, int transpose, void* wp,
                            hiast_stream_t stream);
 int hiast_split_planes(float* x, void* planes, int64_t M, int C, int inverse, hiast_stream_t stream);
@@ -238,6 +242,7 @@ int hiast_split_planes(float* x, void* planes, int64_t M, int C, int inverse, hi
 size_t hiast_bn_nhwc_workspace_bytes(int C);
 int hiast_bn_nhwc_stats(const void* x, int64_t M, int C, double* sums, void* workspace, size_t workspace_bytes,
                         hiast_stream_t stream);
+int hiast_bn_nhwc_stats_from_partial(const float* partial, int nblk, int C, double* sums, hiast_stream_t stream);
 int hiast_bn_nhwc_apply(const void* x, const void* res, void* y, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, const double* sums, double count, float momentum,
                         float eps, int relu, float* save_mean, float* save_invstd, int64_t M, int C,

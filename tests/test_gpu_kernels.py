@@ -548,6 +548,20 @@ def test_conv_nhwc_autograd_vs_fp64(K, cfg):
     assert ((xt.grad.double().cpu() - xd.grad).abs() <= tol(xd.grad)).all()
     assert conv.weight.grad.dtype == torch.float32
     assert ((conv.weight.grad.double().cpu() - wd.grad).abs() <= tol(wd.grad)).all()
+    # statistics epilogue: per-256-row-block sums of the STORED outputs, and the BN forward fed by them
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y2, partial = HF.conv_nhwc(xt.detach(), conv, want_stats=True)
+    assert torch.equal(y2, y.detach())
+    yf = y2.float().permute(0, 2, 3, 1).reshape(-1, Cout).double()
+    nb = (yf.shape[0] + 255) // 256
+    assert tuple(partial.shape) == (nb, Cout, 2)
+    for b in range(nb):
+        blk = yf[b * 256:(b + 1) * 256]
+        assert torch.allclose(partial[b, :, 0].double(), blk.sum(0), rtol=1e-4, atol=1e-3)
+        assert torch.allclose(partial[b, :, 1].double(), (blk * blk).sum(0), rtol=1e-4, atol=1e-3)
+    s_ep = K.bn_nhwc_stats_from_partial(partial)
+    s_pass = K.bn_nhwc_stats(y2)
+    assert torch.allclose(s_ep, s_pass, rtol=1e-5, atol=1e-3)
 
 
 def test_training_trunk_channels_last_as_accurate_as_nchw_path(K):
