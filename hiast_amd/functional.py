@@ -3,6 +3,8 @@
 CUDA(HIP) tensors only.  Autocast: inputs are taken in fp32 (the reference's losses and the
 pseudo-label path are fp32 even under apex O1; the ASPP head is computed in exact fp32 MFMA).
 """
+import os
+
 import torch
 
 from . import kernels as K
@@ -272,6 +274,11 @@ class _ConvNhwcFn(torch.autograd.Function):
         if need_x and stride == 1:
             wpt = K.pack_conv_weight(weight, 1, transpose=True)
             dx = K.igemm_bn_act(dy.permute(0, 2, 3, 1), wpt, 1, None, None, False, 1, dil).permute(0, 3, 1, 2)
+        own_w = need_w and os.environ.get("HIAST_LIB_WGRAD", "0") != "1" and K.conv_wgrad_preferred(
+            weight.shape[1], weight.shape[0], k, stride)
+        if own_w:            # transposed-read GEMM over the pixel index (hiast_conv_wgrad_nhwc)
+            dw = K.conv_wgrad_nhwc(dy.permute(0, 2, 3, 1), x.permute(0, 2, 3, 1), k, stride, dil)
+            need_w = False
         if need_w or lib_x:
             wl = torch.empty(weight.shape, dtype=torch.bfloat16, device=weight.device)
             if lib_x:
@@ -280,7 +287,7 @@ class _ConvNhwcFn(torch.autograd.Function):
                                                             False, (0, 0), 1, (lib_x, need_w, False))
             if lib_x:
                 dx = gx
-            if need_w:
+            if need_w and not own_w:
                 # fp32, NCHW-contiguous like the parameter (DDP's gradient-layout contract): one cast+layout kernel
                 dw = gw.to(dtype=weight.dtype, memory_format=torch.contiguous_format)
         return dx, dw, None, None, None

@@ -234,6 +234,16 @@ int hiast_pack_conv_weight(const float* w, int N, int K, int taps, int planes, i
                            hiast_stream_t stream);
 int hiast_split_planes(float* x, void* planes, int64_t M, int C, int inverse, hiast_stream_t stream);
 
+/* ---- K9d: weight gradient of the trunk convolutions on channels-last bf16 activations -------------------------
+ * autograd of nn.Conv2d in Bottleneck.forward (resnet.py:78-98) under mixed precision:
+ *   dW[n][k][tap] = Σ_m dy[m][n] * x[m + off(tap)][k], bf16 operands, fp32 accumulation, fp32 result in torch's
+ *   [Cout][Cin][kh][kw] layout.  dy [B,Ho,Wo,Cout], x [B,H,W,Cin] bf16; taps = 1 | 9 (padding = dilation, stride 1|2).
+ * Cin % 256 == 0 and Cout % 256 == 0 (layer3 / layer4 of the trunk: 91 % of its FLOPs).  Pixel ranges are reduced in
+ * a fixed order (bitwise reproducible).  workspace: hiast_conv_wgrad_workspace_bytes(...) (0 = unsupported shape). */
+size_t hiast_conv_wgrad_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout, int taps);
+int hiast_conv_wgrad_nhwc(const void* dy, const void* x, float* dw, int B, int H, int W, int Cin, int Cout, int taps,
+                          int stride, int dil, void* workspace, size_t workspace_bytes, hiast_stream_t stream);
+
 /* ---- K10b: BatchNorm2d (+ residual) (+ ReLU), TRAINING mode, on channels-last bf16 activations [M = B*H*W][C] ------
  * Same arithmetic and passes as K10 (resnet.py:78-98 in train(): batch statistics even with frozen affine
  * parameters, utils/utils.py:60-65) in the layout the convolution kernels of K9c produce / consume.

@@ -523,10 +523,13 @@ def test_bn_nhwc_matches_fp64(K, shape, res, relu):
 
 
 @pytest.mark.parametrize("cfg", [(2, 64, 64, 10, 18, 1, 1, 1), (1, 256, 128, 12, 20, 3, 1, 2), (2, 128, 128, 16, 16, 3, 2, 1),
-                                 (1, 512, 256, 9, 11, 3, 1, 4), (1, 1024, 256, 8, 8, 1, 1, 1)])
-def test_conv_nhwc_autograd_vs_fp64(K, cfg):
-    """_ConvNhwcFn (igemm forward / data gradient, library weight gradient) vs float64 autograd on bf16-rounded data"""
+                                 (1, 512, 256, 9, 11, 3, 1, 4), (1, 1024, 256, 8, 8, 1, 1, 1),
+                                 (2, 256, 256, 16, 16, 3, 2, 1), (2, 256, 512, 20, 33, 3, 1, 2), (3, 256, 1024, 33, 21, 1, 1, 1)])
+def test_conv_nhwc_autograd_vs_fp64(K, cfg, monkeypatch):
+    """_ConvNhwcFn (igemm forward / data gradient; weight gradient by hiast_conv_wgrad_nhwc where the shape allows,
+    else by the library) vs float64 autograd on bf16-rounded data"""
     from hiast_amd import functional as HF
+    monkeypatch.setenv("HIAST_OWN_WGRAD3", "1")          # exercise the 3x3 form of the own weight-gradient kernel too
     B, Cin, Cout, H, W, k, stride, dil = cfg
     conv = torch.nn.Conv2d(Cin, Cout, k, stride=stride, padding=dil if k == 3 else 0, dilation=dil if k == 3 else 1,
                            bias=False).cuda()

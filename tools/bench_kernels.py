@@ -104,6 +104,21 @@ def main():
             med, best = timeit(lambda: torch.nn.functional.conv2d(xn, wb, None, 1, dl if taps == 9 else 0, dl), n=20, warm=5)
             row += " miopen bf16 conv only %7.3f ms" % med
             print(row, flush=True)
+    if "wgrad" in which:
+        Bn, Hh, Ww = B, 64, 128
+        for name, Cin_, Cout_, k, dl in (("l3.conv1", 1024, 256, 1, 1), ("l3.conv2", 256, 256, 3, 2), ("l3.conv3", 256, 1024, 1, 1),
+                                        ("l4.conv1", 2048, 512, 1, 1), ("l4.conv2", 512, 512, 3, 4), ("l4.conv3", 512, 2048, 1, 1)):
+            x = torch.randn(Bn, Hh, Ww, Cin_, device=dev).bfloat16()
+            dy = torch.randn(Bn, Hh, Ww, Cout_, device=dev).bfloat16()
+            gf = 2.0 * Bn * Hh * Ww * Cin_ * Cout_ * k * k / 1e9
+            med, best = timeit(lambda: K.conv_wgrad_nhwc(dy, x, k, 1, dl), n=10, warm=3)
+            xl, dyl = x.permute(0, 3, 1, 2), dy.permute(0, 3, 1, 2)
+            wl = torch.empty(Cout_, Cin_, k, k, device=dev, dtype=torch.bfloat16)
+            pad = dl if k == 3 else 0
+            med2, _ = timeit(lambda: torch.ops.aten.convolution_backward(dyl, xl, wl, None, (1, 1), (pad, pad), (dl, dl), False,
+                                                                         (0, 0), 1, (False, True, False)), n=10, warm=3)
+            print("wgrad %-9s %6.1f GFLOP | own %7.3f ms %5.0f TF/s | miopen %7.3f ms %5.0f TF/s" %
+                  (name, gf, med, gf / med, med2, gf / med2), flush=True)
     if "plabel" in which:
         z = torch.randn(B, C, h, w, device=dev) * 3
         med, best = timeit(lambda: K.plabel_pass1(z, H, W))
