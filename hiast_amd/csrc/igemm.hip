@@ -368,28 +368,38 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
 // transpose: pack the weight of the ADJOINT convolution instead (the data-gradient of a stride-1 conv is a conv of
 // dY with the channel-transposed, spatially flipped kernel): Wp[k][taps-1-t][.. n ..] = w[n][k][t]; the output then
 // has N_out = K rows and K_out = N reduction channels.
+// element offset of (row n, tap t, reduction channel k) in a packed weight with KO reduction channels
+template <int PL>
+__device__ __forceinline__ size_t ig_wp_elem(int n, int t, int k, int taps, int KO)
+{
+    const size_t row = ((size_t)n * taps + t) * PL * KO;
+    return PL == 2 ? row + (size_t)(k >> 5) * 64 + (k & 31) : row + k;      // lo plane: + 32
+}
+
+// mode 0: wp = forward weight; 1: wp = adjoint weight; 2: wp = forward, wpt = adjoint (one pass over w)
 template <int PL>
 __global__ __launch_bounds__(256) void pack_conv_weight_kernel(const float* __restrict__ w,
-                                                               unsigned short* __restrict__ wp, int N, int K, int taps,
-                                                               int transpose)
+                                                               unsigned short* __restrict__ wp,
+                                                               unsigned short* __restrict__ wpt, int N, int K, int taps,
+                                                               int mode)
 {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long long)N * taps * K) return;
-    const int NO = transpose ? K : N, KO = transpose ? N : K;       // rows / reduction length of the packed matrix
-    const int k = (int)(idx % KO);
-    const int t = (int)((idx / KO) % taps);
-    const int n = (int)(idx / ((long long)KO * taps));
-    (void)NO;
-    const float v = transpose ? w[((size_t)k * K + n) * taps + (taps - 1 - t)] : w[((size_t)n * K + k) * taps + t];
+    const int k = (int)(idx % K);
+    const int t = (int)((idx / K) % taps);
+    const int n = (int)(idx / ((long long)K * taps));
+    const float v = w[((size_t)n * K + k) * taps + t];
     unsigned short h, l;
     ig_split(v, h, l);
-    unsigned short* row = wp + ((size_t)n * taps + t) * PL * KO;
-    if (PL == 2) {
-        unsigned short* dst = row + (size_t)(k >> 5) * 64 + (k & 31);
-        dst[0] = h;
-        dst[32] = l;
-    } else {
-        row[k] = h;
+    if (mode != 1) {
+        unsigned short* d = wp + ig_wp_elem<PL>(n, t, k, taps, K);
+        d[0] = h;
+        if (PL == 2) d[32] = l;
+    }
+    if (mode != 0) {                                     // adjoint: rows = k, reduction = n, taps flipped
+        unsigned short* d = (mode == 1 ? wp : wpt) + ig_wp_elem<PL>(k, taps - 1 - t, n, taps, N);
+        d[0] = h;
+        if (PL == 2) d[32] = l;
     }
 }
 
@@ -514,19 +524,20 @@ extern "C" int hiast_igemm_bn_act(const void* x, const void* wp, const float* ga
 }
 
 extern "C" int hiast_pack_conv_weight(const float* w, int N, int K, int taps, int planes, int transpose, void* wp,
-                                      hiast_stream_t stream)
+                                      void* wpt, hiast_stream_t stream)
 {
     if (!w || !wp) return HIAST_E_ARG;
     if (N <= 0 || K <= 0 || taps <= 0) return HIAST_E_ARG;
-    if (planes != 1 && planes != 2) return HIAST_E_RANGE;
+    if ((planes != 1 && planes != 2) || transpose < 0 || transpose > 2) return HIAST_E_RANGE;
+    if (transpose == 2 && !wpt) return HIAST_E_ARG;
     const long long total = (long long)N * K * taps;
     const dim3 grid((unsigned)((total + 255) / 256));
     if (planes == 2)
         hipLaunchKernelGGL(hiast::pack_conv_weight_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, w,
-                           (unsigned short*)wp, N, K, taps, transpose);
+                           (unsigned short*)wp, (unsigned short*)wpt, N, K, taps, transpose);
     else
         hipLaunchKernelGGL(hiast::pack_conv_weight_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, w,
-                           (unsigned short*)wp, N, K, taps, transpose);
+                           (unsigned short*)wp, (unsigned short*)wpt, N, K, taps, transpose);
     HIAST_CHECK_LAUNCH();
     return 0;
 }

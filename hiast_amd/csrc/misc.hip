@@ -35,6 +35,22 @@ __global__ __launch_bounds__(256) void ema_kernel(const hiast_ema_rec* __restric
     }
 }
 
+// copy a list of small tensors (the BatchNorm buffers the EMA teacher takes over from the student,
+// utils/utils.py:120-123: ~300 tensors of <= 8 KB) in ONE launch: block b copies tensor b.
+__global__ __launch_bounds__(256) void multi_copy_kernel(const hiast_copy_rec* __restrict__ table)
+{
+    const hiast_copy_rec r = table[blockIdx.x];
+    unsigned char* d = (unsigned char*)r.dst;
+    const unsigned char* s = (const unsigned char*)r.src;
+    if (((((uintptr_t)d) | ((uintptr_t)s)) & 15) == 0) {
+        const int64_t nv = r.nbytes / 16;
+        for (int64_t i = threadIdx.x; i < nv; i += 256) reinterpret_cast<uint4*>(d)[i] = reinterpret_cast<const uint4*>(s)[i];
+        for (int64_t i = nv * 16 + threadIdx.x; i < r.nbytes; i += 256) d[i] = s[i];
+    } else {
+        for (int64_t i = threadIdx.x; i < r.nbytes; i += 256) d[i] = s[i];
+    }
+}
+
 // K13 — Adam step over the whole parameter list in ONE launch (reference: torch.optim.Adam(weight_decay=5e-4) built
 // in utils/utils.py:135-154 and stepped by BaseTrainer.update_model, workflows/trainer/base_trainer.py:127-141;
 // there a per-tensor loop of ~10 elementwise kernels).  torch's single-tensor formulas, in its operation order:
@@ -44,12 +60,12 @@ __global__ __launch_bounds__(256) void ema_kernel(const hiast_ema_rec* __restric
 __global__ __launch_bounds__(256) void adam_kernel(const hiast_adam_rec* __restrict__ table,
                                                    const int32_t* __restrict__ chunk_tensor,
                                                    const int64_t* __restrict__ chunk_start, float beta1, float beta2,
-                                                   float eps, float wd)
+                                                   float omb1, float omb2, float eps, float wd)
 {
     const hiast_adam_rec r = table[chunk_tensor[blockIdx.x]];
     const int64_t s = chunk_start[blockIdx.x];
     const int64_t e = (s + 65536 < r.n) ? s + 65536 : r.n;
-    const float step_size = r.lr / r.bc1, omb1 = 1.0f - beta1, omb2 = 1.0f - beta2;
+    const float step_size = r.lr / r.bc1;     // omb1 / omb2 = float(1 - beta) formed in double on the host, as torch does
     auto upd = [&](float& p, float g, float& m, float& v) {
         if (wd != 0.f) g = g + wd * p;
         m = m + (g - m) * omb1;
@@ -149,13 +165,23 @@ extern "C" int hiast_confusion_hist(const int64_t* pred, const int64_t* target, 
 }
 
 extern "C" int hiast_adam_step(const hiast_adam_rec* table, const int32_t* chunk_tensor, const int64_t* chunk_start,
-                               int n_chunks, float beta1, float beta2, float eps, float weight_decay,
+                               int n_chunks, double beta1, double beta2, float eps, float weight_decay,
                                hiast_stream_t stream)
 {
     if (!table || !chunk_tensor || !chunk_start) return HIAST_E_ARG;
     if (n_chunks <= 0) return HIAST_E_ARG;
     hipLaunchKernelGGL(hiast::adam_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, table, chunk_tensor,
-                       chunk_start, beta1, beta2, eps, weight_decay);
+                       chunk_start, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), eps,
+                       weight_decay);
+    HIAST_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int hiast_multi_copy(const hiast_copy_rec* table, int n_tensors, hiast_stream_t stream)
+{
+    if (!table) return HIAST_E_ARG;
+    if (n_tensors <= 0) return HIAST_E_ARG;
+    hipLaunchKernelGGL(hiast::multi_copy_kernel, dim3(n_tensors), dim3(256), 0, (hipStream_t)stream, table);
     HIAST_CHECK_LAUNCH();
     return 0;
 }

@@ -249,7 +249,11 @@ class _ConvNhwcFn(torch.autograd.Function):
     @torch.amp.custom_fwd(device_type="cuda")
     def forward(ctx, x, weight, stride, dil, want_stats):
         xv = x.permute(0, 2, 3, 1)
-        wp = K.pack_conv_weight(weight, 1)
+        ctx.wpt = None
+        if stride == 1 and ctx.needs_input_grad[0]:      # forward + adjoint (data-gradient) weight in one pack launch
+            wp, ctx.wpt = K.pack_conv_weight(weight, 1, both=True)
+        else:
+            wp = K.pack_conv_weight(weight, 1)
         ctx.save_for_backward(x, weight)
         ctx.geo = (stride, dil)
         if want_stats:       # + per-block Σy, Σy² of the stored outputs for the BatchNorm that follows
@@ -272,7 +276,7 @@ class _ConvNhwcFn(torch.autograd.Function):
         dx = dw = None
         lib_x = need_x and stride != 1
         if need_x and stride == 1:
-            wpt = K.pack_conv_weight(weight, 1, transpose=True)
+            wpt = ctx.wpt if ctx.wpt is not None else K.pack_conv_weight(weight, 1, transpose=True)
             dx = K.igemm_bn_act(dy.permute(0, 2, 3, 1), wpt, 1, None, None, False, 1, dil).permute(0, 3, 1, 2)
         own_w = need_w and os.environ.get("HIAST_LIB_WGRAD", "0") != "1" and K.conv_wgrad_preferred(
             weight.shape[1], weight.shape[0], k, stride)
@@ -311,11 +315,14 @@ def conv_nhwc(x, conv, want_stats=False):
     return _ConvNhwcFn.apply(x, conv.weight, conv.stride[0], conv.dilation[0], bool(want_stats))
 
 
+_nbt_batched = [False]      # set by ResNet.forward while it has already advanced every num_batches_tracked at once
+
+
 def bn_act(x, bn, res=None, relu=True, partial=None):
     """Fused replacement of `relu(bn(x) [+ res])` for a torch BatchNorm2d / SyncBatchNorm module `bn`
     (which keeps owning the parameters and running statistics)."""
     training = bn.training or (bn.running_mean is None)
-    if training and bn.track_running_stats and bn.num_batches_tracked is not None:
+    if training and bn.track_running_stats and bn.num_batches_tracked is not None and not _nbt_batched[0]:
         bn.num_batches_tracked.add_(1)
     momentum = 0.1 if bn.momentum is None else bn.momentum
     if (training and x.dtype == torch.bfloat16 and _is_cl(x) and not x.is_contiguous()

@@ -345,6 +345,30 @@ def ema_update(plan, gamma):
                                        _stream()), "hiast_ema_update")
 
 
+class CopyPlan:
+    """device table for copying a fixed list of (small) tensors in one launch"""
+
+    def __init__(self, dsts, srcs):
+        assert len(dsts) == len(srcs) and len(dsts) > 0
+        recs = np.zeros((len(dsts), 3), dtype=np.int64)
+        for i, (d, s_) in enumerate(zip(dsts, srcs)):
+            if not (d.is_cuda and s_.is_cuda and d.is_contiguous() and s_.is_contiguous() and d.dtype == s_.dtype
+                    and d.numel() == s_.numel()):
+                raise ValueError("multi_copy: tensor %d: contiguous HIP tensors of equal dtype and size required" % i)
+            recs[i] = (d.data_ptr(), s_.data_ptr(), d.numel() * d.element_size())
+        self.keep = (list(dsts), list(srcs))
+        self.ptrs = recs[:, :2].copy()
+        self.table = torch.from_numpy(recs).to(dsts[0].device)
+        self.n = len(dsts)
+
+    def still_valid(self):
+        return all(d.data_ptr() == a and s_.data_ptr() == b for (d, s_, (a, b)) in zip(self.keep[0], self.keep[1], self.ptrs))
+
+
+def multi_copy(plan):
+    check(_lib.load().hiast_multi_copy(_ptr(plan.table), plan.n, _stream()), "hiast_multi_copy")
+
+
 # ------------------------------------------------------------------------------- K13 Adam
 class AdamPlan:
     """chunk tables for one list of parameter sizes (static); the pointer / lr records are rebuilt per step because
@@ -552,19 +576,27 @@ def merge_planes(p):
     return x
 
 
-def pack_conv_weight(weight, planes, transpose=False):
+def pack_conv_weight(weight, planes, transpose=False, both=False):
     """fp32 conv weight [N,K,kh,kw] (torch layout) -> packed bf16 [N, kh*kw, planes*K]; transpose=True packs the
-    adjoint (data-gradient) convolution's weight [K, kh*kw (flipped), planes*N]"""
+    adjoint (data-gradient) convolution's weight [K, kh*kw (flipped), planes*N]; both=True -> (forward, adjoint) in
+    one launch"""
     w = weight.detach()
     if w.dim() == 2:
         w = w.reshape(w.shape[0], w.shape[1], 1, 1)
     _req(w, torch.float32, 4, "weight")
     N, K_, kh, kw = w.shape
-    shape = (K_, kh * kw, planes * N) if transpose else (N, kh * kw, planes * K_)
-    wp = torch.empty(shape, dtype=torch.bfloat16, device=w.device)
-    check(_lib.load().hiast_pack_conv_weight(_ptr(w), N, K_, kh * kw, planes, int(bool(transpose)), _ptr(wp), _stream()),
+    fwd_shape, adj_shape = (N, kh * kw, planes * K_), (K_, kh * kw, planes * N)
+    wpt = None
+    if both:
+        wp = torch.empty(fwd_shape, dtype=torch.bfloat16, device=w.device)
+        wpt = torch.empty(adj_shape, dtype=torch.bfloat16, device=w.device)
+        mode = 2
+    else:
+        wp = torch.empty(adj_shape if transpose else fwd_shape, dtype=torch.bfloat16, device=w.device)
+        mode = 1 if transpose else 0
+    check(_lib.load().hiast_pack_conv_weight(_ptr(w), N, K_, kh * kw, planes, mode, _ptr(wp), _ptr(wpt), _stream()),
           "hiast_pack_conv_weight")
-    return wp
+    return (wp, wpt) if both else wp
 
 
 def igemm_bn_act(x, wp, planes, bn, res, relu, stride=1, dil=1, out_f32=False, want_stats=False):

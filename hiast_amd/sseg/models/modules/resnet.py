@@ -187,9 +187,26 @@ class ResNet(nn.Module):
             x = self.conv1(x).contiguous(memory_format=torch.channels_last)
         else:
             x = self.conv1(x)
-        x = self.maxpool(bn_act(self.bn1, x))
-        low = self.layer1(x)
-        x = self.layer4(self.layer3(self.layer2(low)))
+        batched = False
+        if self.training and x.is_cuda:
+            # one foreach add for the 104 num_batches_tracked counters instead of one tiny kernel per BN layer
+            nbt = self.__dict__.get("_hiast_nbt")
+            if nbt is None or nbt[0].device != x.device:
+                nbt = [m.num_batches_tracked for m in self.modules()
+                       if isinstance(m, nn.modules.batchnorm._BatchNorm) and m.track_running_stats
+                       and m.num_batches_tracked is not None]
+                self.__dict__["_hiast_nbt"] = nbt
+            if nbt:
+                torch._foreach_add_(nbt, 1)
+                batched = True
+        prev = HF._nbt_batched[0]
+        HF._nbt_batched[0] = batched or prev
+        try:
+            x = self.maxpool(bn_act(self.bn1, x))
+            low = self.layer1(x)
+            x = self.layer4(self.layer3(self.layer2(low)))
+        finally:
+            HF._nbt_batched[0] = prev
         return (x, low) if is_return_low else x
 
 

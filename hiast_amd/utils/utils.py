@@ -95,6 +95,7 @@ class EmaUpdater:
 
     def __init__(self):
         self._plan = None
+        self._bplan = None
 
     def __call__(self, ema_model, model, gamma):
         from hiast_amd import kernels as K
@@ -108,8 +109,10 @@ class EmaUpdater:
         K.ema_update(self._plan, gamma)
         eb = [b for b in ema_model.buffers()]
         sb = [b for b in src.buffers()]
-        if eb:
-            torch._foreach_copy_(eb, sb)
+        if eb:      # ~300 BatchNorm buffers: one launch instead of one copy kernel per tensor
+            if self._bplan is None or not self._bplan.still_valid() or self._bplan.n != len(eb):
+                self._bplan = K.CopyPlan(eb, sb)
+            K.multi_copy(self._bplan)
         return ema_model
 
 

@@ -218,8 +218,9 @@ int hiast_bn_act_nhwc_infer(const void* x, void* y, const float* gamma, const fl
  * res like y.  planes = 2: hi*hi + lo*hi + hi*lo on the bf16 matrix cores (fp32-class, the pseudo-label forward);
  * planes = 1: plain bf16.  The split is done once by the producer's epilogue instead of by every consumer block.
  * wp: packed bf16 [Cout][taps][planes*Cin] from hiast_pack_conv_weight (w: torch layout [Cout][Cin][taps], taps = 1 | 9;
- * transpose = 1 packs the ADJOINT convolution's weight [Cin][taps flipped][planes*Cout]: running the same kernel on dY
- * with it is the data gradient of a stride-1 convolution — autograd of nn.Conv2d in resnet.py:78-98).
+ * transpose = 1 packs the ADJOINT convolution's weight [Cin][taps flipped][planes*Cout] into wp: running the same kernel
+ * on dY with it is the data gradient of a stride-1 convolution — autograd of nn.Conv2d in resnet.py:78-98;
+ * transpose = 2 writes the forward weight to wp AND the adjoint to wpt in one pass; wpt is unused otherwise).
  * taps = 9: padding = dilation, stride 1 | 2.  out_f32 = 1: y is fp32 [B,Ho,Wo,Cout] (no residual).  mean == NULL: no
  * BatchNorm (plain GEMM).  Cin % 32 == 0, Cout % 64 == 0, every tensor < 2 GiB, 16-byte aligned.
  * hiast_split_planes: fp32 [M][C] <-> planes [M][2][C] (inverse = 1: x is written; hi + lo is exact in fp32).
@@ -230,7 +231,7 @@ int hiast_igemm_bn_act(const void* x, const void* wp, const float* gamma, const 
                        const float* var, float eps, const void* res, int relu, void* y, int B, int H, int W, int Cin,
                        int Cout, int taps, int stride, int dil, int planes, int out_f32, float* stats,
                        hiast_stream_t stream);
-int hiast_pack_conv_weight(const float* w, int N, int K, int taps, int planes, int transpose, void* wp,
+int hiast_pack_conv_weight(const float* w, int N, int K, int taps, int planes, int transpose, void* wp, void* wpt,
                            hiast_stream_t stream);
 int hiast_split_planes(float* x, void* planes, int64_t M, int C, int inverse, hiast_stream_t stream);
 
@@ -277,6 +278,11 @@ int hiast_ema_update(const hiast_ema_rec* table, const int32_t* chunk_tensor,
                      const int64_t* chunk_start, int n_chunks, float gamma,
                      float one_minus_gamma, hiast_stream_t stream);
 
+/* K11b: copy n_tensors small tensors in one launch (the BatchNorm buffers update_ema_model copies from the student,
+ * utils/utils.py:120-123).  table: device array of {dst, src, nbytes}; one block per tensor. */
+typedef struct { void* dst; const void* src; int64_t nbytes; } hiast_copy_rec;
+int hiast_multi_copy(const hiast_copy_rec* table, int n_tensors, hiast_stream_t stream);
+
 /* ---- K13: Adam step ---------------------------------------------------------------------
  * torch.optim.Adam(betas, weight_decay) as built by utils/utils.py:135-154 and stepped by BaseTrainer.update_model
  * (workflows/trainer/base_trainer.py:127-141): every parameter tensor in ONE launch, torch's single-tensor
@@ -285,7 +291,7 @@ int hiast_ema_update(const hiast_ema_rec* table, const int32_t* chunk_tensor,
  * chunk tables as for K11. */
 typedef struct { float* p; const float* g; float* m; float* v; int64_t n; float lr; float bc1; float bc2_sqrt; float pad; } hiast_adam_rec;
 int hiast_adam_step(const hiast_adam_rec* table, const int32_t* chunk_tensor, const int64_t* chunk_start,
-                    int n_chunks, float beta1, float beta2, float eps, float weight_decay, hiast_stream_t stream);
+                    int n_chunks, double beta1, double beta2, float eps, float weight_decay, hiast_stream_t stream);
 
 /* ---- K12: IoU histograms --------------------------------------------------------------
  * utils/metrics.py:6-19 intersectionAndUnionGPU: pred/target int64 [N]; target==255 is

@@ -666,9 +666,9 @@ def test_fused_adam_matches_torch_adam(K):
     for k in sb:
         assert float(sa[k]["step"]) == float(sb[k]["step"])
         # (torch's foreach path forms m by lerp / mul+add in another association: a few ulps of the LARGER term)
-        assert torch.allclose(sa[k]["exp_avg"], sb[k]["exp_avg"], rtol=2e-6, atol=2e-7 * float(sb[k]["exp_avg"].abs().max()))
-        assert torch.allclose(sa[k]["exp_avg_sq"], sb[k]["exp_avg_sq"], rtol=2e-6,
-                              atol=2e-7 * float(sb[k]["exp_avg_sq"].abs().max()))
+        assert torch.allclose(sa[k]["exp_avg"], sb[k]["exp_avg"], rtol=1e-5, atol=1e-6 * float(sb[k]["exp_avg"].abs().max()))
+        assert torch.allclose(sa[k]["exp_avg_sq"], sb[k]["exp_avg_sq"], rtol=1e-5,
+                              atol=1e-6 * float(sb[k]["exp_avg_sq"].abs().max()))
 
 
 def test_ema_bit_exact(K):
