@@ -100,7 +100,7 @@ class KernelTimer:
         def aspp_key(x, wpack, Cout, dil, workspace=None):
             return ("aspp_fwd", tuple(x.shape), Cout)
 
-        def ig_key(x, wp, planes, bn, res, relu, stride=1, dil=1, out_f32=False, want_stats=False):
+        def ig_key(x, wp, planes, bn, res, relu, stride=1, dil=1, out_f32=False, **_kw):
             return ("igemm", tuple(x.shape), tuple(wp.shape), int(planes), int(stride), int(dil), res is not None,
                     bool(out_f32))
         self.wrap(K, "aspp_fwd", aspp_key)

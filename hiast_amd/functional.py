@@ -206,7 +206,7 @@ class _BnActNhwcFn(torch.autograd.Function):
     kernels, so the student forward / backward needs no NCHW<->NHWC transposes."""
 
     @staticmethod
-    def forward(ctx, x, res, gamma, beta, running_mean, running_var, momentum, eps, relu, world, partial):
+    def forward(ctx, x, res, gamma, beta, running_mean, running_var, momentum, eps, relu, world, partial, box):
         # batch statistics: from the producing convolution's epilogue when it delivered them, else one pass over x
         sums = K.bn_nhwc_stats_from_partial(partial) if partial is not None else K.bn_nhwc_stats(x)
         count = float(x.shape[0] * x.shape[2] * x.shape[3])
@@ -219,6 +219,10 @@ class _BnActNhwcFn(torch.autograd.Function):
         ctx.gate = 0 if not relu else (1 if res is not None else 2)
         ctx.save_for_backward(x, y if ctx.gate == 1 else None, gamma, beta, sm, si)
         ctx.has_res, ctx.world, ctx.count = res is not None, world, count
+        # identity-branch hand-off (see Bottleneck.forward): when the block's first convolution has announced that its
+        # data-gradient epilogue will add the ReLU-masked gradient of the identity branch itself, this backward
+        # neither writes that masked copy (dres) nor returns it for autograd to add
+        ctx.box = box if (box is not None and box.get("armed") and ctx.gate == 1) else None
         return y
 
     @staticmethod
@@ -232,10 +236,13 @@ class _BnActNhwcFn(torch.autograd.Function):
             import torch.distributed as dist
             dist.all_reduce(sums)
         want_p = gamma is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3])
+        handoff = ctx.box is not None and ctx.needs_input_grad[1]
         dx, dres, dg, db = K.bn_nhwc_bwd_apply(dy, y, x, gamma, beta, sm, si, sums, ctx.count, ctx.gate,
-                                               ctx.has_res and ctx.needs_input_grad[1], want_p)
+                                               ctx.has_res and ctx.needs_input_grad[1] and not handoff, want_p)
+        if handoff:
+            ctx.box["gated"] = (dy, y)            # consumed by the block's conv1 backward
         return (dx, dres, dg if ctx.needs_input_grad[2] else None, db if ctx.needs_input_grad[3] else None,
-                None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None)
 
 
 class _ConvNhwcFn(torch.autograd.Function):
@@ -247,9 +254,13 @@ class _ConvNhwcFn(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
-    def forward(ctx, x, weight, stride, dil, want_stats):
+    def forward(ctx, x, weight, stride, dil, want_stats, box):
         xv = x.permute(0, 2, 3, 1)
         ctx.wpt = None
+        ctx.box = None
+        if box is not None and stride == 1 and ctx.needs_input_grad[0]:
+            box["armed"] = True                    # this conv's backward will take over the identity-branch gradient
+            ctx.box = box
         if stride == 1 and ctx.needs_input_grad[0]:      # forward + adjoint (data-gradient) weight in one pack launch
             wp, ctx.wpt = K.pack_conv_weight(weight, 1, both=True)
         else:
@@ -277,7 +288,12 @@ class _ConvNhwcFn(torch.autograd.Function):
         lib_x = need_x and stride != 1
         if need_x and stride == 1:
             wpt = ctx.wpt if ctx.wpt is not None else K.pack_conv_weight(weight, 1, transpose=True)
-            dx = K.igemm_bn_act(dy.permute(0, 2, 3, 1), wpt, 1, None, None, False, 1, dil).permute(0, 3, 1, 2)
+            gated = ctx.box.pop("gated", None) if ctx.box is not None else None
+            if gated is not None:      # + dy_block * (y_block > 0): the identity branch's gradient, in the epilogue
+                dx = K.igemm_bn_act(dy.permute(0, 2, 3, 1), wpt, 1, None, gated[0].permute(0, 2, 3, 1), False, 1, dil,
+                                    res_gate=gated[1].permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+            else:
+                dx = K.igemm_bn_act(dy.permute(0, 2, 3, 1), wpt, 1, None, None, False, 1, dil).permute(0, 3, 1, 2)
         own_w = need_w and os.environ.get("HIAST_LIB_WGRAD", "0") != "1" and K.conv_wgrad_preferred(
             weight.shape[1], weight.shape[0], k, stride)
         if own_w:            # transposed-read GEMM over the pixel index (hiast_conv_wgrad_nhwc)
@@ -294,7 +310,7 @@ class _ConvNhwcFn(torch.autograd.Function):
             if need_w and not own_w:
                 # fp32, NCHW-contiguous like the parameter (DDP's gradient-layout contract): one cast+layout kernel
                 dw = gw.to(dtype=weight.dtype, memory_format=torch.contiguous_format)
-        return dx, dw, None, None, None
+        return dx, dw, None, None, None, None
 
 
 def conv_nhwc_ok(x, conv):
@@ -310,15 +326,15 @@ def conv_nhwc_ok(x, conv):
     return conv.padding == conv.dilation and conv.dilation[0] == conv.dilation[1] and conv.stride[0] in (1, 2)
 
 
-def conv_nhwc(x, conv, want_stats=False):
-    """-> y, or (y, partial) with want_stats (see igemm_bn_act)"""
-    return _ConvNhwcFn.apply(x, conv.weight, conv.stride[0], conv.dilation[0], bool(want_stats))
+def conv_nhwc(x, conv, want_stats=False, box=None):
+    """-> y, or (y, partial) with want_stats (see igemm_bn_act); box: identity-branch hand-off of a bottleneck"""
+    return _ConvNhwcFn.apply(x, conv.weight, conv.stride[0], conv.dilation[0], bool(want_stats), box)
 
 
 _nbt_batched = [False]      # set by ResNet.forward while it has already advanced every num_batches_tracked at once
 
 
-def bn_act(x, bn, res=None, relu=True, partial=None):
+def bn_act(x, bn, res=None, relu=True, partial=None, box=None):
     """Fused replacement of `relu(bn(x) [+ res])` for a torch BatchNorm2d / SyncBatchNorm module `bn`
     (which keeps owning the parameters and running statistics)."""
     training = bn.training or (bn.running_mean is None)
@@ -328,6 +344,6 @@ def bn_act(x, bn, res=None, relu=True, partial=None):
     if (training and x.dtype == torch.bfloat16 and _is_cl(x) and not x.is_contiguous()
             and K.bn_nhwc_supported(x.shape[1]) and (res is None or (res.dtype == x.dtype and _is_cl(res)))):
         return _BnActNhwcFn.apply(x, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, momentum, bn.eps, relu,
-                                  _sync_world(bn), partial)
+                                  _sync_world(bn), partial, box)
     return _BnActFn.apply(x, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum,
                           bn.eps, relu, _sync_world(bn) if training else 1)

@@ -599,7 +599,7 @@ def pack_conv_weight(weight, planes, transpose=False, both=False):
     return (wp, wpt) if both else wp
 
 
-def igemm_bn_act(x, wp, planes, bn, res, relu, stride=1, dil=1, out_f32=False, want_stats=False):
+def igemm_bn_act(x, wp, planes, bn, res, relu, stride=1, dil=1, out_f32=False, want_stats=False, res_gate=None):
     """x: bf16 [B,H,W,planes*Cin] (planes = 2 split planes | 1 plain bf16); wp from pack_conv_weight (same planes);
     bn: BatchNorm2d in eval mode or None (plain GEMM); res: like the output or None
     -> y bf16 [B,Ho,Wo,planes*Cout], or fp32 [B,Ho,Wo,Cout] if out_f32;
@@ -624,6 +624,9 @@ def igemm_bn_act(x, wp, planes, bn, res, relu, stride=1, dil=1, out_f32=False, w
     if res is not None:
         _req(res, torch.bfloat16, 4, "res")
         assert tuple(res.shape) == tuple(y.shape)
+    if res_gate is not None:        # residual added only where res_gate > 0 (planes = 1)
+        _req(res_gate, torch.bfloat16, 4, "res_gate")
+        assert PL == 1 and res is not None and tuple(res_gate.shape) == tuple(res.shape)
     if bn is not None:
         g, b, mu, var, eps = _bn_params(bn)
     else:
@@ -635,7 +638,7 @@ def igemm_bn_act(x, wp, planes, bn, res, relu, stride=1, dil=1, out_f32=False, w
         partial = torch.empty(((B * Ho * Wo + 255) // 256, N, 2), dtype=torch.float32, device=x.device)
     check(_lib.load().hiast_igemm_bn_act(_ptr(x), _ptr(wp), g, b, mu, var, eps, _ptr(res), int(bool(relu)), _ptr(y),
                                          B, H, W, Cin, N, taps, int(stride), int(dil), PL, int(bool(out_f32)),
-                                         _ptr(partial), _stream()), "hiast_igemm_bn_act")
+                                         _ptr(partial), _ptr(res_gate), _stream()), "hiast_igemm_bn_act")
     return (y, partial) if want_stats else y
 
 

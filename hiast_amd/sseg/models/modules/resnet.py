@@ -31,12 +31,12 @@ def conv(m, x):
     return m(x)
 
 
-def conv_bn_act(cv, bn, x, res=None, relu=True):
+def conv_bn_act(cv, bn, x, res=None, relu=True, conv_box=None, bn_box=None):
     """relu?(bn(conv(x)) [+ res]).  On the channels-last bf16 training path the convolution's epilogue also
     delivers the per-block sums the BatchNorm needs (one pass over the activation less)."""
     if x.is_cuda and x.dtype == torch.bfloat16 and bn.training and HF.conv_nhwc_ok(x, cv):
-        y, partial = HF.conv_nhwc(x, cv, want_stats=True)
-        return HF.bn_act(y, bn, res, relu, partial=partial)
+        y, partial = HF.conv_nhwc(x, cv, want_stats=True, box=conv_box)
+        return HF.bn_act(y, bn, res, relu, partial=partial, box=bn_box)
     return bn_act(bn, conv(cv, x), res, relu)
 
 
@@ -81,9 +81,13 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         idt = x if self.downsample is None else conv_bn_act(self.downsample[0], self.downsample[1], x, relu=False)
-        o = conv_bn_act(self.conv1, self.bn1, x)
+        # identity blocks on the channels-last training path: conv1's data-gradient epilogue adds the ReLU-masked
+        # gradient of the identity branch itself (no masked copy written by bn3's backward, no separate add kernel);
+        # `box` is the hand-off between the two autograd nodes of this call
+        box = {} if (self.downsample is None and os.environ.get("HIAST_NO_IDT_HANDOFF", "0") != "1") else None
+        o = conv_bn_act(self.conv1, self.bn1, x, conv_box=box)
         o = conv_bn_act(self.conv2, self.bn2, o)
-        return conv_bn_act(self.conv3, self.bn3, o, res=idt)        # += identity, ReLU
+        return conv_bn_act(self.conv3, self.bn3, o, res=idt, bn_box=box)        # += identity, ReLU
 
     def forward_eval_planes(self, x, PL):
         """inference on channels-last 16-bit activations [B,H,W,PL*C] (PL = 2: split planes, fp32-class — the

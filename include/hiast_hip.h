@@ -226,11 +226,14 @@ int hiast_bn_act_nhwc_infer(const void* x, void* y, const float* gamma, const fl
  * hiast_split_planes: fp32 [M][C] <-> planes [M][2][C] (inverse = 1: x is written; hi + lo is exact in fp32).
  * stats (planes = 1, 16-bit output only; may be NULL): [ceil(B*Ho*Wo/256)][Cout][2] fp32, per 256-row block the sums
  * Σy and Σy² of the stored (bf16) outputs — the BatchNorm batch statistics of the training forward come out of the
- * convolution's epilogue (hiast_bn_nhwc_stats_from_partial reduces them) instead of another pass over y. */
+ * convolution's epilogue (hiast_bn_nhwc_stats_from_partial reduces them) instead of another pass over y.
+ * res_gate (planes = 1, with res; may be NULL): like res; the residual is then added only where res_gate > 0 — the data
+ * gradient of a bottleneck's first convolution takes the ReLU-masked gradient of the identity branch (dy of the block
+ * output, gated by the block output) in its epilogue instead of a masked copy + a separate add. */
 int hiast_igemm_bn_act(const void* x, const void* wp, const float* gamma, const float* beta, const float* mean,
                        const float* var, float eps, const void* res, int relu, void* y, int B, int H, int W, int Cin,
                        int Cout, int taps, int stride, int dil, int planes, int out_f32, float* stats,
-                       hiast_stream_t stream);
+                       const void* res_gate, hiast_stream_t stream);
 int hiast_pack_conv_weight(const float* w, int N, int K, int taps, int planes, int transpose, void* wp, void* wpt,
                            hiast_stream_t stream);
 int hiast_split_planes(float* x, void* planes, int64_t M, int C, int inverse, hiast_stream_t stream);

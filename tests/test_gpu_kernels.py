@@ -567,6 +567,36 @@ def test_conv_nhwc_autograd_vs_fp64(K, cfg, monkeypatch):
     assert torch.allclose(s_ep, s_pass, rtol=1e-5, atol=1e-3)
 
 
+def test_bottleneck_identity_handoff_matches_autograd_add(K, monkeypatch):
+    """identity block, channels-last training path: the gradient of the identity branch added in conv1's data-gradient
+    epilogue (gated by the block output) vs the plain autograd formulation (masked copy + add kernel)"""
+    from hiast_amd.sseg.models.modules.resnet import Bottleneck
+    torch.manual_seed(0)
+    blk = Bottleneck(256, 64, 1, 2).cuda().train()
+    x0 = _cl(dev(_bf16r(synth.normal_f32(950, (2, 256, 24, 40)))).bfloat16())
+    gy = _cl(dev(_bf16r(synth.normal_f32(951, (2, 256, 24, 40)))).bfloat16())
+    outs = []
+    for off in ("1", "0"):
+        monkeypatch.setenv("HIAST_NO_IDT_HANDOFF", off)
+        blk.zero_grad()
+        # the block input is itself the output of an op (as in the trunk), so that its gradient is what autograd delivers
+        src = x0.clone().requires_grad_(True)
+        xin = src * 1.0
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = blk(xin)
+        y.backward(gy)
+        outs.append((y.detach().float(), src.grad.float(), blk.conv1.weight.grad.clone(), blk.conv3.weight.grad.clone()))
+    (y0, g0, a0, c0), (y1, g1, a1, c1) = outs
+    assert torch.equal(y0, y1)
+    # one bf16 rounding of (data gradient + masked identity gradient) instead of two: differences are ulps of the
+    # LARGER addend, so the bound is relative to the tensor's scale
+    assert ((g0 - g1).abs() <= 2.0 ** -6 * g0.abs() + 2.0 ** -7 * g0.abs().max()).all()
+    assert float((g0 - g1).abs().mean()) <= 2e-3 * float(g0.abs().mean())
+    # weight gradients do not depend on the hand-off (64-channel shapes: library kernels, bf16 results, atomics)
+    assert torch.allclose(a0, a1, rtol=1e-2, atol=1e-2 * float(a0.abs().max()))
+    assert torch.allclose(c0, c1, rtol=1e-2, atol=1e-2 * float(c0.abs().max()))
+
+
 def test_training_trunk_channels_last_as_accurate_as_nchw_path(K):
     """mixed-precision training forward/backward of the whole DeepLab.  A random-init train-mode ResNet-101 amplifies
     bf16 rounding noise layer by layer (both bf16 paths end ~0.8 of max away from the fp32 forward), so the
