@@ -133,3 +133,54 @@ def test_unsupported_shapes_are_refused_not_faulted(K):
     # empty batch: nothing is launched, shapes are right
     mp, am, hist = K.plabel_pass1(torch.zeros(0, 19, 8, 16, device="cuda"), 64, 128)
     assert mp.shape == (0, 64, 128) and int(hist.sum()) == 0
+
+
+def test_igemm_trunk_properties_full_size(K):
+    """the LDS-DMA convolution kernel at the bench shapes (8 x 64 x 128 pixels): linearity in the input, determinism,
+    zero-padding (a one-pixel impulse spreads to exactly the 9 dilated taps), and refusal of shapes it does not tile"""
+    from hiast_amd._lib import HiastLibraryError
+    Bn, Hh, Ww, Ci, Co, dil = 8, 64, 128, 256, 256, 2
+    w = rnd(Co, Ci, 3, 3, seed=21, scale=(2.0 / (9 * Ci)) ** 0.5)
+    wp = K.pack_conv_weight(w, 2)
+    xa, xb = rnd(Bn * Hh * Ww, Ci, seed=22), rnd(Bn * Hh * Ww, Ci, seed=23)
+    pa, pb = (K.split_planes(t).view(Bn, Hh, Ww, 2 * Ci) for t in (xa, xb))
+    pab = K.split_planes(xa + xb).view(Bn, Hh, Ww, 2 * Ci)
+    ya, yb, yab = (K.merge_planes(K.igemm_bn_act(p, wp, 2, None, None, False, 1, dil).view(-1, 2 * Co)) for p in (pa, pb, pab))
+    assert (yab - (ya + yb)).abs().max() <= 5e-5 * yab.abs().max()
+    assert torch.equal(ya, K.merge_planes(K.igemm_bn_act(pa, wp, 2, None, None, False, 1, dil).view(-1, 2 * Co)))
+    # impulse at a corner pixel of image 3, channel 5: the response is non-zero exactly at the in-image taps
+    imp = torch.zeros(Bn, Hh, Ww, Ci, device="cuda")
+    imp[3, 0, 0, 5] = 1.0
+    yi = K.merge_planes(K.igemm_bn_act(K.split_planes(imp.view(-1, Ci)).view(Bn, Hh, Ww, 2 * Ci), wp, 2, None, None, False,
+                                       1, dil).view(-1, 2 * Co)).view(Bn, Hh, Ww, Co)
+    nz = (yi.abs().sum(-1) > 0).nonzero().tolist()
+    assert sorted(nz) == sorted([[3, yy, xx] for yy in (0, dil) for xx in (0, dil)])
+    whl = sum(t.float() for t in K.pack_conv_weight(w, 2).view(Co, 9, Ci // 32, 2, 32).unbind(3)).reshape(Co, 9, Ci)
+    assert torch.allclose(yi[3, dil, dil], whl[:, 0, 5], rtol=0, atol=1e-6)      # tap (-1,-1) of w reaches (+d,+d)
+    with pytest.raises(HiastLibraryError):       # channel counts the kernel does not tile
+        K.igemm_bn_act(torch.zeros(1, 8, 8, 2 * 48, device="cuda", dtype=torch.bfloat16),
+                       torch.zeros(64, 1, 2 * 48, device="cuda", dtype=torch.bfloat16), 2, None, None, False)
+
+
+def test_full_resolution_2048x1024_inference_matches_module_path(K, monkeypatch):
+    """BASELINE configs[4] geometry: one 2048x1024 image through the fp32-class fast path (split planes, 128x256 head
+    map) against the module path (library convolutions + fused BN kernels, fp32): logits within the 1e-3 contract,
+    identical argmax label map up to genuine near-ties"""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from hiast_amd.utils.registry import register  # noqa: F401
+    from hiast_amd.utils.registry.registries import SEG_MODEL
+    from make_golden import seeded_state_dict
+    m = SEG_MODEL["DeepLab_V2"](19, 256)
+    m.load_state_dict(seeded_state_dict(m, 9000))
+    m = m.cuda().eval()
+    x = rnd(1, 3, 1024, 2048, seed=31)
+    with torch.no_grad():
+        fast, _ = m(x, need_feat=False)
+        monkeypatch.setenv("HIAST_NO_FAST_EVAL", "1")
+        slow, _ = m(x)
+    assert tuple(fast.shape) == (1, 19, 128, 256)
+    assert (fast - slow).abs().max() <= 1e-3 * slow.abs().max()
+    top2 = slow.topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 2e-3 * slow.abs().max()
+    assert torch.equal(fast.argmax(1)[clear], slow.argmax(1)[clear])
