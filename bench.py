@@ -184,6 +184,7 @@ class HotPath:
             for p in self.ema.parameters():
                 p.requires_grad = False
             self.ema_updater = utils.EmaUpdater()
+            self.side = torch.cuda.Stream(device=device)
         # synthetic batch, resident on the device (normalised float images: what Dataset.transform emits)
         g = torch.Generator(device="cpu").manual_seed(1234 + rank)
         self.weak = torch.randn(B, 3, H, W, generator=g).to(device)
@@ -218,12 +219,21 @@ class HotPath:
     def train_step(self, plbl):
         self.model.train()
         teacher_lr = None
+        main = torch.cuda.current_stream()
         if self.teacher:
+            # EMA-teacher forward on a side stream: its MFMA-bound convolutions co-run with the HBM-bound BatchNorm
+            # passes of the student forward (ConsistencySelfTrainingTrainer.train_on does the same)
             self.ema.eval()
-            with torch.no_grad(), torch.autocast("cuda", dtype=self.amp, enabled=self.amp is not None):
+            side = self.side if os.environ.get("HIAST_NO_SIDE_STREAM", "0") != "1" else main
+            side.wait_stream(main)
+            with torch.cuda.stream(side), torch.no_grad(), torch.autocast("cuda", dtype=self.amp,
+                                                                          enabled=self.amp is not None):
                 teacher_lr = self.ema(self.weak, lowres=True)["logits_lowres"].float()
         with torch.autocast("cuda", dtype=self.amp, enabled=self.amp is not None):
             out = self.model(self.strong, lowres=True)
+        if self.teacher and side is not main:
+            main.wait_stream(side)
+            teacher_lr.record_stream(main)
         losses = self.model.module.compute_loss_lowres(out["logits_lowres"], plbl, out["size"], teacher_lr)
         g_loss = sum(torch.mean(v) for v in losses.values())
         self.opt.zero_grad(set_to_none=True)

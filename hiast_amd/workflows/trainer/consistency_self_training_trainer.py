@@ -55,14 +55,24 @@ class ConsistencySelfTrainingTrainer(BaseTrainer):
         self.validate(self.ema_model, self.ema_model_recorder, current_iter, True)
 
     def train_on(self, t_weak_img, t_strong_img, t_plbl):
-        self.ema_model.eval()
-        with torch.no_grad(), torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
-            teacher_lr = self.ema_model(t_weak_img, lowres=True)["logits_lowres"].float()
         if self.cfg.cst_training.cst_loss.type != "SoftCE":
             raise NotImplementedError("cst_loss.type %r" % self.cfg.cst_training.cst_loss.type)
+        self.ema_model.eval()
+        # teacher forward on a side stream: its MFMA-bound convolutions co-run with the HBM-bound BatchNorm passes of
+        # the student forward; the loss waits for both
+        main = torch.cuda.current_stream()
+        if getattr(self, "_side_stream", None) is None:
+            self._side_stream = torch.cuda.Stream(device=t_weak_img.device)
+        side = self._side_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side), torch.no_grad(), torch.autocast("cuda", dtype=self.amp_dtype,
+                                                                      enabled=self.amp_dtype is not None):
+            teacher_lr = self.ema_model(t_weak_img, lowres=True)["logits_lowres"].float()
         self.model.train()
         with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
             out = self.model(t_strong_img, lowres=True)
+        main.wait_stream(side)
+        teacher_lr.record_stream(main)
         return self.model.module.compute_loss_lowres(out["logits_lowres"], t_plbl, out["size"], teacher_lr)
 
     def train(self):
