@@ -55,6 +55,8 @@ SIGNATURES = {
     "hiast_bn_nhwc_workspace_bytes": (c_sz, [c_int]),
     "hiast_bn_nhwc_stats": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_sz, c_vp]),
     "hiast_bn_nhwc_apply": (c_int, [c_vp] * 8 + [ctypes.c_double, c_f32, c_f32, c_int, c_vp, c_vp, c_i64, c_int, c_vp]),
+    "hiast_bn_nhwc_apply_partial": (c_int, [c_vp] * 8 + [c_int, ctypes.c_double, c_f32, c_f32, c_int, c_vp, c_vp, c_i64,
+                                            c_int, c_vp]),
     "hiast_bn_nhwc_bwd_stats": (c_int, [c_vp] * 7 + [c_int, c_i64, c_int, c_vp, c_vp, c_sz, c_vp]),
     "hiast_bn_nhwc_bwd_apply": (c_int, [c_vp] * 8 + [ctypes.c_double, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp]),
     "hiast_split_planes": (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp]),

@@ -154,6 +154,41 @@ __global__ __launch_bounds__(256) void bnh_prep_fwd_kernel(const double* __restr
     }
 }
 
+// finalize + prep in one launch (single-rank forward: no all-reduce between them): a block owns 8 channels = 16
+// consecutive (Σx, Σx²) entries; the even lane of each pair derives mean / invstd / running statistics
+__global__ __launch_bounds__(256) void bnh_finalize_prep_kernel(const float* __restrict__ partial, int nblk, int C,
+                                                                double count, float momentum, float eps,
+                                                                float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                                float* __restrict__ save_mean,
+                                                                float* __restrict__ save_invstd)
+{
+    __shared__ double s[16][17];
+    const int e = threadIdx.x & 15, j = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + e;
+    double acc = 0.0;
+#pragma unroll 4
+    for (int b = j; b < nblk; b += 16) acc += (double)partial[(size_t)b * C * 2 + i];
+    s[j][e] = acc;
+    __syncthreads();
+    if (j == 0 && (e & 1) == 0) {
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { s1 += s[q][e]; s2 += s[q][e + 1]; }
+        const int c = i >> 1;
+        const double m = s1 / count;
+        double var = s2 / count - m * m;
+        var = var < 0.0 ? 0.0 : var;
+        const float mean = (float)m;
+        save_mean[c] = mean;
+        save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (run_mean) {
+            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * mean;
+            run_var[c] = (1.0f - momentum) * run_var[c] + momentum * (float)unb;
+        }
+    }
+}
+
 template <bool RES, bool RELU>
 __global__ __launch_bounds__(256) void bnh_apply_kernel(const unsigned short* __restrict__ x,
                                                         const unsigned short* __restrict__ res,
@@ -297,6 +332,35 @@ extern "C" int hiast_bn_nhwc_apply(const void* x, const void* res, void* y, cons
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(hiast::bnh_prep_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, count, momentum, eps,
                        running_mean, running_var, save_mean, save_invstd, C);
+    HIAST_CHECK_LAUNCH();
+#define L(RES, RELU)                                                                                              \
+    hipLaunchKernelGGL((hiast::bnh_apply_kernel<RES, RELU>), dim3((unsigned)nb), dim3(256), 0, st,                 \
+                       (const unsigned short*)x, (const unsigned short*)res, (unsigned short*)y, gamma, beta,      \
+                       save_mean, save_invstd, (long long)M, C)
+    if (res) { if (relu) L(true, true); else L(true, false); }
+    else { if (relu) L(false, true); else L(false, false); }
+#undef L
+    HIAST_CHECK_LAUNCH();
+    return 0;
+}
+
+// single-rank forward fed by per-block partial sums (the statistics epilogue of hiast_igemm_bn_act): finalize + prep in
+// one launch, then the elementwise pass
+extern "C" int hiast_bn_nhwc_apply_partial(const void* x, const void* res, void* y, const float* gamma, const float* beta,
+                                           float* running_mean, float* running_var, const float* partial, int nblk,
+                                           double count, float momentum, float eps, int relu, float* save_mean,
+                                           float* save_invstd, int64_t M, int C, hiast_stream_t stream)
+{
+    int e = bnh_check(x, M, C);
+    if (e) return e;
+    if (!y || !partial || !save_mean || !save_invstd || count <= 0 || nblk <= 0) return HIAST_E_ARG;
+    if ((((uintptr_t)y) | ((uintptr_t)res)) & 15) return HIAST_E_RANGE;
+    const int rpp = 256 / (C / 8);
+    long long nb = (M + (long long)rpp * 8 - 1) / ((long long)rpp * 8);
+    nb = nb < 1 ? 1 : (nb > 2048 ? 2048 : nb);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(hiast::bnh_finalize_prep_kernel, dim3(C * 2 / 16), dim3(256), 0, st, partial, nblk, C, count,
+                       momentum, eps, running_mean, running_var, save_mean, save_invstd);
     HIAST_CHECK_LAUNCH();
 #define L(RES, RELU)                                                                                              \
     hipLaunchKernelGGL((hiast::bnh_apply_kernel<RES, RELU>), dim3((unsigned)nb), dim3(256), 0, st,                 \

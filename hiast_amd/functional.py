@@ -208,13 +208,17 @@ class _BnActNhwcFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, res, gamma, beta, running_mean, running_var, momentum, eps, relu, world, partial, box):
         # batch statistics: from the producing convolution's epilogue when it delivered them, else one pass over x
-        sums = K.bn_nhwc_stats_from_partial(partial) if partial is not None else K.bn_nhwc_stats(x)
         count = float(x.shape[0] * x.shape[2] * x.shape[3])
-        if world > 1:      # SyncBN: one all-reduce of [C,2] double sums
-            import torch.distributed as dist
-            dist.all_reduce(sums)
-            count *= world
-        y, sm, si = K.bn_nhwc_apply(x, res, gamma, beta, running_mean, running_var, sums, count, momentum, eps, relu)
+        if world == 1 and partial is not None:      # no all-reduce point: statistics + apply straight from the partials
+            y, sm, si = K.bn_nhwc_apply_partial(x, res, gamma, beta, running_mean, running_var, partial, count, momentum,
+                                                eps, relu)
+        else:
+            sums = K.bn_nhwc_stats_from_partial(partial) if partial is not None else K.bn_nhwc_stats(x)
+            if world > 1:      # SyncBN: one all-reduce of [C,2] double sums
+                import torch.distributed as dist
+                dist.all_reduce(sums)
+                count *= world
+            y, sm, si = K.bn_nhwc_apply(x, res, gamma, beta, running_mean, running_var, sums, count, momentum, eps, relu)
         # ReLU gate of the backward: recomputed from x when there is no residual input (y is then not read again)
         ctx.gate = 0 if not relu else (1 if res is not None else 2)
         ctx.save_for_backward(x, y if ctx.gate == 1 else None, gamma, beta, sm, si)

@@ -710,6 +710,22 @@ def bn_nhwc_apply(x, res, gamma, beta, running_mean, running_var, sums, count, m
     return y, sm, si
 
 
+def bn_nhwc_apply_partial(x, res, gamma, beta, running_mean, running_var, partial, count, momentum, eps, relu):
+    """single-rank forward from per-block partial sums [nblk,C,2] (igemm_bn_act(..., want_stats=True))"""
+    xv, M, C = _bnh_view(x, "x")
+    _req(partial, torch.float32, 3, "partial")
+    assert partial.shape[1] == C and partial.shape[2] == 2
+    y = torch.empty_like(x, memory_format=torch.channels_last)
+    rv = _bnh_view(res, "res")[0] if res is not None else None
+    sm = torch.empty(C, dtype=torch.float32, device=x.device)
+    si = torch.empty(C, dtype=torch.float32, device=x.device)
+    check(_lib.load().hiast_bn_nhwc_apply_partial(_ptr(xv), _ptr(rv), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(running_mean),
+                                                  _ptr(running_var), _ptr(partial), partial.shape[0], float(count),
+                                                  float(momentum), float(eps), int(bool(relu)), _ptr(sm), _ptr(si), M, C,
+                                                  _stream()), "hiast_bn_nhwc_apply_partial")
+    return y, sm, si
+
+
 def bn_nhwc_bwd_stats(dy, y, x, gamma, beta, save_mean, save_invstd, gate):
     """gate: 0 = no ReLU, 1 = y > 0 (reads y), 2 = recomputed from x (forward without residual; y unused)"""
     xv, M, C = _bnh_view(x, "x")

@@ -257,6 +257,11 @@ size_t hiast_bn_nhwc_workspace_bytes(int C);
 int hiast_bn_nhwc_stats(const void* x, int64_t M, int C, double* sums, void* workspace, size_t workspace_bytes,
                         hiast_stream_t stream);
 int hiast_bn_nhwc_stats_from_partial(const float* partial, int nblk, int C, double* sums, hiast_stream_t stream);
+/* single-rank forward straight from the per-block partial sums (no all-reduce point): statistics + apply */
+int hiast_bn_nhwc_apply_partial(const void* x, const void* res, void* y, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, const float* partial, int nblk, double count,
+                                float momentum, float eps, int relu, float* save_mean, float* save_invstd, int64_t M,
+                                int C, hiast_stream_t stream);
 int hiast_bn_nhwc_apply(const void* x, const void* res, void* y, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, const double* sums, double count, float momentum,
                         float eps, int relu, float* save_mean, float* save_invstd, int64_t M, int C,
