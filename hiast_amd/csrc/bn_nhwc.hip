@@ -46,7 +46,8 @@ __device__ __forceinline__ void bnh_store8(unsigned short* p, const float (&v)[8
 // r0 + (t / G) + k * RPP, RPP = 256 / G rows per pass.
 // BWD = false: (Σx, Σx²) of x;  BWD = true: (Σg, Σ g*xhat) with g = dy * (y > 0 | all).
 // GATE (ReLU gate of the backward passes): 0 = none, 1 = y > 0 (y is read), 2 = recomputed from x as
-// x*scale + shift > 0 — valid when the forward had no residual input, and saves reading y in both backward passes.
+// x*scale + shift > 0 — valid when the forward had no residual input, and saves reading y in both backward passes,
+// 3 = the bit mask the forward wrote ([M][C/8] bytes, passed in place of y): 1/16 of y's bytes.
 template <bool BWD, int GATE>
 __global__ __launch_bounds__(256) void bnh_partial_kernel(const unsigned short* __restrict__ a,    // x | dy
                                                           const unsigned short* __restrict__ y,
@@ -79,10 +80,13 @@ __global__ __launch_bounds__(256) void bnh_partial_kernel(const unsigned short* 
         } else {
             float yy[8], xx[8];
             if (GATE == 1) bnh_load8(y + off, yy);
+            unsigned bits = 0;
+            if (GATE == 3) bits = reinterpret_cast<const unsigned char*>(y)[(size_t)r * G + cg];
             bnh_load8(x + off, xx);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const bool open = GATE == 0 || (GATE == 1 ? yy[k] > 0.f : fmaf(xx[k], gsc[k], gsh[k]) > 0.f);
+                const bool open = GATE == 0 || (GATE == 1 ? yy[k] > 0.f
+                                                : (GATE == 3 ? ((bits >> k) & 1u) != 0u : fmaf(xx[k], gsc[k], gsh[k]) > 0.f));
                 const float g = open ? v[k] : 0.f;
                 s1[k] += g;
                 s2[k] = fmaf(g, (xx[k] - mean[k]) * invstd[k], s2[k]);
@@ -195,7 +199,8 @@ __global__ __launch_bounds__(256) void bnh_apply_kernel(const unsigned short* __
                                                         unsigned short* __restrict__ y, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta,
                                                         const float* __restrict__ save_mean,
-                                                        const float* __restrict__ save_invstd, long long M, int C)
+                                                        const float* __restrict__ save_invstd, long long M, int C,
+                                                        unsigned char* __restrict__ mask)   // optional [M][C/8]: y > 0 bits
 {
     const int G = C >> 3, RPP = 256 / G;
     const int cg = threadIdx.x % G, rsub = threadIdx.x / G;
@@ -211,14 +216,17 @@ __global__ __launch_bounds__(256) void bnh_apply_kernel(const unsigned short* __
         float v[8], rr[8];
         bnh_load8(x + off, v);
         if (RES) bnh_load8(res + off, rr);
+        unsigned bits = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             float o = fmaf(v[k], scale[k], shift[k]);
             if (RES) o += rr[k];
             if (RELU) o = o > 0.f ? o : 0.f;
+            bits |= (o > 0.f ? 1u : 0u) << k;
             v[k] = o;
         }
         bnh_store8(y + off, v);
+        if (mask) mask[(size_t)r * G + cg] = (unsigned char)bits;
     }
 }
 
@@ -253,10 +261,13 @@ __global__ __launch_bounds__(256) void bnh_bwd_apply_kernel(
         float g[8], yy[8], xx[8];
         bnh_load8(dy + off, g);
         if (GATE == 1) bnh_load8(y + off, yy);
+        unsigned bits = 0;
+        if (GATE == 3) bits = reinterpret_cast<const unsigned char*>(y)[(size_t)r * G + cg];
         bnh_load8(x + off, xx);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const bool open = GATE == 0 || (GATE == 1 ? yy[k] > 0.f : fmaf(xx[k], k0[k], gsh[k]) > 0.f);
+            const bool open = GATE == 0 || (GATE == 1 ? yy[k] > 0.f
+                                            : (GATE == 3 ? ((bits >> k) & 1u) != 0u : fmaf(xx[k], k0[k], gsh[k]) > 0.f));
             const float gg = open ? g[k] : 0.f;
             g[k] = gg;
             xx[k] = k0[k] * (gg - mg[k] - (xx[k] - mean[k]) * invstd[k] * mgx[k]);
@@ -320,7 +331,7 @@ extern "C" int hiast_bn_nhwc_stats_from_partial(const float* partial, int nblk, 
 extern "C" int hiast_bn_nhwc_apply(const void* x, const void* res, void* y, const float* gamma, const float* beta,
                                    float* running_mean, float* running_var, const double* sums, double count,
                                    float momentum, float eps, int relu, float* save_mean, float* save_invstd,
-                                   int64_t M, int C, hiast_stream_t stream)
+                                   int64_t M, int C, void* mask, hiast_stream_t stream)
 {
     int e = bnh_check(x, M, C);
     if (e) return e;
@@ -336,7 +347,7 @@ extern "C" int hiast_bn_nhwc_apply(const void* x, const void* res, void* y, cons
 #define L(RES, RELU)                                                                                              \
     hipLaunchKernelGGL((hiast::bnh_apply_kernel<RES, RELU>), dim3((unsigned)nb), dim3(256), 0, st,                 \
                        (const unsigned short*)x, (const unsigned short*)res, (unsigned short*)y, gamma, beta,      \
-                       save_mean, save_invstd, (long long)M, C)
+                       save_mean, save_invstd, (long long)M, C, (unsigned char*)mask)
     if (res) { if (relu) L(true, true); else L(true, false); }
     else { if (relu) L(false, true); else L(false, false); }
 #undef L
@@ -349,7 +360,7 @@ extern "C" int hiast_bn_nhwc_apply(const void* x, const void* res, void* y, cons
 extern "C" int hiast_bn_nhwc_apply_partial(const void* x, const void* res, void* y, const float* gamma, const float* beta,
                                            float* running_mean, float* running_var, const float* partial, int nblk,
                                            double count, float momentum, float eps, int relu, float* save_mean,
-                                           float* save_invstd, int64_t M, int C, hiast_stream_t stream)
+                                           float* save_invstd, int64_t M, int C, void* mask, hiast_stream_t stream)
 {
     int e = bnh_check(x, M, C);
     if (e) return e;
@@ -365,7 +376,7 @@ extern "C" int hiast_bn_nhwc_apply_partial(const void* x, const void* res, void*
 #define L(RES, RELU)                                                                                              \
     hipLaunchKernelGGL((hiast::bnh_apply_kernel<RES, RELU>), dim3((unsigned)nb), dim3(256), 0, st,                 \
                        (const unsigned short*)x, (const unsigned short*)res, (unsigned short*)y, gamma, beta,      \
-                       save_mean, save_invstd, (long long)M, C)
+                       save_mean, save_invstd, (long long)M, C, (unsigned char*)mask)
     if (res) { if (relu) L(true, true); else L(true, false); }
     else { if (relu) L(false, true); else L(false, false); }
 #undef L
@@ -380,8 +391,8 @@ extern "C" int hiast_bn_nhwc_bwd_stats(const void* dy, const void* y, const void
 {
     int e = bnh_check(x, M, C);
     if (e) return e;
-    if (!dy || !save_mean || !save_invstd || !sums || !workspace || (relu == 1 && !y)) return HIAST_E_ARG;
-    if (relu < 0 || relu > 2 || ((((uintptr_t)dy) | ((uintptr_t)y)) & 15)) return HIAST_E_RANGE;
+    if (!dy || !save_mean || !save_invstd || !sums || !workspace || ((relu == 1 || relu == 3) && !y)) return HIAST_E_ARG;
+    if (relu < 0 || relu > 3 || (((uintptr_t)dy) & 15) || (relu == 1 && (((uintptr_t)y) & 15))) return HIAST_E_RANGE;
     const int nblk = hiast::bnh_nblk(M, C);
     if (workspace_bytes < (size_t)nblk * C * 2 * sizeof(float)) return HIAST_E_WS;
     hipStream_t st = (hipStream_t)stream;
@@ -389,7 +400,7 @@ extern "C" int hiast_bn_nhwc_bwd_stats(const void* dy, const void* y, const void
     hipLaunchKernelGGL((hiast::bnh_partial_kernel<true, G>), dim3(nblk), dim3(256), 0, st, (const unsigned short*)dy, \
                        (const unsigned short*)y, (const unsigned short*)x, gamma, beta, save_mean, save_invstd,      \
                        (long long)M, C, (float*)workspace)
-    if (relu == 1) L(1); else if (relu == 2) L(2); else L(0);
+    if (relu == 1) L(1); else if (relu == 2) L(2); else if (relu == 3) L(3); else L(0);
 #undef L
     HIAST_CHECK_LAUNCH();
     hipLaunchKernelGGL(hiast::bnh_finalize_kernel, dim3(C * 2 / 16), dim3(256), 0, st, (const float*)workspace, nblk, C,
@@ -406,8 +417,10 @@ extern "C" int hiast_bn_nhwc_bwd_apply(const void* dy, const void* y, const void
 {
     int e = bnh_check(x, M, C);
     if (e) return e;
-    if (!dy || !save_mean || !save_invstd || !sums || !dx || (relu == 1 && !y) || count <= 0) return HIAST_E_ARG;
-    if (relu < 0 || relu > 2 || ((((uintptr_t)dy) | ((uintptr_t)y) | ((uintptr_t)dx) | ((uintptr_t)dres)) & 15))
+    if (!dy || !save_mean || !save_invstd || !sums || !dx || ((relu == 1 || relu == 3) && !y) || count <= 0)
+        return HIAST_E_ARG;
+    if (relu < 0 || relu > 3 || ((((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)dres)) & 15) ||
+        (relu == 1 && (((uintptr_t)y) & 15)))
         return HIAST_E_RANGE;
     const int rpp = 256 / (C / 8);
     long long nb = (M + (long long)rpp * 8 - 1) / ((long long)rpp * 8);
@@ -419,6 +432,7 @@ extern "C" int hiast_bn_nhwc_bwd_apply(const void* dy, const void* y, const void
                        save_mean, save_invstd, sums, 1.0 / count, (unsigned short*)dx, (unsigned short*)dres, dgamma, \
                        dbeta, (long long)M, C)
     if (relu == 1) { if (dres) L(1, true); else L(1, false); }
+    else if (relu == 3) { if (dres) L(3, true); else L(3, false); }
     else if (relu == 2) { if (dres) L(2, true); else L(2, false); }
     else { if (dres) L(0, true); else L(0, false); }
 #undef L

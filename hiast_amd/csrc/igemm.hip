@@ -81,8 +81,9 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
     const unsigned short* __restrict__ X, const unsigned short* __restrict__ Wp, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ var, float eps,
     const unsigned short* __restrict__ R, void* __restrict__ Yv, int M, int K, int N, IGeo geo, int dbg,
-    float* __restrict__ stats, const unsigned short* __restrict__ Rg)   // Rg (PL = 1, optional): the residual is gated,
-                                                                          // o += Rg > 0 ? R : 0 (ReLU-masked gradient)           // optional [gridDim m-blocks][N][2]: per-block Σy, Σy² of the STORED values
+    float* __restrict__ stats, const unsigned short* __restrict__ Rg,   // Rg (PL = 1, optional): the residual is gated,
+    int gate_mask)                       // o += gate ? R : 0 (ReLU-masked gradient); gate = Rg > 0 (values like R), or,
+                                         // with gate_mask, bit (n & 7) of byte Rg[m][n / 8]           // optional [gridDim m-blocks][N][2]: per-block Σy, Σy² of the STORED values
 {
     constexpr int WN = BN / 64, WM = 8 / WN;
     constexpr int TM = IG_BM / WM / 32;                 // 32-row tiles per wave (4 | 2 | 1)
@@ -314,7 +315,12 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
                 const size_t g = ig_elem<PL>((size_t)(m < M ? m : 0), nc, N);
                 rh[ps] = *reinterpret_cast<const uint4*>(R + g);
                 if (PL == 2) rl4[ps] = *reinterpret_cast<const uint4*>(R + g + 32);
-                if (PL == 1 && Rg) rl4[ps] = *reinterpret_cast<const uint4*>(Rg + g);     // gate rows ride in rl4
+                if (PL == 1 && Rg) {                                            // gate rows ride in rl4
+                    if (gate_mask)
+                        rl4[ps].x = reinterpret_cast<const unsigned char*>(Rg)[(size_t)(m < M ? m : 0) * (N >> 3) + (nc >> 3)];
+                    else
+                        rl4[ps] = *reinterpret_cast<const uint4*>(Rg + g);
+                }
             }
         }
         if (!M16) {
@@ -353,7 +359,9 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
                         const unsigned wg[4] = {rl4[ps].x, rl4[ps].y, rl4[ps].z, rl4[ps].w};
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const bool g0 = __uint_as_float(wg[q] << 16) > 0.f, g1 = __uint_as_float(wg[q] & 0xFFFF0000u) > 0.f;
+                            const bool g0 = gate_mask ? ((wg[0] >> (2 * q)) & 1u) != 0u : __uint_as_float(wg[q] << 16) > 0.f;
+                            const bool g1 = gate_mask ? ((wg[0] >> (2 * q + 1)) & 1u) != 0u
+                                                      : __uint_as_float(wg[q] & 0xFFFF0000u) > 0.f;
                             wh[q] = (g0 ? wh[q] & 0x0000FFFFu : 0u) | (g1 ? wh[q] & 0xFFFF0000u : 0u);
                         }
                     }
@@ -526,7 +534,7 @@ __global__ __launch_bounds__(256) void from_planes_kernel(const unsigned short* 
 template <int PL, bool OUTF32>
 static int launch_igemm_t(const void* x, const void* wp, const float* gamma, const float* beta, const float* mean,
                           const float* var, float eps, const void* res, int relu, void* y, int64_t M, int K, int N,
-                          int taps, hiast::IGeo geo, float* stats, const void* res_gate, hipStream_t st)
+                          int taps, hiast::IGeo geo, float* stats, const void* res_gate, int gate_mask, hipStream_t st)
 {
     int dbg = 0;
     if (const char* env = getenv("HIAST_IGEMM_DEBUG")) dbg = atoi(env);
@@ -541,7 +549,7 @@ static int launch_igemm_t(const void* x, const void* wp, const float* gamma, con
 #define L(BNV, T, RES, RELU)                                                                                         \
     hipLaunchKernelGGL((hiast::igemm_bn_act_kernel<PL, OUTF32, BNV, T, RES, RELU, MF>), grid, dim3(512), 0, st,       \
                        (const unsigned short*)x, (const unsigned short*)wp, gamma, beta, mean, var, eps,              \
-                       (const unsigned short*)res, y, (int)M, K, N, geo, dbg, stats, (const unsigned short*)res_gate)
+                       (const unsigned short*)res, y, (int)M, K, N, geo, dbg, stats, (const unsigned short*)res_gate, gate_mask)
 #define LL(BNV, T)                                                              \
     if (res) { if (relu) L(BNV, T, true, true); else L(BNV, T, true, false); }  \
     else { if (relu) L(BNV, T, false, true); else L(BNV, T, false, false); }
@@ -566,10 +574,10 @@ static int launch_igemm_t(const void* x, const void* wp, const float* gamma, con
 int hiast_igemm_launch(const void* x, const void* wp, const float* gamma, const float* beta, const float* mean,
                        const float* var, float eps, const void* res, int relu, void* y, int64_t M, int K, int N,
                        int taps, int H, int W, int stride, int dil, int planes, int out_f32, hipStream_t st,
-                       float* stats, const void* res_gate)
+                       float* stats, const void* res_gate, int gate_mask)
 {
     if (stats && (planes != 1 || out_f32)) return HIAST_E_RANGE;
-    if (res_gate && (planes != 1 || !res || (((uintptr_t)res_gate) & 15))) return HIAST_E_RANGE;
+    if (res_gate && (planes != 1 || !res || (!gate_mask && (((uintptr_t)res_gate) & 15)))) return HIAST_E_RANGE;
     if (!x || !wp || !y || (mean && !var)) return HIAST_E_ARG;
     if (M <= 0 || K <= 0 || N <= 0) return HIAST_E_ARG;
     if ((planes != 1 && planes != 2) || (taps != 1 && taps != 9)) return HIAST_E_RANGE;
@@ -588,23 +596,23 @@ int hiast_igemm_launch(const void* x, const void* wp, const float* gamma, const 
     // buffer-descriptor addressing: byte offsets and the out-of-range marker need 31 bits
     if (in_pix * planes * K * 2 >= (1ull << 31) || (size_t)N * taps * planes * K * 2 >= (1ull << 31)) return HIAST_E_RANGE;
     if (planes == 2) {
-        if (out_f32) return launch_igemm_t<2, true>(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, stats, res_gate, st);
-        return launch_igemm_t<2, false>(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, stats, res_gate, st);
+        if (out_f32) return launch_igemm_t<2, true>(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, stats, res_gate, gate_mask, st);
+        return launch_igemm_t<2, false>(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, stats, res_gate, gate_mask, st);
     }
-    if (out_f32) return launch_igemm_t<1, true>(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, stats, res_gate, st);
-    return launch_igemm_t<1, false>(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, stats, res_gate, st);
+    if (out_f32) return launch_igemm_t<1, true>(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, stats, res_gate, gate_mask, st);
+    return launch_igemm_t<1, false>(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, stats, res_gate, gate_mask, st);
 }
 
 extern "C" int hiast_igemm_bn_act(const void* x, const void* wp, const float* gamma, const float* beta,
                                   const float* mean, const float* var, float eps, const void* res, int relu, void* y,
                                   int B, int H, int W, int Cin, int Cout, int taps, int stride, int dil, int planes,
-                                  int out_f32, float* stats, const void* res_gate, hiast_stream_t stream)
+                                  int out_f32, float* stats, const void* res_gate, int gate_mask, hiast_stream_t stream)
 {
     if (B <= 0 || H <= 0 || W <= 0) return HIAST_E_ARG;
     if (taps == 1 && stride != 1) return HIAST_E_RANGE;       // strided 1x1: subsample the input first
     const int Ho = taps == 1 ? H : (H - 1) / stride + 1, Wo = taps == 1 ? W : (W - 1) / stride + 1;
     return hiast_igemm_launch(x, wp, gamma, beta, mean, var, eps, res, relu, y, (int64_t)B * Ho * Wo, Cin, Cout, taps, H,
-                              W, stride, dil, planes, out_f32, (hipStream_t)stream, stats, res_gate);
+                              W, stride, dil, planes, out_f32, (hipStream_t)stream, stats, res_gate, gate_mask);
 }
 
 extern "C" int hiast_pack_conv_weight(const float* w, int N, int K, int taps, int planes, int transpose, void* wp,

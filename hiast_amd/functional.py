@@ -209,24 +209,30 @@ class _BnActNhwcFn(torch.autograd.Function):
     def forward(ctx, x, res, gamma, beta, running_mean, running_var, momentum, eps, relu, world, partial, box):
         # batch statistics: from the producing convolution's epilogue when it delivered them, else one pass over x
         count = float(x.shape[0] * x.shape[2] * x.shape[3])
+        # ReLU gate of the backward: recomputed from x when there is no residual input; with a residual the forward
+        # writes a bit mask (1/16 of y's bytes) that both backward passes (and the identity hand-off) read instead of y
+        ctx.gate = 0 if not relu else (3 if res is not None else 2)
+        if ctx.gate == 3 and os.environ.get("HIAST_NO_BN_MASK", "0") == "1":
+            ctx.gate = 1                                # A/B switch: gate read from y itself
+        want_mask = ctx.gate == 3
         if world == 1 and partial is not None:      # no all-reduce point: statistics + apply straight from the partials
-            y, sm, si = K.bn_nhwc_apply_partial(x, res, gamma, beta, running_mean, running_var, partial, count, momentum,
-                                                eps, relu)
+            out = K.bn_nhwc_apply_partial(x, res, gamma, beta, running_mean, running_var, partial, count, momentum, eps,
+                                          relu, want_mask)
         else:
             sums = K.bn_nhwc_stats_from_partial(partial) if partial is not None else K.bn_nhwc_stats(x)
             if world > 1:      # SyncBN: one all-reduce of [C,2] double sums
                 import torch.distributed as dist
                 dist.all_reduce(sums)
                 count *= world
-            y, sm, si = K.bn_nhwc_apply(x, res, gamma, beta, running_mean, running_var, sums, count, momentum, eps, relu)
-        # ReLU gate of the backward: recomputed from x when there is no residual input (y is then not read again)
-        ctx.gate = 0 if not relu else (1 if res is not None else 2)
-        ctx.save_for_backward(x, y if ctx.gate == 1 else None, gamma, beta, sm, si)
+            out = K.bn_nhwc_apply(x, res, gamma, beta, running_mean, running_var, sums, count, momentum, eps, relu,
+                                  want_mask)
+        y, sm, si = out[:3]
+        ctx.save_for_backward(x, out[3] if want_mask else (y if ctx.gate == 1 else None), gamma, beta, sm, si)
         ctx.has_res, ctx.world, ctx.count = res is not None, world, count
         # identity-branch hand-off (see Bottleneck.forward): when the block's first convolution has announced that its
         # data-gradient epilogue will add the ReLU-masked gradient of the identity branch itself, this backward
         # neither writes that masked copy (dres) nor returns it for autograd to add
-        ctx.box = box if (box is not None and box.get("armed") and ctx.gate == 1) else None
+        ctx.box = box if (box is not None and box.get("armed") and ctx.gate in (1, 3)) else None
         return y
 
     @staticmethod
@@ -244,7 +250,7 @@ class _BnActNhwcFn(torch.autograd.Function):
         dx, dres, dg, db = K.bn_nhwc_bwd_apply(dy, y, x, gamma, beta, sm, si, sums, ctx.count, ctx.gate,
                                                ctx.has_res and ctx.needs_input_grad[1] and not handoff, want_p)
         if handoff:
-            ctx.box["gated"] = (dy, y)            # consumed by the block's conv1 backward
+            ctx.box["gated"] = (dy, y)            # (gradient, bit mask): consumed by the block's conv1 backward
         return (dx, dres, dg if ctx.needs_input_grad[2] else None, db if ctx.needs_input_grad[3] else None,
                 None, None, None, None, None, None, None, None)
 
@@ -295,7 +301,8 @@ class _ConvNhwcFn(torch.autograd.Function):
             gated = ctx.box.pop("gated", None) if ctx.box is not None else None
             if gated is not None:      # + dy_block * (y_block > 0): the identity branch's gradient, in the epilogue
                 dx = K.igemm_bn_act(dy.permute(0, 2, 3, 1), wpt, 1, None, gated[0].permute(0, 2, 3, 1), False, 1, dil,
-                                    res_gate=gated[1].permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+                                    res_gate=(gated[1] if gated[1].dtype == torch.uint8
+                                              else gated[1].permute(0, 2, 3, 1))).permute(0, 3, 1, 2)
             else:
                 dx = K.igemm_bn_act(dy.permute(0, 2, 3, 1), wpt, 1, None, None, False, 1, dil).permute(0, 3, 1, 2)
         own_w = need_w and os.environ.get("HIAST_LIB_WGRAD", "0") != "1" and K.conv_wgrad_preferred(

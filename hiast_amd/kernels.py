@@ -624,9 +624,16 @@ def igemm_bn_act(x, wp, planes, bn, res, relu, stride=1, dil=1, out_f32=False, w
     if res is not None:
         _req(res, torch.bfloat16, 4, "res")
         assert tuple(res.shape) == tuple(y.shape)
-    if res_gate is not None:        # residual added only where res_gate > 0 (planes = 1)
-        _req(res_gate, torch.bfloat16, 4, "res_gate")
-        assert PL == 1 and res is not None and tuple(res_gate.shape) == tuple(res.shape)
+    gate_mask = 0
+    if res_gate is not None:        # residual added only where the gate is open (planes = 1)
+        assert PL == 1 and res is not None
+        if res_gate.dtype == torch.uint8:        # bit mask [M, Cout/8] from bn_nhwc_apply(..., want_mask=True)
+            _req(res_gate, torch.uint8, 2, "res_gate")
+            assert tuple(res_gate.shape) == (B * Ho * Wo, N // 8)
+            gate_mask = 1
+        else:                                    # values: gate = res_gate > 0
+            _req(res_gate, torch.bfloat16, 4, "res_gate")
+            assert tuple(res_gate.shape) == tuple(res.shape)
     if bn is not None:
         g, b, mu, var, eps = _bn_params(bn)
     else:
@@ -638,7 +645,7 @@ def igemm_bn_act(x, wp, planes, bn, res, relu, stride=1, dil=1, out_f32=False, w
         partial = torch.empty(((B * Ho * Wo + 255) // 256, N, 2), dtype=torch.float32, device=x.device)
     check(_lib.load().hiast_igemm_bn_act(_ptr(x), _ptr(wp), g, b, mu, var, eps, _ptr(res), int(bool(relu)), _ptr(y),
                                          B, H, W, Cin, N, taps, int(stride), int(dil), PL, int(bool(out_f32)),
-                                         _ptr(partial), _ptr(res_gate), _stream()), "hiast_igemm_bn_act")
+                                         _ptr(partial), _ptr(res_gate), gate_mask, _stream()), "hiast_igemm_bn_act")
     return (y, partial) if want_stats else y
 
 
@@ -694,9 +701,11 @@ def bn_nhwc_stats_from_partial(partial):
     return sums
 
 
-def bn_nhwc_apply(x, res, gamma, beta, running_mean, running_var, sums, count, momentum, eps, relu):
+def bn_nhwc_apply(x, res, gamma, beta, running_mean, running_var, sums, count, momentum, eps, relu, want_mask=False):
+    """-> (y, save_mean, save_invstd[, mask u8 [M, C/8]: bits y > 0])"""
     xv, M, C = _bnh_view(x, "x")
     y = torch.empty_like(x, memory_format=torch.channels_last)
+    mask = torch.empty((M, C // 8), dtype=torch.uint8, device=x.device) if want_mask else None
     rv = None
     if res is not None:
         rv, M2, C2 = _bnh_view(res, "res")
@@ -706,13 +715,16 @@ def bn_nhwc_apply(x, res, gamma, beta, running_mean, running_var, sums, count, m
     si = torch.empty(C, dtype=torch.float32, device=x.device)
     check(_lib.load().hiast_bn_nhwc_apply(_ptr(xv), _ptr(rv), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(running_mean),
                                           _ptr(running_var), _ptr(sums), float(count), float(momentum), float(eps),
-                                          int(bool(relu)), _ptr(sm), _ptr(si), M, C, _stream()), "hiast_bn_nhwc_apply")
-    return y, sm, si
+                                          int(bool(relu)), _ptr(sm), _ptr(si), M, C, _ptr(mask), _stream()),
+          "hiast_bn_nhwc_apply")
+    return (y, sm, si, mask) if want_mask else (y, sm, si)
 
 
-def bn_nhwc_apply_partial(x, res, gamma, beta, running_mean, running_var, partial, count, momentum, eps, relu):
+def bn_nhwc_apply_partial(x, res, gamma, beta, running_mean, running_var, partial, count, momentum, eps, relu,
+                          want_mask=False):
     """single-rank forward from per-block partial sums [nblk,C,2] (igemm_bn_act(..., want_stats=True))"""
     xv, M, C = _bnh_view(x, "x")
+    mask = torch.empty((M, C // 8), dtype=torch.uint8, device=x.device) if want_mask else None
     _req(partial, torch.float32, 3, "partial")
     assert partial.shape[1] == C and partial.shape[2] == 2
     y = torch.empty_like(x, memory_format=torch.channels_last)
@@ -722,16 +734,17 @@ def bn_nhwc_apply_partial(x, res, gamma, beta, running_mean, running_var, partia
     check(_lib.load().hiast_bn_nhwc_apply_partial(_ptr(xv), _ptr(rv), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(running_mean),
                                                   _ptr(running_var), _ptr(partial), partial.shape[0], float(count),
                                                   float(momentum), float(eps), int(bool(relu)), _ptr(sm), _ptr(si), M, C,
-                                                  _stream()), "hiast_bn_nhwc_apply_partial")
-    return y, sm, si
+                                                  _ptr(mask), _stream()), "hiast_bn_nhwc_apply_partial")
+    return (y, sm, si, mask) if want_mask else (y, sm, si)
 
 
 def bn_nhwc_bwd_stats(dy, y, x, gamma, beta, save_mean, save_invstd, gate):
-    """gate: 0 = no ReLU, 1 = y > 0 (reads y), 2 = recomputed from x (forward without residual; y unused)"""
+    """gate: 0 = no ReLU, 1 = y > 0 (reads y), 2 = recomputed from x (forward without residual; y unused),
+    3 = y is the bit mask u8 [M, C/8] the forward wrote"""
     xv, M, C = _bnh_view(x, "x")
     dv, M2, C2 = _bnh_view(dy, "dy")
     assert (M2, C2) == (M, C)
-    yv = _bnh_view(y, "y")[0] if gate == 1 else None
+    yv = _bnh_view(y, "y")[0] if gate == 1 else (_req(y, torch.uint8, 2, "mask") if gate == 3 else None)
     sums = torch.empty((C, 2), dtype=torch.float64, device=x.device)
     ws = _bnh_workspace(C, x.device)
     check(_lib.load().hiast_bn_nhwc_bwd_stats(_ptr(dv), _ptr(yv), _ptr(xv), _ptr(gamma), _ptr(beta), _ptr(save_mean),
@@ -743,7 +756,7 @@ def bn_nhwc_bwd_stats(dy, y, x, gamma, beta, save_mean, save_invstd, gate):
 def bn_nhwc_bwd_apply(dy, y, x, gamma, beta, save_mean, save_invstd, sums, count, gate, want_dres, want_dparam):
     xv, M, C = _bnh_view(x, "x")
     dv = _bnh_view(dy, "dy")[0]
-    yv = _bnh_view(y, "y")[0] if gate == 1 else None
+    yv = _bnh_view(y, "y")[0] if gate == 1 else (_req(y, torch.uint8, 2, "mask") if gate == 3 else None)
     dx = torch.empty_like(x, memory_format=torch.channels_last)
     dres = torch.empty_like(x, memory_format=torch.channels_last) if want_dres else None
     dg = torch.empty(C, dtype=torch.float32, device=x.device) if want_dparam else None

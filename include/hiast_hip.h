@@ -229,11 +229,12 @@ int hiast_bn_act_nhwc_infer(const void* x, void* y, const float* gamma, const fl
  * convolution's epilogue (hiast_bn_nhwc_stats_from_partial reduces them) instead of another pass over y.
  * res_gate (planes = 1, with res; may be NULL): like res; the residual is then added only where res_gate > 0 — the data
  * gradient of a bottleneck's first convolution takes the ReLU-masked gradient of the identity branch (dy of the block
- * output, gated by the block output) in its epilogue instead of a masked copy + a separate add. */
+ * output, gated by the block output) in its epilogue instead of a masked copy + a separate add.  gate_mask = 1:
+ * res_gate is the [M][Cout/8] bit mask written by hiast_bn_nhwc_apply instead of a tensor of values. */
 int hiast_igemm_bn_act(const void* x, const void* wp, const float* gamma, const float* beta, const float* mean,
                        const float* var, float eps, const void* res, int relu, void* y, int B, int H, int W, int Cin,
                        int Cout, int taps, int stride, int dil, int planes, int out_f32, float* stats,
-                       const void* res_gate, hiast_stream_t stream);
+                       const void* res_gate, int gate_mask, hiast_stream_t stream);
 int hiast_pack_conv_weight(const float* w, int N, int K, int taps, int planes, int transpose, void* wp, void* wpt,
                            hiast_stream_t stream);
 int hiast_split_planes(float* x, void* planes, int64_t M, int C, int inverse, hiast_stream_t stream);
@@ -261,13 +262,15 @@ int hiast_bn_nhwc_stats_from_partial(const float* partial, int nblk, int C, doub
 int hiast_bn_nhwc_apply_partial(const void* x, const void* res, void* y, const float* gamma, const float* beta,
                                 float* running_mean, float* running_var, const float* partial, int nblk, double count,
                                 float momentum, float eps, int relu, float* save_mean, float* save_invstd, int64_t M,
-                                int C, hiast_stream_t stream);
+                                int C, void* mask, hiast_stream_t stream);
 int hiast_bn_nhwc_apply(const void* x, const void* res, void* y, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, const double* sums, double count, float momentum,
-                        float eps, int relu, float* save_mean, float* save_invstd, int64_t M, int C,
+                        float eps, int relu, float* save_mean, float* save_invstd, int64_t M, int C, void* mask,
                         hiast_stream_t stream);
-/* relu: 0 = no ReLU in the forward, 1 = gate y > 0 read from y, 2 = gate recomputed as x*scale + shift > 0 (only
- * when the forward had NO residual input; y may be NULL and is not read) */
+/* apply: mask (may be NULL) receives the bits y > 0, [M][C/8] bytes (bit k of byte (m, g) = channel 8g + k).
+ * relu of the backward calls: 0 = no ReLU in the forward, 1 = gate y > 0 read from y, 2 = gate recomputed as
+ * x*scale + shift > 0 (only when the forward had NO residual input; y may be NULL and is not read), 3 = y points to the
+ * bit mask written by the forward (1/16 of y's bytes) */
 int hiast_bn_nhwc_bwd_stats(const void* dy, const void* y, const void* x, const float* gamma, const float* beta,
                             const float* save_mean, const float* save_invstd, int relu, int64_t M, int C, double* sums,
                             void* workspace, size_t workspace_bytes, hiast_stream_t stream);
