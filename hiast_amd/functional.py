@@ -1,7 +1,8 @@
 """torch.autograd bindings of the HIP kernels (one C-ABI call per forward / backward).
 
-CUDA(HIP) tensors only.  Autocast: inputs are taken in fp32 (the reference's losses and the
-pseudo-label path are fp32 even under apex O1; the ASPP head is computed in exact fp32 MFMA).
+CUDA(HIP) tensors only.  Autocast: the losses and the pseudo-label kernels take fp32 inputs (as in the reference
+even under apex O1); the ASPP head and the trunk convolutions / BatchNorms run in bf16 on channels-last activations
+under bf16 autocast (_Aspp2Fn, _ConvNhwcFn, _BnActNhwcFn) and in fp32 otherwise (_AsppFn, _BnActFn).
 """
 import os
 
