@@ -35,6 +35,25 @@ __global__ __launch_bounds__(256) void ema_kernel(const hiast_ema_rec* __restric
     }
 }
 
+// K14 — ToTensor + Normalize on the device (reference: transform, sseg/datasets/utils.py:37-55 = torchvision ToTensor
+// then Normalize, executed in the DataLoader workers on float tensors): the workers hand over the uint8 HWC image (4x
+// fewer bytes over PCIe), this kernel writes the normalised float32 CHW tensor.  Arithmetic = torch's, operation for
+// operation (IEEE float division twice), so the result is bit-identical: v = float(u8) / 255;  out = (v - mean) / std.
+__global__ __launch_bounds__(256) void normalize_u8_kernel(const unsigned char* __restrict__ img, float* __restrict__ out,
+                                                           long long HW, float m0, float m1, float m2, float s0, float s1,
+                                                           float s2)
+{
+    const int b = blockIdx.y;
+    const unsigned char* src = img + (size_t)b * HW * 3;
+    float* dst = out + (size_t)b * 3 * HW;
+    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < HW; p += (long long)gridDim.x * 256) {
+        const float r = (float)src[p * 3] / 255.0f, g = (float)src[p * 3 + 1] / 255.0f, bl = (float)src[p * 3 + 2] / 255.0f;
+        dst[p] = (r - m0) / s0;
+        dst[HW + p] = (g - m1) / s1;
+        dst[2 * HW + p] = (bl - m2) / s2;
+    }
+}
+
 // copy a list of small tensors (the BatchNorm buffers the EMA teacher takes over from the student,
 // utils/utils.py:120-123: ~300 tensors of <= 8 KB) in ONE launch: block b copies tensor b.
 __global__ __launch_bounds__(256) void multi_copy_kernel(const hiast_copy_rec* __restrict__ table)
@@ -182,6 +201,20 @@ extern "C" int hiast_multi_copy(const hiast_copy_rec* table, int n_tensors, hias
     if (!table) return HIAST_E_ARG;
     if (n_tensors <= 0) return HIAST_E_ARG;
     hipLaunchKernelGGL(hiast::multi_copy_kernel, dim3(n_tensors), dim3(256), 0, (hipStream_t)stream, table);
+    HIAST_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int hiast_normalize_u8(const uint8_t* img, float* out, int B, int64_t HW, const float* mean, const float* std,
+                                  hiast_stream_t stream)
+{
+    if (!img || !out || !mean || !std) return HIAST_E_ARG;
+    if (B <= 0 || HW <= 0) return HIAST_E_ARG;
+    if (B > 65535) return HIAST_E_RANGE;
+    long long nb = (HW + 256 * 4 - 1) / (256 * 4);
+    nb = nb < 1 ? 1 : (nb > 1024 ? 1024 : nb);
+    hipLaunchKernelGGL(hiast::normalize_u8_kernel, dim3((unsigned)nb, B), dim3(256), 0, (hipStream_t)stream, img, out,
+                       (long long)HW, mean[0], mean[1], mean[2], std[0], std[1], std[2]);
     HIAST_CHECK_LAUNCH();
     return 0;
 }

@@ -345,6 +345,19 @@ def ema_update(plan, gamma):
                                        _stream()), "hiast_ema_update")
 
 
+def normalize_u8(img_u8, mean, std):
+    """uint8 [B,H,W,3] (HWC, as decoded) on the device -> float32 [B,3,H,W]: torchvision ToTensor + Normalize"""
+    _req(img_u8, torch.uint8, 4, "img_u8")
+    B, H, W, three = img_u8.shape
+    assert three == 3 and len(mean) == 3 and len(std) == 3
+    out = torch.empty((B, 3, H, W), dtype=torch.float32, device=img_u8.device)
+    m = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    s_ = (ctypes.c_float * 3)(*[float(v) for v in std])
+    if B:
+        check(_lib.load().hiast_normalize_u8(_ptr(img_u8), _ptr(out), B, H * W, m, s_, _stream()), "hiast_normalize_u8")
+    return out
+
+
 class CopyPlan:
     """device table for copying a fixed list of (small) tensors in one launch"""
 

@@ -69,14 +69,14 @@ class BaseDataset(Dataset):
     def original_get_item(self, index):
         (img, lbl, path), index = self._safe_load(index)
         img, lbl = augmentations.aug(self.aug_fun, img, lbl, index)
-        img, lbl = utils.transform(img, lbl)
+        img, lbl = utils.transform(img, lbl, raw_u8=getattr(self, "device_transform", False))
         return {"images": img, "labels": lbl, "image_paths": path}
 
     def get_item_with_copy_paste(self, index):
         (img, lbl, path), index = self._safe_load(index)
         img, lbl, cp_mask = self.preprocessor.run(img, lbl)
         img, lbl = augmentations.aug(self.aug_fun, img, lbl)
-        img, lbl = utils.transform(img, lbl)
+        img, lbl = utils.transform(img, lbl, raw_u8=getattr(self, "device_transform", False))
         out = {"images": img, "labels": lbl, "image_paths": path}
         if cp_mask is not None:
             out["copy_paste_mask"] = torch.from_numpy(cp_mask).long()

@@ -33,11 +33,19 @@ def _img_to_tensor(img, mean, std):
     return (t - m) / s
 
 
-def transform(img, lbl, mean=MEAN, std=STD):
-    """utils.py:37-55: images normalised float32 CHW, labels int64; lists map element-wise."""
+def transform(img, lbl, mean=MEAN, std=STD, raw_u8=False):
+    """utils.py:37-55: images normalised float32 CHW, labels int64; lists map element-wise.
+    raw_u8: hand the uint8 HWC image over untouched — the consumer normalises it on the device
+    (hiast_normalize_u8: 4x fewer bytes through the worker pipes and over PCIe, same bits)."""
     def one_lbl(x):
         return torch.from_numpy(np.ascontiguousarray(x)).long()
-    img_t = [_img_to_tensor(i, mean, std) for i in img] if isinstance(img, (list, tuple)) else _img_to_tensor(img, mean, std)
+    if raw_u8:
+        def one_img(i):
+            return torch.from_numpy(np.ascontiguousarray(np.asarray(i), dtype=np.uint8))
+    else:
+        def one_img(i):
+            return _img_to_tensor(i, mean, std)
+    img_t = [one_img(i) for i in img] if isinstance(img, (list, tuple)) else one_img(img)
     lbl_t = [one_lbl(l) for l in lbl] if isinstance(lbl, (list, tuple)) else one_lbl(lbl)
     return img_t, lbl_t
 

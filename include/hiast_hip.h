@@ -289,6 +289,13 @@ int hiast_ema_update(const hiast_ema_rec* table, const int32_t* chunk_tensor,
                      const int64_t* chunk_start, int n_chunks, float gamma,
                      float one_minus_gamma, hiast_stream_t stream);
 
+/* ---- K14: ToTensor + Normalize on the device ------------------------------------------------------
+ * transform (sseg/datasets/utils.py:37-55: torchvision ToTensor + Normalize in the DataLoader workers): img uint8
+ * [B][H*W][3] (HWC as decoded) -> out float32 [B][3][H*W]; v = float(u8)/255, out = (v - mean[c])/std[c], torch's
+ * operations in torch's order (bit-identical).  mean / std: HOST float[3]. */
+int hiast_normalize_u8(const uint8_t* img, float* out, int B, int64_t HW, const float* mean, const float* std,
+                       hiast_stream_t stream);
+
 /* K11b: copy n_tensors small tensors in one launch (the BatchNorm buffers update_ema_model copies from the student,
  * utils/utils.py:120-123).  table: device array of {dst, src, nbytes}; one block per tensor. */
 typedef struct { void* dst; const void* src; int64_t nbytes; } hiast_copy_rec;

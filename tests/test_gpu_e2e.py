@@ -60,9 +60,13 @@ def test_config2_generator_matches_oracle(world):
     # replay: same model forward on the device for the low-res logits, then the ORACLE for everything else
     st = ias_ref.IASState(C, cfg.pseudo_policy.ias.alpha, cfg.pseudo_policy.ias.beta, cfg.pseudo_policy.ias.gamma, 0.99)
     model = gen.engine.model
+    from hiast_amd.sseg.datasets import utils as du
     for data in gen.t_loader:
+        imgs = data["images"]
+        if imgs.dtype == torch.uint8:      # the generator normalises on the device; the replay uses the HOST transform
+            imgs = torch.stack([du._img_to_tensor(i.numpy(), du.MEAN, du.STD) for i in imgs])
         with torch.no_grad():
-            z = model(data["images"].cuda(), lowres=True)["logits_lowres"].float().cpu().numpy()
+            z = model(imgs.cuda(), lowres=True)["logits_lowres"].float().cpu().numpy()
         mp, am = cref.plabel_stage_a(z, H, W)
         plbl = st.step(mp, am.astype(np.int64), data["image_paths"])
         for b, p in enumerate(data["image_paths"]):

@@ -701,6 +701,20 @@ def test_fused_adam_matches_torch_adam(K):
                               atol=1e-6 * float(sb[k]["exp_avg_sq"].abs().max()))
 
 
+def test_normalize_u8_bit_exact_vs_host_transform(K):
+    """device ToTensor + Normalize == the DataLoader-worker transform (torchvision semantics), bit for bit"""
+    from hiast_amd.sseg.datasets import utils as du
+    r = synth.rng(77)
+    img = r.integers(0, 256, size=(3, 37, 53, 3), dtype=np.uint8)
+    img[0, 0, :8, 0] = [0, 1, 2, 127, 128, 254, 255, 3]
+    got = K.normalize_u8(dev(img), du.MEAN, du.STD).cpu()
+    want = torch.stack([du._img_to_tensor(img[b], du.MEAN, du.STD) for b in range(3)])
+    assert got.dtype == torch.float32 and tuple(got.shape) == (3, 3, 37, 53)
+    assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+    t_img, _ = du.transform(img[1], np.zeros((37, 53), np.uint8), raw_u8=True)
+    assert t_img.dtype == torch.uint8 and tuple(t_img.shape) == (37, 53, 3)
+
+
 def test_ema_bit_exact(K):
     shapes = [(7, 5), (70001,), (3, 2, 3, 3), (64, 2048, 1, 1)]
     e = [synth.normal_f32(70 + i, s) for i, s in enumerate(shapes)]
