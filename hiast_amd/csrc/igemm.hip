@@ -303,26 +303,35 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
     float st1[8], st2[8];                               // BatchNorm statistics of this lane's 8 channels (if asked for)
 #pragma unroll
     for (int q = 0; q < 8; ++q) { st1[q] = 0.f; st2[q] = 0.f; }
+    // residual rows: with one 8-wave block per CU only this wave's own loads hide the HBM latency of the epilogue, so
+    // the rows of chunk a + RD are requested while chunk a goes through its LDS round trip (RD chunks = RD x 4 x 16-byte
+    // loads per lane in flight; 2 for one plane, 1 for split planes where hi and lo double the registers)
+    constexpr int RD = PL == 2 ? 1 : 2;
+    uint4 rhA[TM][4], rlA[TM][4];
+    auto load_res = [&](int a) {
 #pragma unroll
-    for (int a = 0; a < TM; ++a) {
-        // residual rows of this 32-row chunk: all 4 passes' loads are issued BEFORE the LDS round trip, so their
-        // HBM latency overlaps it (with one 8-wave block per CU nothing else would hide it)
-        uint4 rh[4], rl4[4];
-        if (RES) {
-#pragma unroll
-            for (int ps = 0; ps < 4; ++ps) {
-                const int m = m0 + wm * (TM * 32) + a * 32 + ps * 8 + erow;
-                const size_t g = ig_elem<PL>((size_t)(m < M ? m : 0), nc, N);
-                rh[ps] = *reinterpret_cast<const uint4*>(R + g);
-                if (PL == 2) rl4[ps] = *reinterpret_cast<const uint4*>(R + g + 32);
-                if (PL == 1 && Rg) {                                            // gate rows ride in rl4
-                    if (gate_mask)
-                        rl4[ps].x = reinterpret_cast<const unsigned char*>(Rg)[(size_t)(m < M ? m : 0) * (N >> 3) + (nc >> 3)];
-                    else
-                        rl4[ps] = *reinterpret_cast<const uint4*>(Rg + g);
-                }
+        for (int ps = 0; ps < 4; ++ps) {
+            const int m = m0 + wm * (TM * 32) + a * 32 + ps * 8 + erow;
+            const size_t g = ig_elem<PL>((size_t)(m < M ? m : 0), nc, N);
+            rhA[a][ps] = *reinterpret_cast<const uint4*>(R + g);
+            if (PL == 2) rlA[a][ps] = *reinterpret_cast<const uint4*>(R + g + 32);
+            if (PL == 1 && Rg) {                                            // gate rows ride in rlA
+                if (gate_mask)
+                    rlA[a][ps].x = reinterpret_cast<const unsigned char*>(Rg)[(size_t)(m < M ? m : 0) * (N >> 3) + (nc >> 3)];
+                else
+                    rlA[a][ps] = *reinterpret_cast<const uint4*>(Rg + g);
             }
         }
+    };
+    if (RES) {
+#pragma unroll
+        for (int a = 0; a < (RD < TM ? RD : TM); ++a) load_res(a);
+    }
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+        if (RES && a + RD < TM) load_res(a + RD);
+        uint4 (&rh)[4] = rhA[a];
+        uint4 (&rl4)[4] = rlA[a];
         if (!M16) {
 #pragma unroll
             for (int b = 0; b < TN; ++b)
