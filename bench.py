@@ -188,6 +188,8 @@ class HotPath:
             self.ema_updater = utils.EmaUpdater()
             self.side = torch.cuda.Stream(device=device)
         self.use_side = True
+        from hiast_amd import functional as HF
+        HF.enable_wgrad_overlap(True)       # train_step() joins the side stream before the optimiser step
         # synthetic batch, resident on the device (normalised float images: what Dataset.transform emits)
         g = torch.Generator(device="cpu").manual_seed(1234 + rank)
         self.weak = torch.randn(B, 3, H, W, generator=g).to(device)
@@ -220,6 +222,7 @@ class HotPath:
         return plbl
 
     def train_step(self, plbl):
+        from hiast_amd import functional as HF
         self.model.train()
         teacher_lr = None
         main = torch.cuda.current_stream()
@@ -241,6 +244,7 @@ class HotPath:
         g_loss = sum(torch.mean(v) for v in losses.values())
         self.opt.zero_grad(set_to_none=True)
         g_loss.backward()
+        HF.wgrad_stream_join()      # weight gradients of the trunk run on a side stream in single-process runs
         self.opt.step()
         if self.teacher:
             self.ema_updater(self.ema, self.model, self.cfg.cst_training.ema_model.gamma)

@@ -308,21 +308,66 @@ class _ConvNhwcFn(torch.autograd.Function):
                 dx = K.igemm_bn_act(dy.permute(0, 2, 3, 1), wpt, 1, None, None, False, 1, dil).permute(0, 3, 1, 2)
         own_w = need_w and os.environ.get("HIAST_LIB_WGRAD", "0") != "1" and K.conv_wgrad_preferred(
             weight.shape[1], weight.shape[0], k, stride)
-        if own_w:            # transposed-read GEMM over the pixel index (hiast_conv_wgrad_nhwc)
-            dw = K.conv_wgrad_nhwc(dy.permute(0, 2, 3, 1), x.permute(0, 2, 3, 1), k, stride, dil)
-            need_w = False
-        if need_w or lib_x:
-            wl = torch.empty(weight.shape, dtype=torch.bfloat16, device=weight.device)
-            if lib_x:
-                wl = weight.to(torch.bfloat16)
-            gx, gw, _ = torch.ops.aten.convolution_backward(dy, x, wl, None, (stride, stride), (pad, pad), (dil, dil),
-                                                            False, (0, 0), 1, (lib_x, need_w, False))
-            if lib_x:
-                dx = gx
-            if need_w and not own_w:
-                # fp32, NCHW-contiguous like the parameter (DDP's gradient-layout contract): one cast+layout kernel
-                dw = gw.to(dtype=weight.dtype, memory_format=torch.contiguous_format)
+        # The weight gradient is off the critical path of the backward pass (nothing but the optimiser consumes it)
+        # and MFMA-bound, while the BatchNorm backward passes that follow on the main stream are HBM-bound: in a
+        # single-process run it goes to a side stream and co-runs with them (wgrad_stream_join() before the optimiser
+        # step).  Under DDP the reducer reads gradients as soon as autograd delivers them, so it stays on the main stream.
+        side = wgrad_side_stream(x.device) if (need_w and not lib_x) else None
+        main = torch.cuda.current_stream()
+        if side is not None:
+            side.wait_stream(main)
+            dy.record_stream(side)
+            x.record_stream(side)
+        with torch.cuda.stream(side if side is not None else main):
+            if own_w:            # transposed-read GEMM over the pixel index (hiast_conv_wgrad_nhwc)
+                dw = K.conv_wgrad_nhwc(dy.permute(0, 2, 3, 1), x.permute(0, 2, 3, 1), k, stride, dil)
+                need_w = False
+            if need_w or lib_x:
+                wl = torch.empty(weight.shape, dtype=torch.bfloat16, device=weight.device)
+                if lib_x:
+                    wl = weight.to(torch.bfloat16)
+                gx, gw, _ = torch.ops.aten.convolution_backward(dy, x, wl, None, (stride, stride), (pad, pad), (dil, dil),
+                                                                False, (0, 0), 1, (lib_x, need_w, False))
+                if lib_x:
+                    dx = gx
+                if need_w and not own_w:
+                    # fp32, NCHW-contiguous like the parameter (DDP's gradient-layout contract): one cast+layout kernel
+                    dw = gw.to(dtype=weight.dtype, memory_format=torch.contiguous_format)
+        if side is not None and dw is not None:
+            dw.record_stream(main)
         return dx, dw, None, None, None, None
+
+
+_wgrad_streams = {}
+_wgrad_overlap = [False]
+
+
+def enable_wgrad_overlap(on=True):
+    """opt in to weight gradients on a side stream.  The caller then owes a wgrad_stream_join() before anything on
+    the main stream reads a .grad (the trainers of this package do: BaseTrainer.update_model, bench.py) and must
+    start every backward with .grad = None (zero_grad(set_to_none=True)): autograd then only stores the tensor."""
+    _wgrad_overlap[0] = bool(on)
+
+
+def wgrad_side_stream(device):
+    """the side stream weight gradients run on, or None (not enabled / DDP / HIAST_NO_WGRAD_STREAM=1)"""
+    if not _wgrad_overlap[0] or os.environ.get("HIAST_NO_WGRAD_STREAM", "0") == "1":
+        return None
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return None
+    st = _wgrad_streams.get(device)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _wgrad_streams[device] = st
+    return st
+
+
+def wgrad_stream_join():
+    """make the current stream wait for every weight gradient issued on a side stream (call before optimizer.step()
+    or before reading .grad)"""
+    for st in _wgrad_streams.values():
+        torch.cuda.current_stream(st.device).wait_stream(st)
 
 
 def conv_nhwc_ok(x, conv):

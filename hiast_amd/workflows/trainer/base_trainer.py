@@ -8,6 +8,8 @@ import os
 import numpy as np
 import torch
 import torch.distributed as dist
+
+from hiast_amd import functional as HF
 from torch.nn.parallel import DistributedDataParallel as DDP
 from torch.utils.data import DataLoader, DistributedSampler
 
@@ -151,7 +153,12 @@ class BaseTrainer:
         """base_trainer.py:127-141: g_loss = Σ mean(loss_i); bf16 autocast needs no loss scaling"""
         g_loss = sum(torch.mean(v) for k, v in losses.items() if "D_" not in k)
         g_optimizer.zero_grad(set_to_none=True)
-        g_loss.backward()
+        HF.enable_wgrad_overlap(True)
+        try:
+            g_loss.backward()
+        finally:
+            HF.enable_wgrad_overlap(False)
+        HF.wgrad_stream_join()      # single-process runs issue the trunk's weight gradients on a side stream
         g_optimizer.step()
 
     def train(self):

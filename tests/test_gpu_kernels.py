@@ -567,6 +567,30 @@ def test_conv_nhwc_autograd_vs_fp64(K, cfg, monkeypatch):
     assert torch.allclose(s_ep, s_pass, rtol=1e-5, atol=1e-3)
 
 
+def test_wgrad_side_stream_gives_identical_gradients(K):
+    """weight gradients issued on the side stream (single-process trainers) == the main-stream ones after the join"""
+    from hiast_amd import functional as HF
+    from hiast_amd.sseg.models.modules.resnet import Bottleneck
+    torch.manual_seed(1)
+    blk = Bottleneck(512, 256, 1, 2).cuda().train()          # 256/512/1024-channel 1x1s: the own weight-gradient kernel
+    x0 = _cl(dev(_bf16r(synth.normal_f32(960, (2, 1024, 16, 24)))).bfloat16())
+    gy = _cl(dev(_bf16r(synth.normal_f32(961, (2, 1024, 16, 24)))).bfloat16())
+    blk = Bottleneck(1024, 256, 1, 2).cuda().train()
+    grads = []
+    for overlap in (False, True):
+        blk.zero_grad(set_to_none=True)
+        HF.enable_wgrad_overlap(overlap)
+        try:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = blk(x0.clone().requires_grad_(True) * 1.0)
+            y.backward(gy)
+        finally:
+            HF.enable_wgrad_overlap(False)
+        HF.wgrad_stream_join()
+        grads.append([blk.conv1.weight.grad.clone(), blk.conv3.weight.grad.clone()])
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])   # own kernel: deterministic
+
+
 def test_bottleneck_identity_handoff_matches_autograd_add(K, monkeypatch):
     """identity block, channels-last training path: the gradient of the identity branch added in conv1's data-gradient
     epilogue (gated by the block output) vs the plain autograd formulation (masked copy + add kernel)"""
