@@ -69,6 +69,7 @@ __global__ __launch_bounds__(512) void wgrad_tn_kernel(const unsigned short* __r
     const int oy = TAPS == 1 ? 0 : (tap / 3 - 1) * geo.dil, ox = TAPS == 1 ? 0 : (tap % 3 - 1) * geo.dil;
 
     constexpr int OOB = (int)0x80000000;
+    const float inv_hw = 1.0f / (float)(geo.Ho * geo.Wo), inv_wo = 1.0f / (float)geo.Wo;
     const size_t in_pix = (TAPS == 1) ? (size_t)M : (size_t)(M / (geo.Ho * geo.Wo)) * geo.H * geo.W;
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)dY, 0, (int)((size_t)M * N * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)(in_pix * K * 2), 0x00020000);
@@ -91,9 +92,17 @@ __global__ __launch_bounds__(512) void wgrad_tn_kernel(const unsigned short* __r
                 if (TAPS == 1) {
                     voff = (int)(((size_t)m * K + k0 + (sub - 2) * 128) * 2) + ch * 16;
                 } else {
+                    // (image, row, column) of output pixel m without integer divisions (they were ~300 VALU per
+                    // k-step and wave, more than its MFMA time): float reciprocal + one-step correction, exact for
+                    // m < 2^24
                     const int hw = geo.Ho * geo.Wo;
-                    const int img = m / hw, r = m - img * hw;
-                    const int yy = (r / geo.Wo) * geo.stride + oy, xx = (r % geo.Wo) * geo.stride + ox;
+                    int img = (int)(((float)m + 0.5f) * inv_hw);
+                    int r = m - img * hw;
+                    if (r < 0) { --img; r += hw; } else if (r >= hw) { ++img; r -= hw; }
+                    int yo = (int)(((float)r + 0.5f) * inv_wo);
+                    int xo = r - yo * geo.Wo;
+                    if (xo < 0) { --yo; xo += geo.Wo; } else if (xo >= geo.Wo) { ++yo; xo -= geo.Wo; }
+                    const int yy = yo * geo.stride + oy, xx = xo * geo.stride + ox;
                     if (yy >= 0 && yy < geo.H && xx >= 0 && xx < geo.W)
                         voff = (int)((((size_t)(img * geo.H + yy) * geo.W + xx) * K + k0 + (sub - 2) * 128) * 2) + ch * 16;
                 }
@@ -188,10 +197,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
-static int wgrad_nsplit(long long M, int tiles)
+static int wgrad_nsplit(long long M, int tiles, int taps)
 {
-    // ~2 blocks per CU in total, at least 8 k-steps (512 pixels) per block
-    long long s = (512 + tiles - 1) / tiles;
+    // ~1-2 blocks per CU in total, at least 8 k-steps (512 pixels) per block
+    long long s = (tiles >= 8 && taps == 1) ? (256 + tiles - 1) / tiles : (512 + tiles - 1) / tiles;
     const long long smax = M / 512 > 0 ? M / 512 : 1;
     s = s < 1 ? 1 : (s > smax ? smax : s);
     s = s > 64 ? 64 : s;
@@ -205,7 +214,7 @@ extern "C" size_t hiast_conv_wgrad_workspace_bytes(int B, int Ho, int Wo, int Ci
     if (B <= 0 || Ho <= 0 || Wo <= 0 || Cin % 256 != 0 || Cout % 256 != 0 || (taps != 1 && taps != 9)) return 0;
     const long long M = (long long)B * Ho * Wo;
     const int tiles = (Cout / 256) * (Cin / 256) * taps;
-    return (size_t)hiast::wgrad_nsplit(M, tiles) * Cout * taps * Cin * sizeof(float);
+    return (size_t)hiast::wgrad_nsplit(M, tiles, taps) * Cout * taps * Cin * sizeof(float);
 }
 
 extern "C" int hiast_conv_wgrad_nhwc(const void* dy, const void* x, float* dw, int B, int H, int W, int Cin, int Cout,
@@ -218,9 +227,10 @@ extern "C" int hiast_conv_wgrad_nhwc(const void* dy, const void* x, float* dw, i
     if ((((uintptr_t)dy) | ((uintptr_t)x) | ((uintptr_t)dw) | ((uintptr_t)workspace)) & 15) return HIAST_E_RANGE;
     const int Ho = taps == 1 ? H : (H - 1) / stride + 1, Wo = taps == 1 ? W : (W - 1) / stride + 1;
     const long long M = (long long)B * Ho * Wo;
-    if ((size_t)M * Cout * 2 >= (1ull << 31) || (size_t)B * H * W * Cin * 2 >= (1ull << 31)) return HIAST_E_RANGE;
+    if ((size_t)M * Cout * 2 >= (1ull << 31) || (size_t)B * H * W * Cin * 2 >= (1ull << 31) || M >= (1ll << 24))
+        return HIAST_E_RANGE;
     const int tiles = (Cout / 256) * (Cin / 256) * taps;
-    const int nsplit = hiast::wgrad_nsplit(M, tiles);
+    const int nsplit = hiast::wgrad_nsplit(M, tiles, taps);
     if (workspace_bytes < (size_t)nsplit * Cout * taps * Cin * sizeof(float)) return HIAST_E_WS;
     int mps = (int)((M + nsplit - 1) / nsplit);
     mps = ((mps + hiast::WG_ROWS - 1) / hiast::WG_ROWS) * hiast::WG_ROWS;
