@@ -267,6 +267,7 @@ class _ConvNhwcFn(torch.autograd.Function):
     @torch.amp.custom_fwd(device_type="cuda")
     def forward(ctx, x, weight, stride, dil, want_stats, box):
         xv = x.permute(0, 2, 3, 1)
+        ctx.set_materialize_grads(False)     # no zero tensor for the (non-differentiable) statistics output
         ctx.wpt = None
         ctx.box = None
         if box is not None and stride == 1 and ctx.needs_input_grad[0]:
@@ -287,6 +288,8 @@ class _ConvNhwcFn(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dy, _dpartial=None):
+        if dy is None:
+            return None, None, None, None, None, None
         x, weight = ctx.saved_tensors
         stride, dil = ctx.geo
         if dy.dtype != torch.bfloat16:
