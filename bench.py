@@ -103,7 +103,10 @@ class KernelTimer:
         def ig_key(x, wp, planes, bn, res, relu, stride=1, dil=1, out_f32=False, **_kw):
             return ("igemm", tuple(x.shape), tuple(wp.shape), int(planes), int(stride), int(dil), res is not None,
                     bool(out_f32), bn is not None, bool(relu))
+        def aspp2_key(x, wt, bias, dil, workspace=None, planes=None):
+            return ("aspp2_fwd", tuple(x.shape), int(bias.numel()), 2 if planes == 2 else (0 if x.dtype == torch.float32 else 1))
         self.wrap(K, "aspp_fwd", aspp_key)
+        self.wrap(K, "aspp2_fwd", aspp2_key)
         self.wrap(K, "igemm_bn_act", ig_key)
 
     def summary(self):
@@ -133,6 +136,28 @@ def roofline_of(key, avg_ms, n, steps):
                           "algorithmic %.0f MB" % (pj["source"], pj["hbm_bytes_uncorrected"] / 1e6,
                                                    pj["algorithmic_bytes"] / 1e6))
         return d
+    if key[0] == "aspp2_fwd":
+        # whole ASPP head forward (tap GEMM + 33-tap shift-add), the kernel group the north star names
+        shp, Cout, mode = key[1], key[2], key[3]
+        if mode == 2:
+            B, h, w, C2 = shp
+            Cin = C2 // 2
+        else:
+            B, Cin, h, w = shp
+        flop = 2.0 * h * w * Cout * Cin * 36 * B
+        ach = flop / (avg_ms * 1e-3) / 1e12
+        peak = 2500.0 / 3.0 if mode != 1 else 2500.0
+        alg_bytes = B * h * w * Cin * (2 if mode == 1 else 4) + 33 * Cout * Cin * 4 + B * Cout * h * w * 4
+        return {"kernel": "hiast_aspp2_fwd (%s tap GEMM on hiast::igemm_bn_act_kernel + aspp2_shift_add_kernel)"
+                          % ("split-bf16" if mode != 1 else "bf16"),
+                "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                "avg_launch_ms": avg_ms, "launches_per_step": n / steps,
+                "note": "ASPP head forward, %d images: algorithmic %.1f GFLOP (36 taps x %d x %d) and %.0f MB (feature "
+                        "read ONCE + weights + logits) -> %.2f TB/s = %.0f%% of the 8 TB/s HBM peak: arithmetic intensity "
+                        "%.0f FLOP/B puts the head on the MFMA roof, not the HBM roof (SURVEY 7.1); the direct exact-fp32 "
+                        "form it replaced took 1.9 ms" % (B, flop / 1e9, Cout, Cin, alg_bytes / 1e6,
+                                                           alg_bytes / (avg_ms * 1e-3) / 1e12,
+                                                           100.0 * alg_bytes / 8e12 / (avg_ms * 1e-3), flop / alg_bytes)}
     # ("igemm", x [B,H,W,PL*Cin], wp [Cout,taps,PL*Cin], PL, stride, dil, has_res, out_f32)
     B, Hh, Ww, CC = key[1]
     Cout, taps, _ = key[2]
@@ -388,9 +413,11 @@ def main():
         groups = timer.summary()
         if groups:
             sampled = len(range(0, args.steps, 3))      # steps on which launches were timed
+            aspp = [g for g in groups if g[0][0] == "aspp2_fwd"]
+            groups = [g for g in groups if g[0][0] != "aspp2_fwd"]   # (its GEMM is also counted in the igemm groups)
             key, avg_ms, n, _tot = groups[0]            # dominant hand-written launch group of the step
             out["roofline"] = roofline_of(key, avg_ms, n, sampled)
-            others = [roofline_of(k, a, c, sampled) for k, a, c, _ in groups[1:4]]
+            others = [roofline_of(k, a, c, sampled) for k, a, c, _ in groups[1:4] + aspp[:2]]
             out["roofline_other"] = [{kk: o[kk] for kk in ("kernel", "bound", "achieved", "peak", "unit", "frac",
                                                             "traffic", "avg_launch_ms", "launches_per_step", "note")}
                                      for o in others]
