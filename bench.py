@@ -297,10 +297,12 @@ def cpu_baseline(cfg, size, threads):
     with torch.no_grad():
         logits, _, _ = deeplab_ref.segmentor_logits(x, sd)
         pp, lp = torch.softmax(logits, 1).max(1)
+    t_post0 = time.time()
     st = ias_ref.IASState(C, 0.5, 0.9, 8.0)
     plbl = st.step(pp.numpy(), lp.numpy(), ["a.png"])
     # reference's per-pixel threshold map (np.apply_along_axis over rows, pseudo_label_generator.py:74)
     np.apply_along_axis(lambda r: [st.class_threshold[e] for e in r], 1, lp.numpy()[0])
+    t_post = time.time() - t_post0          # the reference's host post-processing: single-threaded Python / numpy
     t_gen = time.time() - t0
     t0 = time.time()
     params = {k: v.requires_grad_(v.dtype.is_floating_point and ".bn" not in k and "downsample.1" not in k)
@@ -318,6 +320,8 @@ def cpu_baseline(cfg, size, threads):
     scale = (H * W) / float(h * w)
     total = (t_gen + t_train) * scale
     return {"value": 1.0 / total, "unit": "images/s", "cores": cores, "kind": "port",
+            "detail_s_per_image": {"eval_forward": (t_gen - t_post) * scale, "ias_post_processing_1_thread": t_post * scale,
+                                   "train_step": t_train * scale},
             "sample": "1 image %dx%d (scaled x%.1f to 1024x512): eval fwd + IAS list/np.quantile post-processing "
                       "%.1fs, teacher fwd + student fwd/bwd + 4-term loss + Adam %.1fs; torch %d threads"
                       % (w, h, scale, t_gen, t_train, cores)}
