@@ -492,6 +492,46 @@ __global__ __launch_bounds__(256) void pack_conv_weight_kernel(const float* __re
     }
 }
 
+// the same for a LIST of weights in one launch (one ResNet trunk = 104 convolutions whose packed forms are rebuilt
+// whenever the optimiser / the EMA update has touched them): block = one 64Ki-element chunk of one tensor
+template <int PL>
+__device__ __forceinline__ void pack_one(const float* __restrict__ w, unsigned short* __restrict__ wp,
+                                         unsigned short* __restrict__ wpt, int N, int K, int taps, int mode, long long idx)
+{
+    const int k = (int)(idx % K);
+    const int t = (int)((idx / K) % taps);
+    const int n = (int)(idx / ((long long)K * taps));
+    const float v = w[((size_t)n * K + k) * taps + t];
+    unsigned short h, l;
+    ig_split(v, h, l);
+    if (mode != 1) {
+        unsigned short* d = wp + ig_wp_elem<PL>(n, t, k, taps, K);
+        d[0] = h;
+        if (PL == 2) d[32] = l;
+    }
+    if (mode != 0) {
+        unsigned short* d = (mode == 1 ? wp : wpt) + ig_wp_elem<PL>(k, taps - 1 - t, n, taps, N);
+        d[0] = h;
+        if (PL == 2) d[32] = l;
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_conv_weight_multi_kernel(const hiast_pack_rec* __restrict__ table,
+                                                                     const int32_t* __restrict__ chunk_tensor,
+                                                                     const int64_t* __restrict__ chunk_start)
+{
+    const hiast_pack_rec r = table[chunk_tensor[blockIdx.x]];
+    const long long total = (long long)r.N * r.K * r.taps;
+    const long long s0 = chunk_start[blockIdx.x];
+    const long long e0 = s0 + 65536 < total ? s0 + 65536 : total;
+    for (long long idx = s0 + threadIdx.x; idx < e0; idx += 256) {
+        if (r.planes == 2)
+            pack_one<2>(r.w, (unsigned short*)r.wp, (unsigned short*)r.wpt, r.N, r.K, r.taps, r.mode, idx);
+        else
+            pack_one<1>(r.w, (unsigned short*)r.wp, (unsigned short*)r.wpt, r.N, r.K, r.taps, r.mode, idx);
+    }
+}
+
 // fp32 [M][C] -> split planes (and back: v = hi + lo, exact in fp32)
 __global__ __launch_bounds__(256) void to_planes_kernel(const float* __restrict__ x, unsigned short* __restrict__ p,
                                                         long long M, int C)
@@ -657,6 +697,17 @@ extern "C" int hiast_split_planes(float* x, void* planes, int64_t M, int C, int 
     else
         hipLaunchKernelGGL(hiast::to_planes_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x,
                            (unsigned short*)planes, (long long)M, C);
+    HIAST_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int hiast_pack_conv_weight_multi(const hiast_pack_rec* table, const int32_t* chunk_tensor,
+                                            const int64_t* chunk_start, int n_chunks, hiast_stream_t stream)
+{
+    if (!table || !chunk_tensor || !chunk_start) return HIAST_E_ARG;
+    if (n_chunks <= 0) return HIAST_E_ARG;
+    hipLaunchKernelGGL(hiast::pack_conv_weight_multi_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, table,
+                       chunk_tensor, chunk_start);
     HIAST_CHECK_LAUNCH();
     return 0;
 }

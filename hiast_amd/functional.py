@@ -265,7 +265,7 @@ class _ConvNhwcFn(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
-    def forward(ctx, x, weight, stride, dil, want_stats, box):
+    def forward(ctx, x, weight, stride, dil, want_stats, box, packed):
         xv = x.permute(0, 2, 3, 1)
         ctx.set_materialize_grads(False)     # no zero tensor for the (non-differentiable) statistics output
         ctx.wpt = None
@@ -273,7 +273,10 @@ class _ConvNhwcFn(torch.autograd.Function):
         if box is not None and stride == 1 and ctx.needs_input_grad[0]:
             box["armed"] = True                    # this conv's backward will take over the identity-branch gradient
             ctx.box = box
-        if stride == 1 and ctx.needs_input_grad[0]:      # forward + adjoint (data-gradient) weight in one pack launch
+        need_adj = stride == 1 and ctx.needs_input_grad[0]
+        if packed is not None and packed[0] is not None and (not need_adj or packed[1] is not None):
+            wp, ctx.wpt = packed                   # kernel-format copies kept current by ResNet.prepack (one launch)
+        elif need_adj:                             # forward + adjoint (data-gradient) weight in one pack launch
             wp, ctx.wpt = K.pack_conv_weight(weight, 1, both=True)
         else:
             wp = K.pack_conv_weight(weight, 1)
@@ -289,7 +292,7 @@ class _ConvNhwcFn(torch.autograd.Function):
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dy, _dpartial=None):
         if dy is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         x, weight = ctx.saved_tensors
         stride, dil = ctx.geo
         if dy.dtype != torch.bfloat16:
@@ -338,7 +341,7 @@ class _ConvNhwcFn(torch.autograd.Function):
                     dw = gw.to(dtype=weight.dtype, memory_format=torch.contiguous_format)
         if side is not None and dw is not None:
             dw.record_stream(main)
-        return dx, dw, None, None, None, None
+        return dx, dw, None, None, None, None, None
 
 
 _wgrad_streams = {}
@@ -388,7 +391,12 @@ def conv_nhwc_ok(x, conv):
 
 def conv_nhwc(x, conv, want_stats=False, box=None):
     """-> y, or (y, partial) with want_stats (see igemm_bn_act); box: identity-branch hand-off of a bottleneck"""
-    return _ConvNhwcFn.apply(x, conv.weight, conv.stride[0], conv.dilation[0], bool(want_stats), box)
+    w = conv.weight
+    fwd = conv.__dict__.get("_hiast_packed", {}).get(1)
+    adj = conv.__dict__.get("_hiast_packed_adj")
+    ok = lambda e: e is not None and e[0] == w._version and e[1] == w.data_ptr()
+    packed = (fwd[2] if ok(fwd) else None, adj[2] if ok(adj) else None)
+    return _ConvNhwcFn.apply(x, w, conv.stride[0], conv.dilation[0], bool(want_stats), box, packed)
 
 
 _nbt_batched = [False]      # set by ResNet.forward while it has already advanced every num_batches_tracked at once

@@ -612,6 +612,54 @@ def pack_conv_weight(weight, planes, transpose=False, both=False):
     return (wp, wpt) if both else wp
 
 
+class PackPlan:
+    """persistent packed copies (forward and, optionally, adjoint) of a fixed list of conv weights, refreshed by ONE
+    launch (hiast_pack_conv_weight_multi) — e.g. the 104 convolutions of a trunk after each optimiser / EMA step"""
+    CHUNK = 65536
+    REC = np.dtype([("w", np.int64), ("wp", np.int64), ("wpt", np.int64), ("N", np.int32), ("K", np.int32),
+                    ("taps", np.int32), ("planes", np.int32), ("mode", np.int32), ("pad", np.int32)])
+
+    def __init__(self, weights, planes, adjoint):
+        """weights: list of fp32 [N,K,kh,kw] parameters; adjoint: list of bool (also keep the data-gradient form)"""
+        assert len(weights) > 0 and len(weights) == len(adjoint)
+        dev = weights[0].device
+        self.weights, self.planes = list(weights), int(planes)
+        self.wp, self.wpt = [], []
+        host = np.zeros(len(weights), dtype=self.REC)
+        ct, cs = [], []
+        for i, (w, adj) in enumerate(zip(weights, adjoint)):
+            _req(w.detach(), torch.float32, 4, "weight")
+            N, K_, kh, kw = w.shape
+            taps = kh * kw
+            wp = torch.empty((N, taps, planes * K_), dtype=torch.bfloat16, device=dev)
+            wpt = torch.empty((K_, taps, planes * N), dtype=torch.bfloat16, device=dev) if adj else None
+            self.wp.append(wp)
+            self.wpt.append(wpt)
+            host[i] = (w.data_ptr(), wp.data_ptr(), wpt.data_ptr() if adj else 0, N, K_, taps, planes, 2 if adj else 0, 0)
+            for s0 in range(0, N * K_ * taps, self.CHUNK):
+                ct.append(i)
+                cs.append(s0)
+        self.ptrs = [w.data_ptr() for w in weights]
+        self.table = torch.from_numpy(host.view(np.uint8).reshape(-1).copy()).to(dev)
+        self.chunk_tensor = torch.tensor(ct, dtype=torch.int32, device=dev)
+        self.chunk_start = torch.tensor(cs, dtype=torch.int64, device=dev)
+        self.n_chunks = len(ct)
+        self.versions = None
+
+    def still_valid(self):
+        return all(w.data_ptr() == p for w, p in zip(self.weights, self.ptrs))
+
+    def refresh(self):
+        """re-pack if any weight has been modified since the last pack; -> True if a launch was made"""
+        v = [w._version for w in self.weights]
+        if v == self.versions:
+            return False
+        check(_lib.load().hiast_pack_conv_weight_multi(_ptr(self.table), _ptr(self.chunk_tensor), _ptr(self.chunk_start),
+                                                       self.n_chunks, _stream()), "hiast_pack_conv_weight_multi")
+        self.versions = v
+        return True
+
+
 def igemm_bn_act(x, wp, planes, bn, res, relu, stride=1, dil=1, out_f32=False, want_stats=False, res_gate=None):
     """x: bf16 [B,H,W,planes*Cin] (planes = 2 split planes | 1 plain bf16); wp from pack_conv_weight (same planes);
     bn: BatchNorm2d in eval mode or None (plain GEMM); res: like the output or None

@@ -138,6 +138,33 @@ class ResNet(nn.Module):
         blocks += [Bottleneck(self.inplanes, planes, 1, dil[1]) for _ in range(1, n)]
         return nn.Sequential(*blocks)
 
+    def prepack(self, PL, adjoint=False):
+        """bring the packed (kernel-format) copies of every bottleneck convolution weight up to date with ONE launch
+        (hiast_pack_conv_weight_multi) — they go stale whenever the optimiser or the EMA update has run — and publish
+        them in the per-module caches packed_weight() / conv_nhwc() look at.  adjoint: also the data-gradient forms."""
+        from hiast_amd import kernels as K
+        plans = self.__dict__.setdefault("_hiast_plans", {})
+        ent = plans.get((PL, adjoint))
+        if ent is None or not ent[0].still_valid():
+            convs = []
+            for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
+                for blk in stage:
+                    convs += [blk.conv1, blk.conv2, blk.conv3] + ([blk.downsample[0]] if blk.downsample is not None else [])
+            convs = [c for c in convs if c.in_channels % 64 == 0 and c.out_channels % 64 == 0 and c.weight.is_cuda]
+            if not convs:
+                return
+            plan = K.PackPlan([c.weight for c in convs], PL, [adjoint and c.stride == (1, 1) for c in convs])
+            ent = (plan, convs)
+            plans[(PL, adjoint)] = ent
+        plan, convs = ent
+        if plan.refresh() or not getattr(plan, "published", False):
+            for i, c in enumerate(convs):
+                w = c.weight
+                c.__dict__.setdefault("_hiast_packed", {})[PL] = (w._version, w.data_ptr(), plan.wp[i])
+                if plan.wpt[i] is not None:
+                    c.__dict__["_hiast_packed_adj"] = (w._version, w.data_ptr(), plan.wpt[i])
+            plan.published = True
+
     def fast_eval_planes(self, x):
         """-> 2 / 1 / 0: inference without autograd on the device runs on the 16-bit channels-last kernels: split
         planes (fp32-class) for an fp32 forward — the pseudo-label pass —, plain bf16 under bf16 autocast — the
@@ -153,6 +180,7 @@ class ResNet(nn.Module):
     def forward_eval_planes(self, x, PL):
         """-> trunk feature as a 16-bit channels-last tensor [B,h,w,PL*2048]"""
         from hiast_amd import kernels as K
+        self.prepack(PL)
         x = x.contiguous(memory_format=torch.channels_last)
         o = self.conv1(x)                 # library 7x7 stem (bf16 output under autocast)
         o = o.contiguous(memory_format=torch.channels_last)
@@ -187,6 +215,8 @@ class ResNet(nn.Module):
         if (x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
                 and os.environ.get("HIAST_TRAIN_NCHW", "0") != "1"):
             # mixed-precision step: the whole trunk runs channels-last (library stem -> bf16 NHWC activations)
+            if self.training and torch.is_grad_enabled():
+                self.prepack(1, adjoint=True)
             x = x.contiguous(memory_format=torch.channels_last)
             x = self.conv1(x).contiguous(memory_format=torch.channels_last)
         else:

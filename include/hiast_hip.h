@@ -238,6 +238,12 @@ int hiast_igemm_bn_act(const void* x, const void* wp, const float* gamma, const 
 int hiast_pack_conv_weight(const float* w, int N, int K, int taps, int planes, int transpose, void* wp, void* wpt,
                            hiast_stream_t stream);
 int hiast_split_planes(float* x, void* planes, int64_t M, int C, int inverse, hiast_stream_t stream);
+/* hiast_pack_conv_weight for a list of weights in ONE launch (a trunk's 104 convolutions after every optimiser / EMA
+ * update).  table: device array of records (mode = the `transpose` argument above); chunk tables as for K11: one
+ * block per 64Ki-element chunk of one weight. */
+typedef struct { const float* w; void* wp; void* wpt; int32_t N, K, taps, planes, mode, pad; } hiast_pack_rec;
+int hiast_pack_conv_weight_multi(const hiast_pack_rec* table, const int32_t* chunk_tensor, const int64_t* chunk_start,
+                                 int n_chunks, hiast_stream_t stream);
 
 /* ---- K9d: weight gradient of the trunk convolutions on channels-last bf16 activations -------------------------
  * autograd of nn.Conv2d in Bottleneck.forward (resnet.py:78-98) under mixed precision:

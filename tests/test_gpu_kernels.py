@@ -739,6 +739,28 @@ def test_normalize_u8_bit_exact_vs_host_transform(K):
     assert t_img.dtype == torch.uint8 and tuple(t_img.shape) == (37, 53, 3)
 
 
+def test_pack_plan_equals_single_packs(K):
+    """the one-launch multi-tensor weight pack == the per-weight packs, forward and adjoint forms, and it refreshes only
+    when a weight's version counter has moved"""
+    ws = [torch.nn.Parameter(dev(synth.normal_f32(1600 + i, shp))) for i, shp in
+          enumerate([(64, 64, 1, 1), (128, 64, 3, 3), (256, 128, 1, 1), (64, 256, 3, 3)])]
+    for PL in (1, 2):
+        plan = K.PackPlan(ws, PL, [True, False, True, True])
+        assert plan.refresh() and not plan.refresh()
+        for i, w in enumerate(ws):
+            assert torch.equal(plan.wp[i], K.pack_conv_weight(w, PL))
+            if plan.wpt[i] is not None:
+                assert torch.equal(plan.wpt[i], K.pack_conv_weight(w, PL, transpose=True))
+            else:
+                assert i == 1
+        with torch.no_grad():
+            ws[2].mul_(2.0)
+        assert plan.refresh()
+        assert torch.equal(plan.wp[2], K.pack_conv_weight(ws[2], PL)) and torch.equal(plan.wp[0], K.pack_conv_weight(ws[0], PL))
+        with torch.no_grad():
+            ws[2].mul_(0.5)
+
+
 def test_ema_bit_exact(K):
     shapes = [(7, 5), (70001,), (3, 2, 3, 3), (64, 2048, 1, 1)]
     e = [synth.normal_f32(70 + i, s) for i, s in enumerate(shapes)]
