@@ -147,6 +147,30 @@ def st_loss(logits_lr, teacher_lr, plbl, size, region="ignored", w_t=1.0, w_k=0.
     return ce, kld, ent, cst
 
 
+class _DInputFn(torch.autograd.Function):
+    """upsample + softmax (+ prob_2_entropy) of LOW-RES logits in one kernel (K15); backward = one kernel
+    recomputing the probabilities + the upsample adjoint."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, logits_lr, H, W, entropy):
+        logits_lr = logits_lr.contiguous()
+        ctx.save_for_backward(logits_lr)
+        ctx.entropy = entropy
+        return K.dinput_fwd(logits_lr, H, W, entropy)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        (logits_lr,) = ctx.saved_tensors
+        return K.dinput_bwd(logits_lr, g.float().contiguous(), ctx.entropy), None, None, None
+
+
+def discriminator_input(logits_lr, size, entropy=False):
+    """D_preprocess_fun(F.interpolate(logits, size)) of adversarial_warmup_segmentor.py:26-29,36,41"""
+    return _DInputFn.apply(logits_lr, int(size[0]), int(size[1]), bool(entropy))
+
+
 def _sync_world(bn):
     import torch.distributed as dist
     if isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized():

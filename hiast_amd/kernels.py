@@ -97,6 +97,34 @@ def plabel_pass2(maxprob, argmax, thr_up, C, count=None, sumprob_fx=None):
     return plbl, count, sumprob_fx
 
 
+# ------------------------------------------------------------------------------- K15 discriminator input
+def dinput_fwd(logits_lr, H, W, entropy):
+    """low-res logits [B,C,h,w] -> softmax (or weighted self-information) map [B,C,H,W] of the upsampled logits"""
+    _req(logits_lr, torch.float32, 4, "logits_lr")
+    B, C, h, w = logits_lr.shape
+    out = torch.empty((B, C, H, W), dtype=torch.float32, device=logits_lr.device)
+    if out.numel():
+        check(_lib.load().hiast_dinput_fwd(_ptr(logits_lr), int(bool(entropy)), _ptr(out), B, C, h, w, H, W, _stream()),
+              "hiast_dinput_fwd")
+    return out
+
+
+def dinput_bwd(logits_lr, gout, entropy):
+    _req(logits_lr, torch.float32, 4, "logits_lr")
+    _req(gout, torch.float32, 4, "gout")
+    B, C, h, w = logits_lr.shape
+    assert tuple(gout.shape[:2]) == (B, C)
+    H, W = gout.shape[2:]
+    d = torch.empty_like(logits_lr)
+    if gout.numel():
+        scratch = torch.empty_like(gout)
+        check(_lib.load().hiast_dinput_bwd(_ptr(logits_lr), int(bool(entropy)), _ptr(gout), _ptr(scratch), _ptr(d),
+                                           B, C, h, w, H, W, _stream()), "hiast_dinput_bwd")
+    else:
+        d.zero_()
+    return d
+
+
 # ------------------------------------------------------------------------------- K5-K8 loss
 REGION = {"ignored": 0, "confident": 1, "all": 2}
 

@@ -5,9 +5,8 @@ on FULL-RES logits [B,C,H,W].  Both go through the fused HIP loss kernel (identi
 the trainers of this package use the low-res fused path (hiast_amd.functional.st_loss) instead
 and never materialise full-res logits.
 
-'MSE', 'KLDIV', 'BCEWithLogits' belong to the adversarial warm-up stage, which is outside the
-self-training hot path; they are registered so that lookups fail with a clear
-message rather than a KeyError."""
+'MSE', 'KLDIV', 'BCEWithLogits' (losses.py:10-30) serve the adversarial warm-up stage; they act on
+the discriminator's B x 1 x H/32 x W/32 maps."""
 import torch
 
 from hiast_amd import functional as HF
@@ -56,12 +55,31 @@ def soft_ce(logits, labels, weights=None, ignore_index=255, refer_labels=None, r
     return loss
 
 
-def _out_of_scope(name):
-    def fn(*a, **k):
-        raise NotImplementedError("LOSS[%r] belongs to the adversarial warm-up stage, which is outside the "
-                                  "self-training hot path implemented here" % name)
-    return fn
+def _plain(name, refer_labels):
+    if refer_labels is not None:
+        raise NotImplementedError("LOSS[%r] with refer_labels / region selection is not used by any trainer" % name)
 
 
-for _n in ("MSE", "KLDIV", "BCEWithLogits"):
-    LOSS.register(_n, _out_of_scope(_n))
+@LOSS.register("MSE")
+def mse(logits, labels, weights=None, ignore_index=255, refer_labels=None, region="ignore"):
+    """nn.MSELoss() (losses.py:10-14); the discriminator maps it is applied to have B*16*32 elements, so the
+    reduction is device plumbing, not a kernel of its own."""
+    _need_hip(logits)
+    _plain("MSE", refer_labels)
+    return torch.nn.functional.mse_loss(logits.float(), labels.float())
+
+
+@LOSS.register("KLDIV")
+def kl_div(input_logits, target_logits, weights=None, ignore_index=255, refer_labels=None, region="confident"):
+    """nn.KLDivLoss() default reduction = element mean of q (log q - log p) (losses.py:17-24)."""
+    _need_hip(input_logits)
+    _plain("KLDIV", refer_labels)
+    logp = torch.log_softmax(input_logits.float(), dim=1)
+    return torch.nn.functional.kl_div(logp, torch.softmax(target_logits.float(), dim=1), reduction="mean")
+
+
+@LOSS.register("BCEWithLogits")
+def bce_with_logits(logits, labels):
+    """nn.BCEWithLogitsLoss() (losses.py:27-30)"""
+    _need_hip(logits)
+    return torch.nn.functional.binary_cross_entropy_with_logits(logits.float(), labels.float())

@@ -169,7 +169,8 @@ class FusedAdam(torch.optim.Optimizer):
 
 
 def init_optimizers(cfg, model):
-    """utils.py:135-154 (generator optimiser only: no discriminator in the self-training stage)"""
+    """utils.py:135-154: generator optimiser over the segmentation net's three LR groups; Adam(lr=discriminator.lr)
+    over model.D when the discriminator is enabled (adversarial warm-up)."""
     groups = _unwrap(model).seg_model.get_optimizer_params(cfg.train.lr)
     groups = [{"params": [p for p in g["params"] if p.requires_grad], "lr": g["lr"]} for g in groups]
     kind = cfg.train.optimizer
@@ -182,13 +183,41 @@ def init_optimizers(cfg, model):
         opt = torch.optim.AdamW(groups, betas=(0.9, 0.999), weight_decay=0.0005)
     else:
         raise ValueError("%s is not a valid optimizer" % kind)
+    d_opt = None
     if cfg.model.discriminator.is_enabled:
-        raise NotImplementedError("adversarial warm-up (discriminator) is outside the self-training hot path")
-    return opt, None
+        d_params = list(_unwrap(model).D.parameters())
+        on_device = all(p.is_cuda for p in d_params)
+        d_opt = (FusedAdam if on_device else torch.optim.Adam)(d_params, lr=cfg.model.discriminator.lr, betas=(0.9, 0.999))
+    return opt, d_opt
 
 
 def init_schedulers(cfg, g_optimizer, d_optimizer=None):
     return [build_scheduler(cfg, o) for o in (g_optimizer, d_optimizer) if o is not None]
+
+
+def all_reduce_grads(params, world_size, bucket_bytes=64 << 20):
+    """average .grad over the ranks in flat buckets (one RCCL all-reduce per ~64 MB)"""
+    from torch._utils import _flatten_dense_tensors, _unflatten_dense_tensors
+    grads = [p.grad for p in params if p.grad is not None]
+    bucket, size = [], 0
+
+    def flush():
+        if not bucket:
+            return
+        flat = _flatten_dense_tensors(bucket)
+        dist.all_reduce(flat)
+        flat.div_(world_size)
+        for g, f in zip(bucket, _unflatten_dense_tensors(flat, bucket)):
+            g.copy_(f)
+        bucket.clear()
+
+    for g in grads:
+        bucket.append(g)
+        size += g.numel() * g.element_size()
+        if size >= bucket_bytes:
+            flush()
+            size = 0
+    flush()
 
 
 def all_reduce_average(tensor, world_size):

@@ -38,6 +38,7 @@ class _Bare(torch.nn.Module):
 
 
 class BaseTrainer:
+    manual_allreduce = False     # True: the trainer all-reduces gradients itself after each backward (no DDP wrapper)
 
     def __init__(self, cfg, gpu_index):
         self.cfg = cfg
@@ -98,6 +99,12 @@ class BaseTrainer:
                                    persistent_workers=self.cfg.dataset.num_workers > 0)
 
     def build_train_data_reader(self):
+        s = self.cfg.dataset.source
+        if s.type is not None and s.json_path is not None and s.image_dir is not None:
+            self.s_dataset = DATASET[s.type](self.cfg, s.json_path, s.image_dir, aug_type=s.aug_type,
+                                             num_classes=self.cfg.dataset.num_classes)
+            self.s_sampler, self.s_loader = self._loader(self.s_dataset, self.cfg.train.batch_size, True, True)
+            self.s_iter = iter(self.s_loader)
         t = self.cfg.dataset.target
         if t.type is not None and t.json_path and t.image_dir is not None:
             self.t_dataset = DATASET[t.type](self.cfg, t.json_path, t.image_dir, pseudo_dir=t.pseudo_dir,
@@ -119,6 +126,14 @@ class BaseTrainer:
             self.t_sampler.set_epoch(self.t_sampler.epoch + 1)
             self.t_iter = iter(self.t_loader)
             return next(self.t_iter)
+
+    def next_source_batch(self):
+        try:
+            return next(self.s_iter)
+        except StopIteration:
+            self.s_sampler.set_epoch(self.s_sampler.epoch + 1)
+            self.s_iter = iter(self.s_loader)
+            return next(self.s_iter)
 
     # ---------------------------------------------------------------- loop
     def run(self):
@@ -149,8 +164,13 @@ class BaseTrainer:
     def validate_all(self, current_iter):
         self.validate(self.model, self.model_recorder, current_iter)
 
+    def _sync_grads(self, optimizer):
+        if self.manual_allreduce and self.world > 1:
+            utils.all_reduce_grads([p for g in optimizer.param_groups for p in g["params"]], self.world)
+
     def update_model(self, g_optimizer, d_optimizer, losses):
-        """base_trainer.py:127-141: g_loss = Σ mean(loss_i); bf16 autocast needs no loss scaling"""
+        """base_trainer.py:127-141: g_loss = Σ mean(loss_i) over the non-'D_' losses -> generator step; then, when
+        there is a 'D_loss', the discriminator step.  bf16 autocast needs no loss scaling."""
         g_loss = sum(torch.mean(v) for k, v in losses.items() if "D_" not in k)
         g_optimizer.zero_grad(set_to_none=True)
         HF.enable_wgrad_overlap(True)
@@ -159,7 +179,13 @@ class BaseTrainer:
         finally:
             HF.enable_wgrad_overlap(False)
         HF.wgrad_stream_join()      # single-process runs issue the trunk's weight gradients on a side stream
+        self._sync_grads(g_optimizer)
         g_optimizer.step()
+        if "D_loss" in losses:
+            d_optimizer.zero_grad(set_to_none=True)
+            torch.mean(losses["D_loss"]).backward()
+            self._sync_grads(d_optimizer)
+            d_optimizer.step()
 
     def train(self):
         raise NotImplementedError

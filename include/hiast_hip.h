@@ -317,6 +317,17 @@ typedef struct { float* p; const float* g; float* m; float* v; int64_t n; float 
 int hiast_adam_step(const hiast_adam_rec* table, const int32_t* chunk_tensor, const int64_t* chunk_start,
                     int n_chunks, double beta1, double beta2, float eps, float weight_decay, hiast_stream_t stream);
 
+/* ---- K15: discriminator input map (adversarial warm-up stage) -----------------------------
+ * sseg/models/segmentors/adversarial_warmup_segmentor.py: F.interpolate(logits, size, bilinear,
+ * align_corners=True) :36,:41 followed by D_preprocess_fun :26-29 — mode 0 = softmax(dim=1)
+ * (AdaptSegNet), mode 1 = prob_2_entropy(softmax) :71-76 (AdvEnt):  -p log2(p + 1e-30) / log2(C).
+ * logits_lr [B,C,h,w] -> out [B,C,H,W]; the full-resolution logits are never stored.
+ * bwd: gout [B,C,H,W] -> dlogits_lr [B,C,h,w] (overwritten); scratch: B*C*H*W floats. */
+int hiast_dinput_fwd(const float* logits_lr, int mode, float* out, int B, int C, int h, int w, int H, int W,
+                     hiast_stream_t stream);
+int hiast_dinput_bwd(const float* logits_lr, int mode, const float* gout, float* scratch, float* dlogits_lr,
+                     int B, int C, int h, int w, int H, int W, hiast_stream_t stream);
+
 /* ---- K12: IoU histograms --------------------------------------------------------------
  * utils/metrics.py:6-19 intersectionAndUnionGPU: pred/target int64 [N]; target==255 is
  * ignored; inter/area_pred/area_tgt i64 [K] ACCUMULATED (caller zeroes). */

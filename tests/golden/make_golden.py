@@ -369,9 +369,107 @@ def g_ema_optim():
     save("ema_optim", p=np.stack(traj_p), e=np.stack(traj_e), lr=np.array(lrs))
 
 
+# ---------------------------------------------------------------------------------- G11
+def seeded_discriminator_state(D, seed):
+    """deterministic weights for an FCDiscriminator-shaped module (conv1..conv4, classifier)"""
+    sd = {}
+    for i, (k, v) in enumerate(D.state_dict().items()):
+        if v.dim() == 4:
+            std = (1.0 / (v.shape[1] * v.shape[2] * v.shape[3])) ** 0.5
+            sd[k] = torch.from_numpy(synth.normal_f32(seed + i, tuple(v.shape), std))
+        else:
+            sd[k] = torch.from_numpy(synth.normal_f32(seed + i, tuple(v.shape), 0.05))
+    return sd
+
+
+WARMUP_CASES = {
+    "mse_prob": dict(seed=2100, d_loss="MSE", entropy_in=False, ent_w=3.0),
+    "bce_prob": dict(seed=2110, d_loss="BCEWithLogits", entropy_in=False, ent_w=0.0),
+    "bce_ent": dict(seed=2120, d_loss="BCEWithLogits", entropy_in=True, ent_w=1.0),
+    "mse_ent": dict(seed=2130, d_loss="MSE", entropy_in=True, ent_w=3.0),
+}
+WARMUP_SHAPE = (2, 19, 9, 17, 65, 129)      # B, C, h, w, H, W
+
+
+class _StubSeg(torch.nn.Module):
+    """stands in for DeepLab_V2: hands out the prepared low-res logits (source first, then target)"""
+
+    def __init__(self, outs):
+        super().__init__()
+        self.outs, self.i = list(outs), 0
+
+    def forward(self, x):
+        o = self.outs[self.i % len(self.outs)]
+        self.i += 1
+        return o, None
+
+
+def g_warmup():
+    """AdversarialWarmupSegmentor.forward in train mode (adversarial_warmup_segmentor.py:33-67) downstream of the
+    segmentation net, followed by the two backward passes of BaseTrainer.update_model (base_trainer.py:127-141)."""
+    aws = ref_import.ref("sseg.models.segmentors.adversarial_warmup_segmentor")
+    disc = ref_import.ref("sseg.models.modules.discriminator")
+    losses_mod = ref_import.ref("sseg.models.modules.losses")
+    F = torch.nn.functional
+    B, C, h, w, H, W = WARMUP_SHAPE
+    out = {"shape": np.array(WARMUP_SHAPE)}
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self          # :49,:56-57 call .cuda() on fresh CPU tensors
+    try:
+        for tag, cs in WARMUP_CASES.items():
+            cfg = ns(dataset=ns(num_classes=C),
+                     model=ns(predictor=ns(seg_loss=ns(type="CE", source_weight=1.0), ent_loss=ns(weight=cs["ent_w"])),
+                              discriminator=ns(is_enabled=True, is_entropy_input=cs["entropy_in"],
+                                               D_loss=ns(type=cs["d_loss"], weight=1.0, adv_weight=0.05))))
+            seg = object.__new__(aws.AdversarialWarmupSegmentor)
+            torch.nn.Module.__init__(seg)
+            seg.cfg = cfg
+            zs = torch.from_numpy(synth.logits_lr(cs["seed"], B, C, h, w, 2.5)).requires_grad_(True)
+            zt = torch.from_numpy(synth.logits_lr(cs["seed"] + 1, B, C, h, w, 2.5)).requires_grad_(True)
+            seg.seg_model = _StubSeg([zs, zt])
+            seg.D = disc.build_discriminator(C)
+            seg.D.load_state_dict(seeded_discriminator_state(seg.D, cs["seed"] + 50))
+            seg.seg_loss_fun = losses_mod.LOSS["CE"]
+            seg.D_loss_fun = losses_mod.LOSS[cs["d_loss"]]
+            if cs["entropy_in"]:
+                seg.D_preprocess_fun = lambda x: aws.prob_2_entropy(F.softmax(x, dim=1))
+            else:
+                seg.D_preprocess_fun = lambda x: F.softmax(x, dim=1)
+            if cs["ent_w"] > 0:
+                seg.ent_loss_fun = lambda x: aws.entropy_loss(F.softmax(x, dim=1))
+            seg.train()
+            s_lbl = torch.from_numpy(synth.pseudo_labels(cs["seed"] + 2, B, H, W, C, 0.1, np.int64))
+            losses = seg(torch.zeros(B, 3, H, W), torch.zeros(B, 3, H, W), s_lbl)
+            names = ["source_seg_loss", "adv_loss", "D_loss", "target_ent_loss"]
+            out["vals_" + tag] = np.array([losses[n].item() if n in losses else np.nan for n in names], np.float64)
+            g_loss = sum(torch.mean(v) for k, v in losses.items() if "D_" not in k)
+            g_loss.backward(retain_graph=True)
+            out["gs_" + tag] = zs.grad.numpy().copy()
+            out["gt_" + tag] = zt.grad.numpy().copy()
+            seg.D.zero_grad()
+            zs.grad = None
+            zt.grad = None
+            losses["D_loss"].backward()
+            assert zs.grad is None and zt.grad is None     # the D step sees detached maps
+            out["gd_conv1_w_" + tag] = seg.D.conv1.weight.grad.numpy().copy()
+            out["gd_cls_w_" + tag] = seg.D.classifier.weight.grad.numpy().copy()
+            out["gd_bias_" + tag] = np.concatenate([getattr(seg.D, n).bias.grad.numpy().ravel() for n in
+                                                    ("conv1", "conv2", "conv3", "conv4", "classifier")])
+            out["gd_wsum_" + tag] = np.array([getattr(seg.D, n).weight.grad.double().sum().item() for n in
+                                              ("conv1", "conv2", "conv3", "conv4", "classifier")])
+            # the discriminator's input map itself (upsample -> softmax [-> self-information])
+            with torch.no_grad():
+                out["dmap_" + tag] = seg.D_preprocess_fun(
+                    F.interpolate(zt.detach(), size=(H, W), mode="bilinear", align_corners=True)).numpy()[:, ::6]
+            out["cfg_" + tag] = np.array(json.dumps(cs))
+    finally:
+        torch.Tensor.cuda = orig_cuda
+    save("warmup", **out)
+
+
 ALL = {"upsample": g_upsample, "stage_a": g_stage_a, "ias": g_ias, "losses": g_losses,
        "aspp": g_aspp, "deeplab": g_deeplab, "metrics": g_metrics, "copy_paste": g_copy_paste,
-       "ema_optim": g_ema_optim}
+       "ema_optim": g_ema_optim, "warmup": g_warmup}
 
 if __name__ == "__main__":
     torch.set_num_threads(8)

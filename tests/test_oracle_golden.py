@@ -6,7 +6,7 @@ import pytest
 import torch
 
 import synth
-from oracle import cref, ias_ref, losses_ref, metrics_ref, deeplab_ref, copy_paste_ref
+from oracle import cref, ias_ref, losses_ref, metrics_ref, deeplab_ref, copy_paste_ref, warmup_ref
 
 
 def ulp_diff(a, b):
@@ -242,3 +242,48 @@ def test_copy_paste_vs_reference(golden):
                                         lambda n: (imgs[names.index(n)], lbls[names.index(n)]), C)
         assert np.array_equal(im, g["img"][i]) and np.array_equal(lb, g["lbl"][i])
         assert np.array_equal(mk, g["mask"][i])
+
+
+WARMUP_CASES = ["mse_prob", "bce_prob", "bce_ent", "mse_ent"]
+
+
+def warmup_case(g, tag):
+    """inputs of one tests/golden/warmup.npz case, regenerated from its seeds"""
+    from make_golden import seeded_discriminator_state
+    from hiast_amd.sseg.models.modules.discriminator import FCDiscriminator
+    B, C, h, w, H, W = [int(v) for v in g["shape"]]
+    cs = json.loads(str(g["cfg_" + tag]))
+    zs = synth.logits_lr(cs["seed"], B, C, h, w, 2.5)
+    zt = synth.logits_lr(cs["seed"] + 1, B, C, h, w, 2.5)
+    lbl = synth.pseudo_labels(cs["seed"] + 2, B, H, W, C, 0.1, np.int64)
+    d_sd = seeded_discriminator_state(FCDiscriminator(C), cs["seed"] + 50)
+    return cs, (B, C, h, w, H, W), zs, zt, lbl, d_sd
+
+
+@pytest.mark.parametrize("tag", WARMUP_CASES)
+def test_warmup_losses_vs_reference(golden, tag):
+    g = golden("warmup")
+    cs, (B, C, h, w, H, W), zs, zt, lbl, d_sd = warmup_case(g, tag)
+    zs = torch.from_numpy(zs).requires_grad_(True)
+    zt = torch.from_numpy(zt).requires_grad_(True)
+    d_sd = {k: v.double().requires_grad_(True) for k, v in d_sd.items()}
+    L = warmup_ref.warmup_losses(zs, zt, torch.from_numpy(lbl), (H, W), d_sd, cs["d_loss"], cs["entropy_in"],
+                                 ent_weight=cs["ent_w"])
+    names = ["source_seg_loss", "adv_loss", "D_loss", "target_ent_loss"]
+    got = np.array([L[n].item() if n in L else np.nan for n in names])
+    want = g["vals_" + tag]
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    ok = ~np.isnan(want)
+    assert np.allclose(got[ok], want[ok], rtol=3e-6)
+    sum(v for k, v in L.items() if "D_" not in k).backward(retain_graph=True)
+    assert np.allclose(zs.grad.numpy(), g["gs_" + tag], rtol=1e-4, atol=1e-9)
+    assert np.allclose(zt.grad.numpy(), g["gt_" + tag], rtol=1e-4, atol=1e-9)
+    assert all(v.grad is None for v in d_sd.values())       # the adversarial pass leaves the discriminator alone
+    L["D_loss"].backward()
+    assert np.allclose(d_sd["conv1.weight"].grad.numpy(), g["gd_conv1_w_" + tag], rtol=1e-4, atol=1e-8)
+    assert np.allclose(d_sd["classifier.weight"].grad.numpy(), g["gd_cls_w_" + tag], rtol=1e-4, atol=1e-8)
+    bias = np.concatenate([d_sd[n + ".bias"].grad.numpy().ravel() for n in
+                           ("conv1", "conv2", "conv3", "conv4", "classifier")])
+    assert np.allclose(bias, g["gd_bias_" + tag], rtol=1e-4, atol=1e-8)
+    dmap = warmup_ref.discriminator_input(zt.detach(), (H, W), cs["entropy_in"]).numpy()[:, ::6]
+    assert np.allclose(dmap, g["dmap_" + tag], rtol=1e-5, atol=1e-7)
