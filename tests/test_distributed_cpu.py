@@ -126,3 +126,31 @@ def test_recorder_packs_losses_into_one_allreduce(tmp_path):
     mp.spawn(_rec_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     v = json.load(open(out))
     assert abs(v["a"] - 2.5) < 1e-6 and abs(v["b"] - 15.0) < 1e-6
+
+
+def _grad_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hiast_amd.utils import utils
+    torch.manual_seed(3)
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in [(5, 3), (7,), (2, 2, 3), (1,), (300,)]]
+    for i, p in enumerate(params):
+        p.grad = torch.full_like(p, float((rank + 1) * (i + 1))) + torch.arange(p.numel()).view(p.shape)
+    params.append(torch.nn.Parameter(torch.zeros(4)))           # a parameter without gradient is skipped
+    utils.all_reduce_grads(params, world, bucket_bytes=64)      # tiny buckets: several flushes
+    if rank == 0:
+        torch.save([p.grad for p in params], out)
+    dist.destroy_process_group()
+
+
+def test_manual_gradient_allreduce_averages_over_ranks(tmp_path):
+    """the adversarial warm-up trainer's own gradient exchange (two backward passes per forward, no DDP wrapper)"""
+    out = str(tmp_path / "g.pt")
+    mp.spawn(_grad_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    grads = torch.load(out)
+    assert grads[-1] is None
+    for i, g in enumerate(grads[:-1]):
+        want = torch.full_like(g, 1.5 * (i + 1)) + torch.arange(g.numel()).view(g.shape)
+        assert torch.equal(g, want)

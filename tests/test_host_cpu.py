@@ -18,9 +18,10 @@ from hiast_amd.tools import synth_data
 
 def test_registries_hold_reference_names():
     assert {"CE", "SoftCE", "MSE", "KLDIV", "BCEWithLogits"} <= set(LOSS)
-    assert {"Cityscapes", "GTAV", "SYNTHIA"} <= set(DATASET)
-    assert {"SelfTrainingSegmentor", "SourceOnlySegmentor"} <= set(MODEL)
-    assert {"SelfTrainingTrainer", "ConsistencySelfTrainingTrainer"} <= set(TRAINER)
+    assert {"Cityscapes", "GTAV", "SYNTHIA", "Oxford"} <= set(DATASET)
+    assert {"SelfTrainingSegmentor", "SourceOnlySegmentor", "AdversarialWarmupSegmentor"} <= set(MODEL)
+    assert {"SelfTrainingTrainer", "ConsistencySelfTrainingTrainer", "SourceOnlyTrainer",
+            "AdversarialWarmupTrainer"} <= set(TRAINER)
     assert {"IAS", "CT", "NT", "CBST"} <= set(PSEUDO_POLICY)
     assert "CopyPaste" in PREPROCESSOR and "DeepLab_V2" in SEG_MODEL
     with pytest.raises(AssertionError):
@@ -109,6 +110,36 @@ def test_dataset_transform_and_pseudo_paths(tmp_path):
     it2 = two[0]
     assert isinstance(it2["images"], list) and len(it2["images"]) == 2
     assert tuple(it2["images"][0].shape) == (3, 512, 1024) and torch.equal(it2["labels"][0], it2["labels"][1])
+
+
+def test_oxford_labels_and_warmup_optimizers(tmp_path):
+    """Oxford RobotCar: RGBA label PNGs whose first channel is the class id (oxford_dataset.py:14-23); the
+    discriminator gets its own Adam(lr = discriminator.lr) (utils.py:148-152) and scheduler (:157-163)."""
+    from PIL import Image
+    from hiast_amd.utils import utils
+    from hiast_amd.sseg.datasets.loader.oxford_dataset import OxfordDataset
+    ids = np.array([[0, 1, 2, 3, 4, 5, 6, 7], [8, 9, 10, 11, 12, 13, 14, 17]], np.uint8)
+    rgba = np.stack([ids, ids * 0 + 9, ids * 0 + 9, ids * 0 + 255], -1)
+    path = str(tmp_path / "lbl.png")
+    Image.fromarray(rgba, "RGBA").save(path)
+    ds = object.__new__(OxfordDataset)
+    ds.num_classes = 9
+    got = ds.read_label(path)
+    want = np.array([[255, 0, 1, 2, 3, 4, 5, 6], [255, 255, 7, 8, 8, 8, 8, 8]], np.uint8)
+    assert np.array_equal(got, want)
+    assert ds.read_label(str(tmp_path / "frame.jpg")) is None          # unlabeled training frames
+    c = synth_data.synthetic_cfg(str(tmp_path), n_train=1, n_val=1, h=16, w=32)
+    c.model.type = "AdversarialWarmupSegmentor"
+    c.model.discriminator.is_enabled = True
+    c.train.total_iter = 10
+    m = MODEL[c.model.type](c)
+    assert [k for k in m.state_dict() if k.startswith("D.")] == [
+        "D.%s.%s" % (n, t) for n in ("conv1", "conv2", "conv3", "conv4", "classifier") for t in ("weight", "bias")]
+    g_opt, d_opt = utils.init_optimizers(c, m)
+    assert len(g_opt.param_groups) == 3 and len(d_opt.param_groups) == 1
+    assert d_opt.param_groups[0]["lr"] == c.model.discriminator.lr and d_opt.param_groups[0]["betas"] == (0.9, 0.999)
+    assert sum(p.numel() for p in d_opt.param_groups[0]["params"]) == sum(p.numel() for p in m.D.parameters())
+    assert len(utils.init_schedulers(c, g_opt, d_opt)) == 2
 
 
 def test_copy_paste_matches_reference_golden(golden):
