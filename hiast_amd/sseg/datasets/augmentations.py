@@ -89,8 +89,12 @@ class ColorAug(_Aug):
 
     @staticmethod
     def _noise(img):
-        n = np.random.normal(0, random.uniform(3, 12), img.shape).astype(np.float32)
-        return np.clip(img.astype(np.float32) + n, 0, 255).astype(np.uint8)
+        sigma = random.uniform(3, 12)
+        g = np.random.Generator(np.random.SFC64(np.random.randint(0, 2 ** 31 - 1)))     # child of the global stream
+        n = g.standard_normal(img.shape, dtype=np.float32)                               # float32 draws: 3x cheaper
+        n *= sigma
+        n += img
+        return np.clip(n, 0, 255, out=n).astype(np.uint8)
 
     def apply(self, image, masks):
         pool = [self._brightness_contrast, self._gamma, self._channel_gain, self._noise]

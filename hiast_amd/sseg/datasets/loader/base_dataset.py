@@ -78,8 +78,9 @@ class BaseDataset(Dataset):
         img, lbl = augmentations.aug(self.aug_fun, img, lbl)
         img, lbl = utils.transform(img, lbl, raw_u8=getattr(self, "device_transform", False))
         out = {"images": img, "labels": lbl, "image_paths": path}
-        if cp_mask is not None:
-            out["copy_paste_mask"] = torch.from_numpy(cp_mask).long()
+        if cp_mask is not None:     # native-resolution map of the pasted classes (255 elsewhere); int64 as the reference,
+            m = torch.from_numpy(cp_mask)           # uint8 for device_transform consumers (8x fewer bytes per sample)
+            out["copy_paste_mask"] = m if getattr(self, "device_transform", False) else m.long()
         return out
 
     def set_preprocessor(self, preprocessor):

@@ -56,19 +56,23 @@ class CopyPaste:
         return self.run_original(img, lbl)
 
     def random_select(self, selected_classes):
-        """rejection-sample a hard class (preprocessor.py:70-77).  Deviation: a class that no pseudo-labelled
-        image contains is rejected too (the reference would raise in np.random.choice on its empty file list);
-        with every hard class populated the draw sequence is identical to the reference's."""
+        """rejection-sample a hard class (preprocessor.py:70-77).  Deviations: a class that no pseudo-labelled
+        image contains is rejected too (the reference would raise in np.random.choice on its empty file list), and
+        after 64 rejections the class is drawn directly from the distribution renormalised over the usable classes
+        (the reference's loop is unbounded: with nearly all probability mass on unusable classes it spins for
+        ~1/P(usable) draws).  With every hard class populated the draw sequence is identical to the reference's."""
         ids = [i for i in range(self.cfg.dataset.num_classes)]
         usable = [c for c in selected_classes if len(self.samples_with_class.get(int(c), [])) > 0]
         if not usable:
             return None
-        if float(np.sum(self.class_probs[np.asarray(usable, dtype=int)])) <= 0.0:
+        p_usable = self.class_probs[np.asarray(usable, dtype=int)]
+        if float(np.sum(p_usable)) <= 0.0:
             return np.random.choice(usable)     # degenerate: all usable classes have sampling probability 0
-        while True:
+        for _ in range(64):
             c = np.random.choice(ids, size=1, replace=False, p=self.class_probs)[0]
             if c in usable:
                 return c
+        return np.random.choice(usable, p=p_usable / p_usable.sum())
 
     def run_original(self, img, lbl):
         """Returns (img, lbl, copy_paste_mask).  The reference's retry loop (up to 3 source images)
@@ -82,11 +86,10 @@ class CopyPaste:
         img_, lbl_, _ = self.dataset_copy_from.load_data(self.dataset_copy_from.get_file_to_idx(name))
         if img.shape != img_.shape:
             img_, lbl_ = self.resize(img_, lbl_, lbl.shape)
-        sel = np.zeros(lbl.shape, dtype=bool)
-        for h in self.hard_classes:
-            hit = lbl_ == h
-            sel[hit] = True
-            mask[hit] = h
-        img[sel] = img_[sel]
-        lbl[sel] = lbl_[sel]
+        lut = np.zeros(256, dtype=bool)          # one table lookup instead of a compare per hard class
+        lut[np.asarray(self.hard_classes, dtype=np.int64)] = True
+        sel = lut[lbl_]
+        np.copyto(mask, lbl_, where=sel)
+        np.copyto(img, img_, where=sel[..., None])
+        np.copyto(lbl, lbl_, where=sel)
         return img, lbl, mask

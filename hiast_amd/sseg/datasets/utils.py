@@ -35,19 +35,39 @@ def _img_to_tensor(img, mean, std):
 
 def transform(img, lbl, mean=MEAN, std=STD, raw_u8=False):
     """utils.py:37-55: images normalised float32 CHW, labels int64; lists map element-wise.
-    raw_u8: hand the uint8 HWC image over untouched — the consumer normalises it on the device
-    (hiast_normalize_u8: 4x fewer bytes through the worker pipes and over PCIe, same bits)."""
-    def one_lbl(x):
-        return torch.from_numpy(np.ascontiguousarray(x)).long()
+    raw_u8: hand the uint8 HWC image and the uint8 label over untouched — the consumer normalises the image on the
+    device (hiast_normalize_u8, same bits) and the fused loss reads uint8 labels directly: 4x (images) and 8x
+    (labels) fewer bytes through the worker pipes, the pinned staging buffers and PCIe."""
     if raw_u8:
+        def one_lbl(x):
+            return torch.from_numpy(np.ascontiguousarray(x, dtype=np.uint8))
+
         def one_img(i):
             return torch.from_numpy(np.ascontiguousarray(np.asarray(i), dtype=np.uint8))
     else:
+        def one_lbl(x):
+            return torch.from_numpy(np.ascontiguousarray(x)).long()
+
         def one_img(i):
             return _img_to_tensor(i, mean, std)
     img_t = [one_img(i) for i in img] if isinstance(img, (list, tuple)) else one_img(img)
     lbl_t = [one_lbl(l) for l in lbl] if isinstance(lbl, (list, tuple)) else one_lbl(lbl)
     return img_t, lbl_t
+
+
+def to_device_batch(images, labels, device):
+    """a collated batch -> device tensors: uint8 HWC images (device_transform datasets) are normalised on the device,
+    float images pass through; labels keep their dtype (the fused loss takes uint8 or int64)"""
+    def img(t):
+        t = t.to(device, non_blocking=True)
+        if t.dtype == torch.uint8:
+            from hiast_amd import kernels as K
+            t = K.normalize_u8(t, MEAN, STD)
+        return t
+    imgs = [img(t) for t in images] if isinstance(images, (list, tuple)) else img(images)
+    lbls = ([l.to(device, non_blocking=True) for l in labels] if isinstance(labels, (list, tuple))
+            else labels.to(device, non_blocking=True))
+    return imgs, lbls
 
 
 def preprocess_label(lbl, id_map, ignored_index=255):

@@ -42,32 +42,49 @@ def make_sample(seed, h, w, num_classes=19, absent=()):
     return img, lbl
 
 
-def write_cityscapes_like(root, split, n, h, w, seed=0, num_classes=19, absent=()):
-    """-> (json_path, image_dir); image_dir is what cfg.dataset.*.image_dir should point at"""
+def _write_one(args):
+    image_dir, img_rel, lbl_rel, seed, h, w, num_classes, absent, upscale = args
+    img, lbl = make_sample(seed, h // upscale, w // upscale, num_classes, absent)
+    if upscale > 1:      # large frames: blocky upsample of a smaller sample (cheap to generate, same statistics)
+        img = np.repeat(np.repeat(img, upscale, axis=0), upscale, axis=1)
+        lbl = np.repeat(np.repeat(lbl, upscale, axis=0), upscale, axis=1)
+    Image.fromarray(img).save(os.path.join(image_dir, img_rel), compress_level=1)
+    Image.fromarray(lbl, mode="L").save(os.path.join(image_dir, lbl_rel), compress_level=1)
+
+
+def write_cityscapes_like(root, split, n, h, w, seed=0, num_classes=19, absent=(), upscale=1, procs=0):
+    """-> (json_path, image_dir); image_dir is what cfg.dataset.*.image_dir should point at.
+    upscale / procs only speed up the writing of large benchmark sets (defaults keep the files byte-identical)."""
     image_dir = os.path.join(root, "data", "cityscapes")
-    entries = []
+    entries, jobs = [], []
     for i in range(n):
         stem = "synth_%06d_%06d" % (seed, i)
         img_rel = "leftImg8bit/%s/synth/%s_leftImg8bit.png" % (split, stem)
         lbl_rel = "gtFine/%s/synth/%s_gtFine_labelTrainIds.png" % (split, stem)
         for rel in (img_rel, lbl_rel):
             os.makedirs(os.path.dirname(os.path.join(image_dir, rel)), exist_ok=True)
-        img, lbl = make_sample(seed * 100003 + i, h, w, num_classes, absent)
-        Image.fromarray(img).save(os.path.join(image_dir, img_rel), compress_level=1)
-        Image.fromarray(lbl, mode="L").save(os.path.join(image_dir, lbl_rel), compress_level=1)
+        jobs.append((image_dir, img_rel, lbl_rel, seed * 100003 + i, h, w, num_classes, absent, upscale))
         entries.append({"image_name": img_rel, "mask_name": lbl_rel, "has_target": True})
+    if procs > 1 and n > 1:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(procs) as pool:
+            pool.map(_write_one, jobs)
+    else:
+        for j in jobs:
+            _write_one(j)
     json_path = os.path.join(root, "data", "cityscapes_%s.json" % split)
     with open(json_path, "w") as f:
         json.dump(entries, f)
     return json_path, image_dir
 
 
-def synthetic_cfg(root, n_train=8, n_val=4, h=256, w=512, seed=1, num_classes=19, source_type="GTAV"):
+def synthetic_cfg(root, n_train=8, n_val=4, h=256, w=512, seed=1, num_classes=19, source_type="GTAV", upscale=1,
+                  procs=0):
     """write a tiny dataset and return a cfg (hiast_amd.utils.default_config.CfgNode) pointing at it"""
     from hiast_amd.utils.default_config import get_default_cfg
     absent = (9, 14, 16) if source_type == "SYNTHIA" else ()
-    tj, td = write_cityscapes_like(root, "train", n_train, h, w, seed, num_classes, absent)
-    vj, vd = write_cityscapes_like(root, "val", n_val, h, w, seed + 1, num_classes, absent)
+    tj, td = write_cityscapes_like(root, "train", n_train, h, w, seed, num_classes, absent, upscale, procs)
+    vj, vd = write_cityscapes_like(root, "val", n_val, h, w, seed + 1, num_classes, absent, upscale, procs)
     c = get_default_cfg()
     c.dataset.num_classes = num_classes
     c.dataset.num_workers = 0

@@ -7,6 +7,7 @@ this trainer keeps the bare module and all-reduces the gradients itself after ea
 RCCL — the reference's apex DDP likewise delays its all-reduce to the end of backward)."""
 import torch
 
+from hiast_amd.sseg.datasets import utils as du
 from hiast_amd.utils.registry.registries import TRAINER
 from hiast_amd.workflows.trainer.base_trainer import BaseTrainer, _Bare
 
@@ -31,6 +32,6 @@ class AdversarialWarmupTrainer(BaseTrainer):
     def train(self):
         s = self.next_source_batch()
         t = self.next_target_batch()
-        return self.train_on(s["images"].to(self.device, non_blocking=True),
-                             s["labels"].to(self.device, non_blocking=True),
-                             t["images"].to(self.device, non_blocking=True))
+        s_img, s_lbl = du.to_device_batch(s["images"], s["labels"], self.device)
+        t_img, _ = du.to_device_batch(t["images"], t["labels"], self.device)
+        return self.train_on(s_img, s_lbl, t_img)

@@ -8,6 +8,7 @@ import os
 import numpy as np
 import torch
 
+from hiast_amd.sseg.datasets import utils as du
 from hiast_amd.sseg.datasets.preprocessor import CopyPaste
 from hiast_amd.utils import utils
 from hiast_amd.utils.registry.registries import DATASET, TRAINER
@@ -83,6 +84,9 @@ class ConsistencySelfTrainingTrainer(BaseTrainer):
             weak, strong, plbl = img[0], img[1], plbl[0]
         else:
             weak = strong = img
-        weak = weak.to(self.device, non_blocking=True)
-        strong = weak if strong is weak else strong.to(self.device, non_blocking=True)
-        return self.train_on(weak, strong, plbl.to(self.device, non_blocking=True))
+        if strong is weak:
+            weak, plbl = du.to_device_batch(weak, plbl, self.device)
+            strong = weak
+        else:
+            (weak, strong), plbl = du.to_device_batch([weak, strong], plbl, self.device)
+        return self.train_on(weak, strong, plbl)

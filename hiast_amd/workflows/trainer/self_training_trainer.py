@@ -3,6 +3,7 @@ one target batch with pseudo labels -> student forward -> 3-term loss.  The stud
 low-res logits and the fused loss kernel does the rest."""
 import torch
 
+from hiast_amd.sseg.datasets import utils as du
 from hiast_amd.utils.registry.registries import TRAINER
 from hiast_amd.workflows.trainer.base_trainer import BaseTrainer
 
@@ -23,5 +24,4 @@ class SelfTrainingTrainer(BaseTrainer):
 
     def train(self):
         t = self.next_target_batch()
-        return self.train_on(t["images"].to(self.device, non_blocking=True),
-                             t["labels"].to(self.device, non_blocking=True))
+        return self.train_on(*du.to_device_batch(t["images"], t["labels"], self.device))

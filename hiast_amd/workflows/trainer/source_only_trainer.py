@@ -3,6 +3,7 @@ source domain.  The model hands over low-res logits; the fused loss kernel does 
 import torch
 
 from hiast_amd import functional as HF
+from hiast_amd.sseg.datasets import utils as du
 from hiast_amd.utils.registry.registries import TRAINER
 from hiast_amd.workflows.trainer.base_trainer import BaseTrainer
 
@@ -20,5 +21,4 @@ class SourceOnlyTrainer(BaseTrainer):
 
     def train(self):
         s = self.next_source_batch()
-        return self.train_on(s["images"].to(self.device, non_blocking=True),
-                             s["labels"].to(self.device, non_blocking=True))
+        return self.train_on(*du.to_device_batch(s["images"], s["labels"], self.device))

@@ -142,6 +142,25 @@ def test_oxford_labels_and_warmup_optimizers(tmp_path):
     assert len(utils.init_schedulers(c, g_opt, d_opt)) == 2
 
 
+def test_copy_paste_rejection_sampling_is_bounded():
+    """nearly all sampling mass on classes no pseudo-labelled image contains (a barely trained model): the class draw
+    must still return promptly, and only usable hard classes come out"""
+    import types
+    from hiast_amd.sseg.datasets.preprocessor import CopyPaste
+    cp = object.__new__(CopyPaste)
+    cp.cfg = types.SimpleNamespace(dataset=types.SimpleNamespace(num_classes=19))
+    cp.samples_with_class = {c: (["a.png"] if c in (0, 1, 5, 17) else []) for c in range(19)}
+    v = np.zeros(19)
+    v[[0, 1, 5, 17]] = 1.0 - 1e-6
+    cp.class_value = v
+    cp.class_probs = CopyPaste.calculate_class_probs(cp)
+    np.random.seed(3)
+    got = {int(cp.random_select(list(range(14)))) for _ in range(50)}
+    assert got <= {0, 1, 5} and len(got) >= 2          # 17 is outside the selected (hard) set
+    cp.samples_with_class = {c: [] for c in range(19)}
+    assert cp.random_select(list(range(14))) is None
+
+
 def test_copy_paste_matches_reference_golden(golden):
     g = golden("copy_paste")
     N, H, W, C = [int(v) for v in g["shape"]]

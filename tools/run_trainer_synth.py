@@ -1,0 +1,94 @@
+"""BASELINE configs[2] as the real workflow, end to end THROUGH THE DATALOADER: TRAINER['ConsistencySelfTrainingTrainer']
+on N synthetic Cityscapes-size (2048x1024) target images whose pseudo-labels were written by PSEUDO_POLICY['IAS'] first
+(PNG decode + CopyPaste + flip / random-sized crop / resize to 1024x512 + two colour views in DataLoader worker
+processes -> H2D -> teacher forward, student forward/backward, Adam, EMA).  Prints images/s including the host data path
+next to the compute-only number bench.py reports.
+    python tools/run_trainer_synth.py [N=32] [batch=8] [workers=14] [iters=24] [native_h=1024] [native_w=2048]"""
+import os
+import shutil
+import sys
+import tempfile
+import time
+
+import torch
+
+LOG = os.environ.get("HIAST_LOG")        # progress also goes to this file (gpurun watches gpurun_out/ for liveness)
+_print = print
+
+
+def print(*a, **k):     # noqa: A001
+    _print(*a, **k)
+    if LOG:
+        with open(LOG, "a") as f:
+            _print(*a, file=f)
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from hiast_amd.utils.registry import register  # noqa: E402,F401
+from hiast_amd.utils.registry.registries import MODEL, PSEUDO_POLICY, TRAINER  # noqa: E402
+from hiast_amd.tools import synth_data  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+bs = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+nw = int(sys.argv[3]) if len(sys.argv) > 3 else 14
+iters = int(sys.argv[4]) if len(sys.argv) > 4 else 24
+nh = int(sys.argv[5]) if len(sys.argv) > 5 else 1024
+nwid = int(sys.argv[6]) if len(sys.argv) > 6 else 2048
+root = tempfile.mkdtemp(prefix="hiast_train_")
+try:
+    t0 = time.time()
+    cfg = synth_data.synthetic_cfg(root, n_train=N, n_val=2, h=nh, w=nwid, upscale=2, procs=min(nw, 14))
+    print("wrote %d synthetic %dx%d images in %.1fs" % (N, nwid, nh, time.time() - t0), flush=True)
+    torch.manual_seed(888)
+    m = MODEL["SelfTrainingSegmentor"](cfg)
+    ck = os.path.join(root, "warmup.pth")
+    torch.save(m.state_dict(), ck)
+    del m
+    cfg.pseudo_policy.resume_from = ck
+    cfg.pseudo_policy.batch_size = 4
+    cfg.pseudo_policy.resize_size = [nh, nwid]
+    cfg.dataset.num_workers = nw
+    t0 = time.time()
+    PSEUDO_POLICY["IAS"](cfg).run()
+    torch.cuda.synchronize()
+    print("IAS generator at %dx%d: %d images in %.1fs (first call, includes kernel load)" % (nwid, nh, N, time.time() - t0),
+          flush=True)
+
+    cfg.trainer = "ConsistencySelfTrainingTrainer"
+    cfg.train.resume_from = ck
+    cfg.train.gpu_num = 1
+    cfg.train.batch_size = bs
+    cfg.train.total_iter = 10 ** 6
+    cfg.train.iter_report = 10 ** 6
+    cfg.train.iter_val = 10 ** 6
+    cfg.train.lr = 3e-6
+    cfg.dataset.target.pseudo_dir = cfg.pseudo_policy.save_dir
+    cfg.dataset.target.aug_type = ["MS", "CCA"]
+    cfg.cst_training.is_enabled = True
+    cfg.cst_training.cst_loss.weight = 0.5
+    cfg.preprocessor.type = "CopyPaste"
+    cfg.work_dir = os.path.join(root, "work")
+    tr = TRAINER[cfg.trainer](cfg, 0)
+    warm = 6
+    for it in range(1, warm + 1):
+        tr.step(it)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    t_data = 0.0
+    for it in range(warm + 1, warm + iters + 1):
+        tr.step(it)
+    torch.cuda.synchronize()
+    dt = (time.time() - t0) / iters
+    print("ConsistencySelfTrainingTrainer end to end (DataLoader, %d workers, CopyPaste + MS + CCA, bs %d): "
+          "%.1f ms/iter = %.1f images/s" % (nw, bs, dt * 1e3, bs / dt), flush=True)
+    # host data path alone: how fast can the workers deliver batches?
+    t0 = time.time()
+    k = 0
+    for _ in range(iters):
+        tr.next_target_batch()
+        k += 1
+    dl = (time.time() - t0) / k
+    print("DataLoader alone: %.1f ms/batch = %.1f images/s with %d workers" % (dl * 1e3, bs / dl, nw), flush=True)
+finally:
+    shutil.rmtree(root, ignore_errors=True)
