@@ -221,23 +221,44 @@ class HotPath:
         self.strong = (self.weak * 1.05 + 0.02).contiguous() if self.teacher else self.weak
         self.thr = 0.9 * np.ones(C)
         self.class_mean_probs = np.zeros(C)
+        self._hist_host = self._hist_ready = None
+        self.pipelined = os.environ.get("HIAST_BENCH_SERIAL", "0") != "1"
 
     def _allreduce(self, t):
         if self.world > 1:
             dist.all_reduce(t)
         return t
 
-    def plabel_pass(self):
+    # One step = the pseudo-label pass and the training step on the same batch.  Both are split at the point where the
+    # host is needed (the IAS threshold update reads the per-class histogram back): the training step's two forward
+    # passes do not depend on the pseudo labels, so they are ENQUEUED before the host waits for the histogram — the
+    # device works through them while the host computes the thresholds, and the launch queue never runs dry behind
+    # the read-back (it did: 0.8 ms of idle device per step + a host that stayed just-in-time for the rest of the step,
+    # profiles/r01_s3_critical_before.txt).  No work is skipped or reordered across steps.
+    def plabel_begin(self):
+        """eval forward (fp32-class) + pass 1 + asynchronous read-back of the histogram"""
         from hiast_amd import kernels as K
-        from hiast_amd.workflows import ias_math
         net = self.ema if self.teacher else self.model.module     # train.sh generates with the EMA model
         net.eval()
         with torch.no_grad():
             out = net(self.weak, lowres=True)                     # fp32, like the reference generator
             mp, am, hist = K.plabel_pass1(out["logits_lowres"].contiguous(), H, W)
             hist = self._allreduce(hist)
+            if self._hist_host is None:
+                self._hist_host = torch.empty(hist.shape, dtype=hist.dtype, pin_memory=True)
+                self._hist_ready = torch.cuda.Event()
+            self._hist_host.copy_(hist, non_blocking=True)
+            self._hist_ready.record()
+        return mp, am
+
+    def plabel_finish(self, mp, am):
+        """host: thresholds from the histogram (bit-identical to the reference's list + np.quantile); pass 2"""
+        from hiast_amd import kernels as K
+        from hiast_amd.workflows import ias_math
+        with torch.no_grad():
+            self._hist_ready.synchronize()
             ias = self.cfg.pseudo_policy.ias
-            _, self.thr = ias_math.ias_update(hist.cpu().numpy().view(np.uint32), self.thr, ias.alpha, ias.beta,
+            _, self.thr = ias_math.ias_update(self._hist_host.numpy().view(np.uint32), self.thr, ias.alpha, ias.beta,
                                               ias.gamma)
             thr_up = torch.from_numpy(ias_math.roundup_f32(self.thr)).to(self.device)
             plbl, count, sfx = K.plabel_pass2(mp, am, thr_up, C)
@@ -246,8 +267,11 @@ class HotPath:
         self._stats = (cnt, sfx)
         return plbl
 
-    def train_step(self, plbl):
-        from hiast_amd import functional as HF
+    def plabel_pass(self):
+        return self.plabel_finish(*self.plabel_begin())
+
+    def train_forward(self):
+        """EMA-teacher forward (no grad) and student forward of the training step -> (student out, teacher logits)"""
         self.model.train()
         teacher_lr = None
         main = torch.cuda.current_stream()
@@ -265,6 +289,11 @@ class HotPath:
         if self.teacher and side is not main:
             main.wait_stream(side)
             teacher_lr.record_stream(main)
+        return out, teacher_lr
+
+    def train_finish(self, plbl, out, teacher_lr):
+        """fused 4-term loss, backward, Adam, EMA update, scheduler"""
+        from hiast_amd import functional as HF
         losses = self.model.module.compute_loss_lowres(out["logits_lowres"], plbl, out["size"], teacher_lr)
         g_loss = sum(torch.mean(v) for v in losses.values())
         self.opt.zero_grad(set_to_none=True)
@@ -277,9 +306,29 @@ class HotPath:
             s.step()
         return losses
 
-    def step(self):
-        plbl = self.plabel_pass()
-        return self.train_step(plbl), plbl
+    def train_step(self, plbl):
+        return self.train_finish(plbl, *self.train_forward())
+
+    def step(self, marks=None):
+        """marks: optional list of 5 events bracketing the four parts"""
+        rec = (lambda i: marks[i].record()) if marks is not None else (lambda i: None)
+        rec(0)
+        mp, am = self.plabel_begin()
+        rec(1)
+        if self.pipelined:
+            out, teacher_lr = self.train_forward()
+            rec(2)
+            plbl = self.plabel_finish(mp, am)
+            rec(3)
+        else:
+            plbl = self.plabel_finish(mp, am)
+            rec(2)
+            rec(3)
+            out, teacher_lr = self.train_forward()
+            # (marks 2..3 then bracket nothing; the forward is counted with the rest of the training step)
+        losses = self.train_finish(plbl, out, teacher_lr)
+        rec(4)
+        return losses, plbl
 
 
 def cpu_baseline(cfg, size, threads):
@@ -379,17 +428,17 @@ def main():
         timer.on = it % 3 == 0          # per-launch events cost ~5 us each (460 per step): sample every third step
         hp.use_side = not timer.on      # ... and on those steps nothing runs beside the timed kernels (teacher on the
                                         # main stream), so the per-launch durations are not stretched by co-running work
-        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-        e[0].record()
-        plbl = hp.plabel_pass()
-        e[1].record()
-        hp.train_step(plbl)
-        e[2].record()
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        hp.step(e)
         marks.append(e)
     sync()
     elapsed = time.perf_counter() - t0
-    t_pl = sum(e[0].elapsed_time(e[1]) for e in marks) * 1e-3
-    t_tr = sum(e[1].elapsed_time(e[2]) for e in marks) * 1e-3
+    if hp.pipelined:    # pseudo-label pass = [0,1] + [2,3]; training step = [1,2] + [3,4]
+        t_pl = sum(e[0].elapsed_time(e[1]) + e[2].elapsed_time(e[3]) for e in marks) * 1e-3
+        t_tr = sum(e[1].elapsed_time(e[2]) + e[3].elapsed_time(e[4]) for e in marks) * 1e-3
+    else:
+        t_pl = sum(e[0].elapsed_time(e[2]) for e in marks) * 1e-3
+        t_tr = sum(e[3].elapsed_time(e[4]) for e in marks) * 1e-3
     timer.on = False
     marker()
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)

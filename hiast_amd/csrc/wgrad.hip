@@ -59,10 +59,20 @@ __global__ __launch_bounds__(512) void wgrad_tn_kernel(const unsigned short* __r
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;             // wave tile: n rows [128*wm, +128), k cols [64*wn, +64)
     const int kt_tiles = K / 256;
-    int t = blockIdx.x;                                   // (n tile, k tile, tap)
+    // XCD-aware block order: the dispatcher deals consecutive workgroup ids round-robin over the 8 XCDs (private L2
+    // each).  The logical order is pixel range OUTER / (n tile, k tile, tap) INNER, and XCD k takes the k-th contiguous
+    // share of it: the blocks that re-read one pixel range's dY and X rows (all taps, all tiles) sit on ONE XCD at the
+    // same time, so those rows leave HBM once instead of once per XCD they were dealt to.
+    int lid = blockIdx.x + gridDim.x * blockIdx.y;
+    {
+        const int total = gridDim.x * gridDim.y, base = total >> 3, rem = total & 7;
+        const int xcd = lid & 7, slot = lid >> 3;
+        lid = xcd * base + (xcd < rem ? xcd : rem) + slot;
+    }
+    int t = lid % (int)gridDim.x;                         // (n tile, k tile, tap)
     const int tap = t % TAPS; t /= TAPS;
     const int k0 = (t % kt_tiles) * 256, n0 = (t / kt_tiles) * 256;
-    const int split = blockIdx.y;
+    const int split = lid / (int)gridDim.x;
     const int m_begin = split * m_per_split;
     const int m_end = (m_begin + m_per_split < M) ? m_begin + m_per_split : M;
     const int nk = (m_end - m_begin + WG_ROWS - 1) / WG_ROWS;
@@ -181,26 +191,35 @@ __global__ __launch_bounds__(512) void wgrad_tn_kernel(const unsigned short* __r
         }
 }
 
-// dW[n][k][tap] (torch [N][K][kh][kw]) = Σ_s P[s][n][tap][k], ascending s; thread = (n, k)
+// dW[n][k][tap] (torch [N][K][kh][kw]) = Σ_s P[s][n][tap][k], ascending s; thread = (n, tap, k): the partials are read
+// as they lie (k fastest, fully coalesced), only the small result is written with the tap stride
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ P, float* __restrict__ dw, int N,
                                                            int K, int taps, int nsplit)
 {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long long)N * K) return;
-    const int n = (int)(idx / K), k = (int)(idx - (long long)n * K);
     const size_t per = (size_t)N * taps * K;
-    for (int t = 0; t < taps; ++t) {
-        float acc = 0.f;
-        const float* p = P + ((size_t)n * taps + t) * K + k;
-        for (int s = 0; s < nsplit; ++s) acc += p[(size_t)s * per];
-        dw[((size_t)n * K + k) * taps + t] = acc;
+    if (idx >= (long long)per) return;
+    const int k = (int)(idx % K);
+    const long long nt = idx / K;
+    const int t = (int)(nt % taps), n = (int)(nt / taps);
+    const float* p = P + idx;
+    float acc = 0.f;
+    int s = 0;
+    for (; s + 4 <= nsplit; s += 4) {           // four loads in flight, the additions keep their order
+        const float v0 = p[(size_t)s * per], v1 = p[(size_t)(s + 1) * per], v2 = p[(size_t)(s + 2) * per],
+                    v3 = p[(size_t)(s + 3) * per];
+        acc = (((acc + v0) + v1) + v2) + v3;
     }
+    for (; s < nsplit; ++s) acc += p[(size_t)s * per];
+    dw[((size_t)n * K + k) * taps + t] = acc;
 }
 
 static int wgrad_nsplit(long long M, int tiles, int taps)
 {
-    // ~1-2 blocks per CU in total, at least 8 k-steps (512 pixels) per block
-    long long s = (tiles >= 8 && taps == 1) ? (256 + tiles - 1) / tiles : (512 + tiles - 1) / tiles;
+    // one block per CU at a time (128 KiB of LDS each) and every block costs a 256 KiB partial tile written here and read
+    // again by the reduction: ONE round of <= 256 blocks (two rounds doubled the partial traffic — 129 MB against 67 MB
+    // of operands on the layer3 3x3 — for the same MFMA time per CU); at least 8 k-steps (512 pixels) per block
+    long long s = 256 / tiles;
     const long long smax = M / 512 > 0 ? M / 512 : 1;
     s = s < 1 ? 1 : (s > smax ? smax : s);
     s = s > 64 ? 64 : s;
@@ -244,7 +263,7 @@ extern "C" int hiast_conv_wgrad_nhwc(const void* dy, const void* x, float* dw, i
         hipLaunchKernelGGL(hiast::wgrad_tn_kernel<9>, grid, dim3(512), 0, st, (const unsigned short*)dy,
                            (const unsigned short*)x, (float*)workspace, (int)M, Cout, Cin, geo, mps);
     HIAST_CHECK_LAUNCH();
-    const long long total = (long long)Cout * Cin;
+    const long long total = (long long)Cout * Cin * taps;
     hipLaunchKernelGGL(hiast::wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                        (const float*)workspace, dw, Cout, Cin, taps, nsplit);
     HIAST_CHECK_LAUNCH();

@@ -867,13 +867,15 @@ def conv_wgrad_supported(Cin, Cout, k, stride):
 
 
 def conv_wgrad_preferred(Cin, Cout, k, stride):
-    """shapes on which it beats the library on MI355X (measured, tools/bench_kernels.py wgrad): the 1x1 convolutions
-    (layer3: 0.074 vs 0.114 ms); the 3x3 form re-reads dY once per tap and trails MIOpen (0.30 vs 0.17 ms) until it
-    shares the dY tile between taps — HIAST_OWN_WGRAD3=1 selects it anyway"""
+    """shapes on which it beats (3x3 at 512 channels: ties) the library on MI355X (measured, tools/bench_kernels.py
+    wgrad, B=8): 1x1 layer3 0.062 vs 0.112 ms, layer4 0.225 vs 0.255 ms; 3x3 layer3 0.153 vs 0.165 ms, layer4 0.490 vs
+    0.488 ms — and the library's result still needs a cast + layout kernel.  (The 3x3 form used to trail at 0.30 ms:
+    two rounds of blocks doubled the partial-tile traffic and the nine tap blocks of a pixel range were dealt to eight
+    different L2s.)  HIAST_LIB_WGRAD3=1 sends the 3x3 shapes to the library."""
     import os
     if not conv_wgrad_supported(Cin, Cout, k, stride):
         return False
-    return k == 1 or os.environ.get("HIAST_OWN_WGRAD3", "0") == "1"
+    return k == 1 or os.environ.get("HIAST_LIB_WGRAD3", "0") != "1"
 
 
 def conv_wgrad_nhwc(dy, x, k, stride, dil):

@@ -529,7 +529,7 @@ def test_conv_nhwc_autograd_vs_fp64(K, cfg, monkeypatch):
     """_ConvNhwcFn (igemm forward / data gradient; weight gradient by hiast_conv_wgrad_nhwc where the shape allows,
     else by the library) vs float64 autograd on bf16-rounded data"""
     from hiast_amd import functional as HF
-    monkeypatch.setenv("HIAST_OWN_WGRAD3", "1")          # exercise the 3x3 form of the own weight-gradient kernel too
+    monkeypatch.delenv("HIAST_LIB_WGRAD3", raising=False)  # the 3x3 form of the own weight-gradient kernel is the default
     B, Cin, Cout, H, W, k, stride, dil = cfg
     conv = torch.nn.Conv2d(Cin, Cout, k, stride=stride, padding=dil if k == 3 else 0, dilation=dil if k == 3 else 1,
                            bias=False).cuda()
