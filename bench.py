@@ -241,8 +241,8 @@ class HotPath:
         net = self.ema if self.teacher else self.model.module     # train.sh generates with the EMA model
         net.eval()
         with torch.no_grad():
-            out = net(self.weak, lowres=True)                     # fp32, like the reference generator
-            mp, am, hist = K.plabel_pass1(out["logits_lowres"].contiguous(), H, W)
+            logits = net(self.weak, lowres=True)["logits_lowres"]     # fp32, like the reference generator
+            mp, am, hist = K.plabel_pass1(logits.contiguous(), H, W)
             hist = self._allreduce(hist)
             if self._hist_host is None:
                 self._hist_host = torch.empty(hist.shape, dtype=hist.dtype, pin_memory=True)
@@ -260,7 +260,7 @@ class HotPath:
             ias = self.cfg.pseudo_policy.ias
             _, self.thr = ias_math.ias_update(self._hist_host.numpy().view(np.uint32), self.thr, ias.alpha, ias.beta,
                                               ias.gamma)
-            thr_up = torch.from_numpy(ias_math.roundup_f32(self.thr)).to(self.device)
+            thr_up = K.h2d_async(ias_math.roundup_f32(self.thr), self.device)
             plbl, count, sfx = K.plabel_pass2(mp, am, thr_up, C)
             cnt = self._allreduce(count.sum(0))
             sfx = self._allreduce(sfx)
@@ -311,7 +311,12 @@ class HotPath:
 
     def step(self, marks=None):
         """marks: optional list of 5 events bracketing the four parts"""
-        rec = (lambda i: marks[i].record()) if marks is not None else (lambda i: None)
+        host = self.host_marks = [0.0] * 5       # host clock at the same points: how long the ENQUEUE of each part takes
+
+        def rec(i):
+            host[i] = time.perf_counter()
+            if marks is not None:
+                marks[i].record()
         rec(0)
         mp, am = self.plabel_begin()
         rec(1)
@@ -422,7 +427,7 @@ def main():
     timer.on = True
     # phases are timed with HIP events on the launch stream: no host synchronisation inside the timed region (the only
     # blocking point is the histogram read-back the IAS threshold update needs), so consecutive steps pipeline
-    marks = []
+    marks, host_parts = [], []
     t0 = time.perf_counter()
     for it in range(args.steps):
         timer.on = it % 3 == 0          # per-launch events cost ~5 us each (460 per step): sample every third step
@@ -431,6 +436,8 @@ def main():
         e = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         hp.step(e)
         marks.append(e)
+        if not timer.on:
+            host_parts.append([1e3 * (hp.host_marks[i + 1] - hp.host_marks[i]) for i in range(4)])
     sync()
     elapsed = time.perf_counter() - t0
     if hp.pipelined:    # pseudo-label pass = [0,1] + [2,3]; training step = [1,2] + [3,4]
@@ -462,6 +469,12 @@ def main():
                        "images_per_gpu_per_step": args.batch, "num_classes": C,
                        "parallelism": "dp%d" % world if world > 1 else "single"},
             "phases_ms": {"pseudo_label": 1e3 * t_pl / args.steps, "train_step": 1e3 * t_tr / args.steps},
+            # host time spent ENQUEUING each part (steps without per-launch events; the third entry includes the wait
+            # for the histogram): the sum must stay below ms_per_step or the step is launch-bound
+            "host_enqueue_ms": dict(zip(["plabel_fwd_pass1", "train_forwards", "hist_wait_thresholds_pass2",
+                                         "loss_bwd_adam_ema"] if hp.pipelined else
+                                        ["plabel_fwd_pass1", "hist_wait_thresholds_pass2", "-", "train_step"],
+                                        [float(v) for v in np.mean(np.array(host_parts), axis=0)])) if host_parts else None,
         }
         groups = timer.summary()
         if groups:

@@ -363,6 +363,9 @@ class _ConvNhwcFn(torch.autograd.Function):
                 if need_w and not own_w:
                     # fp32, NCHW-contiguous like the parameter (DDP's gradient-layout contract): one cast+layout kernel
                     dw = gw.to(dtype=weight.dtype, memory_format=torch.contiguous_format)
+                    if dw.stride() != weight.stride() and dw.is_contiguous() and weight.is_contiguous():
+                        dw = dw.view(-1).view(weight.shape)     # 1x1 kernels: canonical strides for the size-1 dims
+                                                                # (DDP compares strides with its bucket view literally)
         if side is not None and dw is not None:
             dw.record_stream(main)
         return dx, dw, None, None, None, None, None

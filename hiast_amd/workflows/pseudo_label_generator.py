@@ -81,7 +81,7 @@ class HipPlabelEngine:
         if self._mp is None:
             z = torch.zeros((C,), dtype=torch.int64, device=self.device)
             return None, torch.zeros((0, C), dtype=torch.int64, device=self.device), z
-        thr_up = None if thr64 is None else torch.from_numpy(ias_math.roundup_f32(thr64)).to(self.device)
+        thr_up = None if thr64 is None else K.h2d_async(ias_math.roundup_f32(thr64), self.device)
         plbl, count, sfx = K.plabel_pass2(self._mp, self._am, thr_up, C)
         return plbl, count, sfx
 
