@@ -591,6 +591,27 @@ def test_wgrad_side_stream_gives_identical_gradients(K):
     assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])   # own kernel: deterministic
 
 
+@pytest.mark.parametrize("cfg", [(2, 256, 256, 64, 128, 3, 2), (1, 512, 512, 64, 128, 3, 4), (2, 1024, 256, 64, 128, 1, 1),
+                                 (1, 256, 1024, 61, 77, 1, 1), (1, 256, 256, 50, 70, 3, 1)])
+def test_conv_wgrad_many_pixel_ranges(K, cfg):
+    """hiast_conv_wgrad_nhwc at sizes where the pixel index is split over many blocks (28-64 ranges): the XCD-aware
+    block order with a block count that is not a multiple of 8, ragged last ranges, the coalesced fixed-order reduce;
+    against the fp32 weight gradient of the same bf16-rounded operands; bitwise repeatable"""
+    B, Cin, Cout, H, W, k, dil = cfg
+    x = dev(_bf16r(synth.normal_f32(970, (B, H, W, Cin)))).bfloat16()
+    dy = dev(_bf16r(synth.normal_f32(971, (B, H, W, Cout)))).bfloat16()
+    dw = K.conv_wgrad_nhwc(dy, x, k, 1, dil)
+    assert dw.dtype == torch.float32 and tuple(dw.shape) == (Cout, Cin, k, k)
+    pad = dil if k == 3 else 0
+    # the library's fp32 weight gradient of the same (exactly representable) operands: both sides only differ by their
+    # fp32 accumulation order; a lost tap / pixel range / block would be off by O(max|dW|)
+    ref = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2).float(), (Cout, Cin, k, k), dy.permute(0, 3, 1, 2).float(),
+                                      stride=1, padding=pad, dilation=dil if k == 3 else 1)
+    err = (dw - ref).abs().max().item()
+    assert err <= 1e-4 * ref.abs().max().item(), (err, ref.abs().max().item())
+    assert torch.equal(dw, K.conv_wgrad_nhwc(dy, x, k, 1, dil))
+
+
 def test_bottleneck_identity_handoff_matches_autograd_add(K, monkeypatch):
     """identity block, channels-last training path: the gradient of the identity branch added in conv1's data-gradient
     epilogue (gated by the block output) vs the plain autograd formulation (masked copy + add kernel)"""
