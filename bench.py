@@ -179,16 +179,25 @@ def roofline_of(key, avg_ms, n, steps):
         PL, "f32out" if out_f32 else "16-bit out", taps, "split-bf16" if PL == 2 else "bf16",
         " + BN" if has_bn else " (plain: student forward / data gradient)", " + residual" if has_res else "",
         " + ReLU" if relu else "")
-    return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+    # the binding roof is the one the launch sits closer to: MFMA (algorithmic flops against the dense bf16 peak, /3 for
+    # split planes) or HBM (algorithmic bytes against 8 TB/s)
+    t = avg_ms * 1e-3
+    f_mfma, hbm_tbs = ach / peak, alg_bytes / t / 1e12
+    f_hbm = hbm_tbs / 8.0
+    flavour = ("fp32-equivalent flops: the kernel issues 3 bf16 MFMA flops per algorithmic flop (hi*hi + lo*hi + hi*lo), "
+               "MFMA ceiling = dense bf16 peak 2500/3 TFLOP/s" if PL == 2 else "plain bf16 MFMA, ceiling 2500 TFLOP/s dense")
+    shape = "B=%d %dx%d Cin=%d Cout=%d taps=%d dil=%d" % (B, Hh, Ww, Cin, Cout, taps, dil)
+    if f_hbm > f_mfma:
+        return {"kernel": name, "bound": "hbm", "achieved": hbm_tbs * 1e3, "peak": 8000.0, "unit": "GB/s", "frac": f_hbm,
+                "traffic": traffic, "avg_launch_ms": avg_ms, "launches_per_step": n / steps,
+                "note": "algorithmic %.0f MB per launch (%s: input + weights + output%s, 16-bit%s); the MFMA side: %.1f "
+                        "GFLOP -> %.0f TFLOP/s = %.0f%% of its ceiling (%s)"
+                        % (alg_bytes / 1e6, shape, " + residual" if has_res else "", " hi|lo pairs" if PL == 2 else "",
+                           flop / 1e9, ach, 100.0 * f_mfma, flavour)}
+    return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": f_mfma,
             "traffic": traffic, "avg_launch_ms": avg_ms, "launches_per_step": n / steps,
-            "note": "algorithmic %.1f GFLOP per launch (B=%d %dx%d Cin=%d Cout=%d taps=%d dil=%d); %s; algorithmic "
-                    "HBM bytes per launch %.0f MB -> %.2f TB/s (HBM time at 8 TB/s = %.0f%% of the launch: the MFMA "
-                    "bound is the binding one unless that nears 100%%)"
-                    % (flop / 1e9, B, Hh, Ww, Cin, Cout, taps, dil,
-                       "fp32-equivalent flops: the kernel issues 3 bf16 MFMA flops per algorithmic flop (hi*hi + lo*hi + "
-                       "hi*lo), ceiling = dense bf16 MFMA peak 2500/3 TFLOP/s" if PL == 2 else
-                       "plain bf16 MFMA, ceiling 2500 TFLOP/s dense",
-                       alg_bytes / 1e6, alg_bytes / (avg_ms * 1e-3) / 1e12, 100.0 * alg_bytes / 8e12 / (avg_ms * 1e-3))}
+            "note": "algorithmic %.1f GFLOP per launch (%s); %s; algorithmic HBM bytes per launch %.0f MB -> %.2f TB/s = "
+                    "%.0f%% of the 8 TB/s HBM roof" % (flop / 1e9, shape, flavour, alg_bytes / 1e6, hbm_tbs, 100.0 * f_hbm)}
 
 
 class HotPath:
@@ -403,7 +412,9 @@ def main():
     torch.backends.cudnn.benchmark = bool(int(os.environ.get("HIAST_MIOPEN_FIND", "0")))
 
     cfg = make_cfg(world, args.trainer)
-    hp = HotPath(cfg, device, rank, world, args.batch)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):        # the package's progress prints ("%% freeze all BN layers" ...)
+        hp = HotPath(cfg, device, rank, world, args.batch)   # must not precede the ONE JSON line on stdout
     timer = KernelTimer()
     timer.install()
 
@@ -428,11 +439,13 @@ def main():
     # phases are timed with HIP events on the launch stream: no host synchronisation inside the timed region (the only
     # blocking point is the histogram read-back the IAS threshold update needs), so consecutive steps pipeline
     marks, host_parts = [], []
+    from hiast_amd import functional as HF
     t0 = time.perf_counter()
     for it in range(args.steps):
-        timer.on = it % 3 == 0          # per-launch events cost ~5 us each (460 per step): sample every third step
-        hp.use_side = not timer.on      # ... and on those steps nothing runs beside the timed kernels (teacher on the
-                                        # main stream), so the per-launch durations are not stretched by co-running work
+        timer.on = it % 6 == 0          # per-launch events cost ~5 us each (460 per step): sample every sixth step
+        hp.use_side = not timer.on      # ... and on those steps nothing runs beside the timed kernels (teacher forward
+        HF.enable_wgrad_overlap(not timer.on)   # and weight gradients on the main stream), so the per-launch durations
+                                                # are not stretched by co-running work
         e = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         hp.step(e)
         marks.append(e)
@@ -478,7 +491,7 @@ def main():
         }
         groups = timer.summary()
         if groups:
-            sampled = len(range(0, args.steps, 3))      # steps on which launches were timed
+            sampled = len(range(0, args.steps, 6))      # steps on which launches were timed
             aspp = [g for g in groups if g[0][0] == "aspp2_fwd"]
             groups = [g for g in groups if g[0][0] != "aspp2_fwd"]   # (its GEMM is also counted in the igemm groups)
             key, avg_ms, n, _tot = groups[0]            # dominant hand-written launch group of the step
@@ -489,7 +502,8 @@ def main():
                                      for o in others]
         if not args.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(cfg, tuple(args.cpu_size), args.cpu_threads)
+                with contextlib.redirect_stdout(sys.stderr):
+                    out["cpu_baseline"] = cpu_baseline(cfg, tuple(args.cpu_size), args.cpu_threads)
             except Exception as e:      # the baseline must never take the measurement down
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out))
