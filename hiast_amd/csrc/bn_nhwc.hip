@@ -21,15 +21,19 @@ namespace hiast {
 
 constexpr int BNH_MAXBLK = 512;
 
-__device__ __forceinline__ void bnh_load8(const unsigned short* p, float (&v)[8])
+__device__ __forceinline__ void bnh_unpack8(const uint4 r, float (&v)[8])
 {
-    const uint4 r = *reinterpret_cast<const uint4*>(p);
     const unsigned w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         v[2 * i] = __uint_as_float(w[i] << 16);
         v[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
     }
+}
+
+__device__ __forceinline__ void bnh_load8(const unsigned short* p, float (&v)[8])
+{
+    bnh_unpack8(*reinterpret_cast<const uint4*>(p), v);
 }
 
 __device__ __forceinline__ void bnh_store8(unsigned short* p, const float (&v)[8])
@@ -70,26 +74,48 @@ __global__ __launch_bounds__(256) void bnh_partial_kernel(const unsigned short* 
         gsc[k] = GATE == 2 ? (gamma ? gamma[cg * 8 + k] : 1.0f) * invstd[k] : 0.f;
         gsh[k] = GATE == 2 ? fmaf(-mean[k], gsc[k], beta ? beta[cg * 8 + k] : 0.0f) : 0.f;
     }
-    for (long long r = (long long)blockIdx.x * RPP + rsub; r < M; r += (long long)gridDim.x * RPP) {
-        const size_t off = (size_t)r * C + cg * 8;
-        float v[8];
-        bnh_load8(a + off, v);
-        if (!BWD) {
+    // UNR rows per thread in flight: with at most BNH_MAXBLK blocks (the partial array and its finalize pass scale with
+    // the block count) one row per iteration left 16 KiB of loads in flight per CU and the pass ran at 2.1-2.6 TB/s;
+    // all loads of UNR rows are issued before the first is used.  The rows are still accumulated in ascending order,
+    // so the sums are bit-identical to the one-row loop.
+    constexpr int UNR = 4;
+    const long long stride = (long long)gridDim.x * RPP;
+    for (long long r0 = (long long)blockIdx.x * RPP + rsub; r0 < M; r0 += stride * UNR) {
+        uint4 ra[UNR], ry[UNR], rx[UNR];
+        unsigned rbits[UNR];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { s1[k] += v[k]; s2[k] = fmaf(v[k], v[k], s2[k]); }
-        } else {
-            float yy[8], xx[8];
-            if (GATE == 1) bnh_load8(y + off, yy);
-            unsigned bits = 0;
-            if (GATE == 3) bits = reinterpret_cast<const unsigned char*>(y)[(size_t)r * G + cg];
-            bnh_load8(x + off, xx);
+        for (int u = 0; u < UNR; ++u) {
+            const long long r = r0 + u * stride;
+            const long long rc = r < M ? r : r0;                    // tail: re-read a valid row, not accumulated
+            const size_t off = (size_t)rc * C + cg * 8;
+            ra[u] = *reinterpret_cast<const uint4*>(a + off);
+            if (BWD) {
+                if (GATE == 1) ry[u] = *reinterpret_cast<const uint4*>(y + off);
+                rbits[u] = GATE == 3 ? reinterpret_cast<const unsigned char*>(y)[(size_t)rc * G + cg] : 0u;
+                rx[u] = *reinterpret_cast<const uint4*>(x + off);
+            }
+        }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const bool open = GATE == 0 || (GATE == 1 ? yy[k] > 0.f
-                                                : (GATE == 3 ? ((bits >> k) & 1u) != 0u : fmaf(xx[k], gsc[k], gsh[k]) > 0.f));
-                const float g = open ? v[k] : 0.f;
-                s1[k] += g;
-                s2[k] = fmaf(g, (xx[k] - mean[k]) * invstd[k], s2[k]);
+        for (int u = 0; u < UNR; ++u) {
+            if (r0 + u * stride >= M) break;
+            float v[8];
+            bnh_unpack8(ra[u], v);
+            if (!BWD) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { s1[k] += v[k]; s2[k] = fmaf(v[k], v[k], s2[k]); }
+            } else {
+                float yy[8], xx[8];
+                if (GATE == 1) bnh_unpack8(ry[u], yy);
+                const unsigned bits = rbits[u];
+                bnh_unpack8(rx[u], xx);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const bool open = GATE == 0 || (GATE == 1 ? yy[k] > 0.f
+                                                    : (GATE == 3 ? ((bits >> k) & 1u) != 0u : fmaf(xx[k], gsc[k], gsh[k]) > 0.f));
+                    const float g = open ? v[k] : 0.f;
+                    s1[k] += g;
+                    s2[k] = fmaf(g, (xx[k] - mean[k]) * invstd[k], s2[k]);
+                }
             }
         }
     }
@@ -211,22 +237,38 @@ __global__ __launch_bounds__(256) void bnh_apply_kernel(const unsigned short* __
         scale[k] = (gamma ? gamma[c] : 1.0f) * save_invstd[c];
         shift[k] = fmaf(-save_mean[c], scale[k], beta ? beta[c] : 0.0f);
     }
-    for (long long r = (long long)blockIdx.x * RPP + rsub; r < M; r += (long long)gridDim.x * RPP) {
-        const size_t off = (size_t)r * C + cg * 8;
-        float v[8], rr[8];
-        bnh_load8(x + off, v);
-        if (RES) bnh_load8(res + off, rr);
-        unsigned bits = 0;
+    // two rows per thread in flight (all loads first): the 256-channel maps run 4 blocks per CU
+    constexpr int UNR = 2;
+    const long long stride = (long long)gridDim.x * RPP;
+    for (long long r0 = (long long)blockIdx.x * RPP + rsub; r0 < M; r0 += stride * UNR) {
+        uint4 rx[UNR], rres[UNR];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            float o = fmaf(v[k], scale[k], shift[k]);
-            if (RES) o += rr[k];
-            if (RELU) o = o > 0.f ? o : 0.f;
-            bits |= (o > 0.f ? 1u : 0u) << k;
-            v[k] = o;
+        for (int u = 0; u < UNR; ++u) {
+            const long long r = r0 + u * stride;
+            const size_t off = (size_t)(r < M ? r : r0) * C + cg * 8;
+            rx[u] = *reinterpret_cast<const uint4*>(x + off);
+            if (RES) rres[u] = *reinterpret_cast<const uint4*>(res + off);
         }
-        bnh_store8(y + off, v);
-        if (mask) mask[(size_t)r * G + cg] = (unsigned char)bits;
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const long long r = r0 + u * stride;
+            if (r >= M) break;
+            const size_t off = (size_t)r * C + cg * 8;
+            float v[8], rr[8];
+            bnh_unpack8(rx[u], v);
+            if (RES) bnh_unpack8(rres[u], rr);
+            unsigned bits = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float o = fmaf(v[k], scale[k], shift[k]);
+                if (RES) o += rr[k];
+                if (RELU) o = o > 0.f ? o : 0.f;
+                bits |= (o > 0.f ? 1u : 0u) << k;
+                v[k] = o;
+            }
+            bnh_store8(y + off, v);
+            if (mask) mask[(size_t)r * G + cg] = (unsigned char)bits;
+        }
     }
 }
 
@@ -256,24 +298,42 @@ __global__ __launch_bounds__(256) void bnh_bwd_apply_kernel(
         mg[k] = (float)(s1 * inv_count);
         mgx[k] = (float)(s2 * inv_count);
     }
-    for (long long r = (long long)blockIdx.x * RPP + rsub; r < M; r += (long long)gridDim.x * RPP) {
-        const size_t off = (size_t)r * C + cg * 8;
-        float g[8], yy[8], xx[8];
-        bnh_load8(dy + off, g);
-        if (GATE == 1) bnh_load8(y + off, yy);
-        unsigned bits = 0;
-        if (GATE == 3) bits = reinterpret_cast<const unsigned char*>(y)[(size_t)r * G + cg];
-        bnh_load8(x + off, xx);
+    constexpr int UNR = 2;                               // two rows per thread in flight (all loads first)
+    const long long stride = (long long)gridDim.x * RPP;
+    for (long long r0 = (long long)blockIdx.x * RPP + rsub; r0 < M; r0 += stride * UNR) {
+        uint4 rg[UNR], ry[UNR], rx[UNR];
+        unsigned rbits[UNR];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const bool open = GATE == 0 || (GATE == 1 ? yy[k] > 0.f
-                                            : (GATE == 3 ? ((bits >> k) & 1u) != 0u : fmaf(xx[k], k0[k], gsh[k]) > 0.f));
-            const float gg = open ? g[k] : 0.f;
-            g[k] = gg;
-            xx[k] = k0[k] * (gg - mg[k] - (xx[k] - mean[k]) * invstd[k] * mgx[k]);
+        for (int u = 0; u < UNR; ++u) {
+            const long long r = r0 + u * stride;
+            const long long rc = r < M ? r : r0;
+            const size_t off = (size_t)rc * C + cg * 8;
+            rg[u] = *reinterpret_cast<const uint4*>(dy + off);
+            if (GATE == 1) ry[u] = *reinterpret_cast<const uint4*>(y + off);
+            rbits[u] = GATE == 3 ? reinterpret_cast<const unsigned char*>(y)[(size_t)rc * G + cg] : 0u;
+            rx[u] = *reinterpret_cast<const uint4*>(x + off);
         }
-        bnh_store8(dx + off, xx);
-        if (DRES) bnh_store8(dres + off, g);
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const long long r = r0 + u * stride;
+            if (r >= M) break;
+            const size_t off = (size_t)r * C + cg * 8;
+            float g[8], yy[8], xx[8];
+            bnh_unpack8(rg[u], g);
+            if (GATE == 1) bnh_unpack8(ry[u], yy);
+            const unsigned bits = rbits[u];
+            bnh_unpack8(rx[u], xx);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const bool open = GATE == 0 || (GATE == 1 ? yy[k] > 0.f
+                                                : (GATE == 3 ? ((bits >> k) & 1u) != 0u : fmaf(xx[k], k0[k], gsh[k]) > 0.f));
+                const float gg = open ? g[k] : 0.f;
+                g[k] = gg;
+                xx[k] = k0[k] * (gg - mg[k] - (xx[k] - mean[k]) * invstd[k] * mgx[k]);
+            }
+            bnh_store8(dx + off, xx);
+            if (DRES) bnh_store8(dres + off, g);
+        }
     }
 }
 
@@ -338,7 +398,7 @@ extern "C" int hiast_bn_nhwc_apply(const void* x, const void* res, void* y, cons
     if (!y || !sums || !save_mean || !save_invstd || count <= 0) return HIAST_E_ARG;
     if ((((uintptr_t)y) | ((uintptr_t)res)) & 15) return HIAST_E_RANGE;
     const int rpp = 256 / (C / 8);
-    long long nb = (M + (long long)rpp * 8 - 1) / ((long long)rpp * 8);      // >= 8 rows per thread
+    long long nb = (M + (long long)rpp * 8 - 1) / ((long long)rpp * 8);      // >= 8 rows per thread (4: more blocks, each paying the scale/shift prologue - slower)
     nb = nb < 1 ? 1 : (nb > 2048 ? 2048 : nb);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(hiast::bnh_prep_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, count, momentum, eps,
