@@ -76,16 +76,22 @@ __device__ __forceinline__ size_t ig_elem(size_t m, int c, int C)
 // M16: build the wave tile from v_mfma_f32_16x16x32_bf16 (16 x 16 output tiles, 32-deep) instead of 32x32x16: the same
 // LDS bytes and MFMA cycles per flop, but the chip holds a higher clock on this shape under load (MI355X_MICROARCH.md,
 // DVFS give-back item 7) — both are built, the launcher picks by measurement (HIAST_IGEMM_MFMA16).
-template <int PL, bool OUTF32, int BN, int TAPS, bool RES, bool RELU, bool M16>
+// GATE (PL = 1, RES, no ReLU): 0 = plain residual; 1 = the residual is kept where the gate tensor Rg (values like R)
+// is > 0; 2 = where bit (n & 7) of byte Rg[m][n / 8] is set.  A compile-time switch: as a run-time test on Rg the
+// gate put ~500 branches and ~300 s_waitcnt into the epilogue of EVERY bf16 residual launch (the teacher forward
+// included), which serialised its residual prefetch.
+// STATS: emit the per-block BatchNorm sums (plain bf16 launches only: the student forward).
+template <int PL, bool OUTF32, int BN, int TAPS, bool RES, bool RELU, bool M16, int GATE = 0, bool STATS = false>
 __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
     const unsigned short* __restrict__ X, const unsigned short* __restrict__ Wp, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ var, float eps,
     const unsigned short* __restrict__ R, void* __restrict__ Yv, int M, int K, int N, IGeo geo, int dbg,
-    float* __restrict__ stats, const unsigned short* __restrict__ Rg,   // Rg (PL = 1, optional): the residual is gated,
-    int gate_mask)                       // o += gate ? R : 0 (ReLU-masked gradient); gate = Rg > 0 (values like R), or,
-                                         // with gate_mask, bit (n & 7) of byte Rg[m][n / 8]           // optional [gridDim m-blocks][N][2]: per-block Σy, Σy² of the STORED values
+    float* __restrict__ stats,           // optional [gridDim m-blocks][N][2]: per-block Σy, Σy² of the STORED values
+    const unsigned short* __restrict__ Rg)   // GATE != 0: o += gate ? R : 0 (the ReLU-masked gradient of an identity branch)
 {
+    static_assert(GATE == 0 || (PL == 1 && RES && !RELU && !OUTF32), "gated residual: bf16 data-gradient launches only");
     constexpr int WN = BN / 64, WM = 8 / WN;
+    static_assert(!STATS || (PL == 1 && !OUTF32 && !RES && !RELU), "statistics epilogue: plain bf16 launches only");
     constexpr int TM = IG_BM / WM / 32;                 // 32-row tiles per wave (4 | 2 | 1)
     constexpr int TN = 2;                               // 32-column tiles per wave
     constexpr int KK = PL == 2 ? 2 : 4;                 // 16-deep MFMA steps per slab
@@ -315,12 +321,10 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
             const size_t g = ig_elem<PL>((size_t)(m < M ? m : 0), nc, N);
             rhA[a][ps] = *reinterpret_cast<const uint4*>(R + g);
             if (PL == 2) rlA[a][ps] = *reinterpret_cast<const uint4*>(R + g + 32);
-            if (PL == 1 && Rg) {                                            // gate rows ride in rlA
-                if (gate_mask)
-                    rlA[a][ps].x = reinterpret_cast<const unsigned char*>(Rg)[(size_t)(m < M ? m : 0) * (N >> 3) + (nc >> 3)];
-                else
-                    rlA[a][ps] = *reinterpret_cast<const uint4*>(Rg + g);
-            }
+            if (GATE == 2)                                                  // gate rows ride in rlA
+                rlA[a][ps].x = reinterpret_cast<const unsigned char*>(Rg)[(size_t)(m < M ? m : 0) * (N >> 3) + (nc >> 3)];
+            else if (GATE == 1)
+                rlA[a][ps] = *reinterpret_cast<const uint4*>(Rg + g);
         }
     };
     if (RES) {
@@ -364,12 +368,12 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
             if (m < M) {
                 if (RES) {
                     unsigned wh[4] = {rh[ps].x, rh[ps].y, rh[ps].z, rh[ps].w};
-                    if (PL == 1 && Rg) {                 // keep a residual element only where its gate value is > 0
+                    if (GATE != 0) {                     // keep a residual element only where its gate value is > 0
                         const unsigned wg[4] = {rl4[ps].x, rl4[ps].y, rl4[ps].z, rl4[ps].w};
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const bool g0 = gate_mask ? ((wg[0] >> (2 * q)) & 1u) != 0u : __uint_as_float(wg[q] << 16) > 0.f;
-                            const bool g1 = gate_mask ? ((wg[0] >> (2 * q + 1)) & 1u) != 0u
+                            const bool g0 = GATE == 2 ? ((wg[0] >> (2 * q)) & 1u) != 0u : __uint_as_float(wg[q] << 16) > 0.f;
+                            const bool g1 = GATE == 2 ? ((wg[0] >> (2 * q + 1)) & 1u) != 0u
                                                       : __uint_as_float(wg[q] & 0xFFFF0000u) > 0.f;
                             wh[q] = (g0 ? wh[q] & 0x0000FFFFu : 0u) | (g1 ? wh[q] & 0xFFFF0000u : 0u);
                         }
@@ -406,7 +410,7 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
                         ig_split(o[2 * q + 1], h1, l1);
                         ph[q] = (unsigned)h0 | ((unsigned)h1 << 16);
                         pl_[q] = (unsigned)l0 | ((unsigned)l1 << 16);
-                        if (PL == 1 && stats) {          // statistics of what is stored (the bf16 roundings)
+                        if (STATS) {                     // statistics of what is stored (the bf16 roundings)
                             const float v0 = __uint_as_float((unsigned)h0 << 16), v1 = __uint_as_float((unsigned)h1 << 16);
                             st1[2 * q] += v0; st2[2 * q] = fmaf(v0, v0, st2[2 * q]);
                             st1[2 * q + 1] += v1; st2[2 * q + 1] = fmaf(v1, v1, st2[2 * q + 1]);
@@ -421,7 +425,7 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    if (PL == 1 && !OUTF32 && stats) {
+    if (STATS) {
         // fold the 8 row-lanes of each channel group (lane bits 3..5), then the WM waves that share these columns
         // (fixed order), and store this block's partial sums: the BN forward then needs no pass over Y for them
 #pragma unroll
@@ -595,13 +599,29 @@ static int launch_igemm_t(const void* x, const void* wp, const float* gamma, con
         if ((v == 64 || v == 128 || v == 256) && N % v == 0) BN = v;
     }
     dim3 grid((unsigned)((M + hiast::IG_BM - 1) / hiast::IG_BM), N / BN);
-#define L(BNV, T, RES, RELU)                                                                                         \
-    hipLaunchKernelGGL((hiast::igemm_bn_act_kernel<PL, OUTF32, BNV, T, RES, RELU, MF>), grid, dim3(512), 0, st,       \
+    const int gate = !res_gate ? 0 : (gate_mask ? 2 : 1);
+#define L(BNV, T, RES, RELU, G)                                                                                      \
+    hipLaunchKernelGGL((hiast::igemm_bn_act_kernel<PL, OUTF32, BNV, T, RES, RELU, MF, G>), grid, dim3(512), 0, st,    \
                        (const unsigned short*)x, (const unsigned short*)wp, gamma, beta, mean, var, eps,              \
-                       (const unsigned short*)res, y, (int)M, K, N, geo, dbg, stats, (const unsigned short*)res_gate, gate_mask)
-#define LL(BNV, T)                                                              \
-    if (res) { if (relu) L(BNV, T, true, true); else L(BNV, T, true, false); }  \
-    else { if (relu) L(BNV, T, false, true); else L(BNV, T, false, false); }
+                       (const unsigned short*)res, y, (int)M, K, N, geo, dbg, stats, (const unsigned short*)res_gate)
+#define LG(BNV, T)                                                                      \
+    if constexpr (PL == 1 && !OUTF32) {                                                 \
+        if (gate == 1) L(BNV, T, true, false, 1); else L(BNV, T, true, false, 2);       \
+    }
+#define LS(BNV, T)                                                                      \
+    if constexpr (PL == 1 && !OUTF32) {                                                 \
+        hipLaunchKernelGGL((hiast::igemm_bn_act_kernel<PL, OUTF32, BNV, T, false, false, MF, 0, true>), grid, dim3(512), 0, st, \
+                           (const unsigned short*)x, (const unsigned short*)wp, gamma, beta, mean, var, eps,                     \
+                           (const unsigned short*)res, y, (int)M, K, N, geo, dbg, stats, (const unsigned short*)res_gate);       \
+    }
+#define LL(BNV, T)                                                                      \
+    if (res) {                                                                          \
+        if (relu) L(BNV, T, true, true, 0);                                             \
+        else if (gate == 0) L(BNV, T, true, false, 0);                                  \
+        else { LG(BNV, T) }                                                             \
+    } else if (relu) L(BNV, T, false, true, 0);                                         \
+    else if (!stats) L(BNV, T, false, false, 0);                                        \
+    else { LS(BNV, T) }
 #define LLL                                                                                                 \
     if (taps == 1) { if (BN == 256) { LL(256, 1) } else if (BN == 128) { LL(128, 1) } else { LL(64, 1) } }  \
     else { if (BN == 256) { LL(256, 9) } else if (BN == 128) { LL(128, 9) } else { LL(64, 9) } }
@@ -614,6 +634,8 @@ static int launch_igemm_t(const void* x, const void* wp, const float* gamma, con
     }
 #undef LLL
 #undef LL
+#undef LS
+#undef LG
 #undef L
     HIAST_CHECK_LAUNCH();
     return 0;
@@ -625,8 +647,8 @@ int hiast_igemm_launch(const void* x, const void* wp, const float* gamma, const 
                        int taps, int H, int W, int stride, int dil, int planes, int out_f32, hipStream_t st,
                        float* stats, const void* res_gate, int gate_mask)
 {
-    if (stats && (planes != 1 || out_f32)) return HIAST_E_RANGE;
-    if (res_gate && (planes != 1 || !res || (!gate_mask && (((uintptr_t)res_gate) & 15)))) return HIAST_E_RANGE;
+    if (stats && (planes != 1 || out_f32 || res || relu)) return HIAST_E_RANGE;
+    if (res_gate && (planes != 1 || !res || relu || out_f32 || (!gate_mask && (((uintptr_t)res_gate) & 15)))) return HIAST_E_RANGE;
     if (!x || !wp || !y || (mean && !var)) return HIAST_E_ARG;
     if (M <= 0 || K <= 0 || N <= 0) return HIAST_E_ARG;
     if ((planes != 1 && planes != 2) || (taps != 1 && taps != 9)) return HIAST_E_RANGE;

@@ -224,10 +224,10 @@ int hiast_bn_act_nhwc_infer(const void* x, void* y, const float* gamma, const fl
  * taps = 9: padding = dilation, stride 1 | 2.  out_f32 = 1: y is fp32 [B,Ho,Wo,Cout] (no residual).  mean == NULL: no
  * BatchNorm (plain GEMM).  Cin % 32 == 0, Cout % 64 == 0, every tensor < 2 GiB, 16-byte aligned.
  * hiast_split_planes: fp32 [M][C] <-> planes [M][2][C] (inverse = 1: x is written; hi + lo is exact in fp32).
- * stats (planes = 1, 16-bit output only; may be NULL): [ceil(B*Ho*Wo/256)][Cout][2] fp32, per 256-row block the sums
+ * stats (planes = 1, 16-bit output, no res, relu = 0; may be NULL): [ceil(B*Ho*Wo/256)][Cout][2] fp32, per 256-row block the sums
  * Σy and Σy² of the stored (bf16) outputs — the BatchNorm batch statistics of the training forward come out of the
  * convolution's epilogue (hiast_bn_nhwc_stats_from_partial reduces them) instead of another pass over y.
- * res_gate (planes = 1, with res; may be NULL): like res; the residual is then added only where res_gate > 0 — the data
+ * res_gate (planes = 1, 16-bit output, with res and relu = 0; may be NULL): like res; the residual is then added only where res_gate > 0 — the data
  * gradient of a bottleneck's first convolution takes the ReLU-masked gradient of the identity branch (dy of the block
  * output, gated by the block output) in its epilogue instead of a masked copy + a separate add.  gate_mask = 1:
  * res_gate is the [M][Cout/8] bit mask written by hiast_bn_nhwc_apply instead of a tensor of values. */
