@@ -193,6 +193,30 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
 #pragma unroll
         for (int b = 0; b < (M16 ? 4 : 1); ++b) acc4[a][b] = (ig_f32x4){0.f, 0.f, 0.f, 0.f};
 
+    const int erow = lane >> 3, ec8 = lane & 7;             // epilogue: lane -> (row of an 8-row group, 8-channel group)
+    const int nc = n0 + wn * 64 + ec8 * 8;
+    // residual rows: with one 8-wave block per CU only this wave's own loads hide the HBM latency of the epilogue, so
+    // the rows of chunk a + RD are requested while chunk a goes through its LDS round trip (RD chunks = RD x 4 x 16-byte
+    // loads per lane in flight; 2 for one plane, 1 for split planes where hi and lo double the registers)
+    constexpr int RD = PL == 2 ? 1 : 2;
+    uint4 rhA[TM][4], rlA[TM][4];
+    auto load_res = [&](int a) {
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int m = m0 + wm * (TM * 32) + a * 32 + ps * 8 + erow;
+            const size_t g = ig_elem<PL>((size_t)(m < M ? m : 0), nc, N);
+            rhA[a][ps] = *reinterpret_cast<const uint4*>(R + g);
+            if (PL == 2) rlA[a][ps] = *reinterpret_cast<const uint4*>(R + g + 32);
+            if (GATE == 2)                                                  // gate rows ride in rlA
+                rlA[a][ps].x = reinterpret_cast<const unsigned char*>(Rg)[(size_t)(m < M ? m : 0) * (N >> 3) + (nc >> 3)];
+            else if (GATE == 1)
+                rlA[a][ps] = *reinterpret_cast<const uint4*>(Rg + g);
+        }
+    };
+    // The first RD chunks are requested during the LAST k-step of the main loop: the block's epilogue no longer starts
+    // with an exposed HBM round trip (four such rounds per CU on the 256->1024 shapes).  One plane only: with split
+    // planes (and with a value gate) the 32 extra live registers spill inside the main loop.
+    constexpr bool HOIST = RES && PL == 1 && GATE != 1;
 #pragma unroll
     for (int p = 0; p < NPIECE; ++p) piece(0, 0, p);
     if ((dbg & 8) && wave >= 4) __builtin_amdgcn_s_setprio(1);
@@ -204,6 +228,10 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's share of tile kt has landed
         __syncthreads();                                          // everyone's has; everyone left buffer buf^1
         const bool more = kt + 1 < nk && !(dbg & 2);     // dbg: tuning experiments only (HIAST_IGEMM_DEBUG)
+        if (HOIST && kt == nk - 1) {
+#pragma unroll
+            for (int a = 0; a < (RD < TM ? RD : TM); ++a) load_res(a);
+        }
         const unsigned char* ta = smem + buf * BUF_BYTES;
         const unsigned char* tb = ta + A_BYTES;
         if (!M16) {
@@ -304,30 +332,10 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
             sh[b] = fmaf(-mean[n], sc[b], beta ? beta[n] : 0.0f);
         }
     }
-    const int erow = lane >> 3, ec8 = lane & 7;
-    const int nc = n0 + wn * 64 + ec8 * 8;
     float st1[8], st2[8];                               // BatchNorm statistics of this lane's 8 channels (if asked for)
 #pragma unroll
     for (int q = 0; q < 8; ++q) { st1[q] = 0.f; st2[q] = 0.f; }
-    // residual rows: with one 8-wave block per CU only this wave's own loads hide the HBM latency of the epilogue, so
-    // the rows of chunk a + RD are requested while chunk a goes through its LDS round trip (RD chunks = RD x 4 x 16-byte
-    // loads per lane in flight; 2 for one plane, 1 for split planes where hi and lo double the registers)
-    constexpr int RD = PL == 2 ? 1 : 2;
-    uint4 rhA[TM][4], rlA[TM][4];
-    auto load_res = [&](int a) {
-#pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
-            const int m = m0 + wm * (TM * 32) + a * 32 + ps * 8 + erow;
-            const size_t g = ig_elem<PL>((size_t)(m < M ? m : 0), nc, N);
-            rhA[a][ps] = *reinterpret_cast<const uint4*>(R + g);
-            if (PL == 2) rlA[a][ps] = *reinterpret_cast<const uint4*>(R + g + 32);
-            if (GATE == 2)                                                  // gate rows ride in rlA
-                rlA[a][ps].x = reinterpret_cast<const unsigned char*>(Rg)[(size_t)(m < M ? m : 0) * (N >> 3) + (nc >> 3)];
-            else if (GATE == 1)
-                rlA[a][ps] = *reinterpret_cast<const uint4*>(Rg + g);
-        }
-    };
-    if (RES) {
+    if (RES && !HOIST) {
 #pragma unroll
         for (int a = 0; a < (RD < TM ? RD : TM); ++a) load_res(a);
     }
