@@ -200,12 +200,15 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
     // loads per lane in flight; 2 for one plane, 1 for split planes where hi and lo double the registers)
     constexpr int RD = PL == 2 ? 1 : 2;
     uint4 rhA[TM][4], rlA[TM][4];
-    auto load_res = [&](int a) {
+    // part: 0 = everything, 1 = the hi plane only, 2 = the rest (split planes: hi and lo of a 32-channel slab share one
+    // 128-byte line, so an early request for hi also brings lo to the L2)
+    auto load_res = [&](int a, int part = 0) {
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
             const int m = m0 + wm * (TM * 32) + a * 32 + ps * 8 + erow;
             const size_t g = ig_elem<PL>((size_t)(m < M ? m : 0), nc, N);
-            rhA[a][ps] = *reinterpret_cast<const uint4*>(R + g);
+            if (part != 2) rhA[a][ps] = *reinterpret_cast<const uint4*>(R + g);
+            if (part == 1) continue;
             if (PL == 2) rlA[a][ps] = *reinterpret_cast<const uint4*>(R + g + 32);
             if (GATE == 2)                                                  // gate rows ride in rlA
                 rlA[a][ps].x = reinterpret_cast<const unsigned char*>(Rg)[(size_t)(m < M ? m : 0) * (N >> 3) + (nc >> 3)];
@@ -217,6 +220,8 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
     // with an exposed HBM round trip (four such rounds per CU on the 256->1024 shapes).  One plane only: with split
     // planes (and with a value gate) the 32 extra live registers spill inside the main loop.
     constexpr bool HOIST = RES && PL == 1 && GATE != 1;
+    constexpr bool HOIST_HI = RES && PL == 2 && TAPS == 1;   // split planes: the hi rows of the first chunk only (16 registers;
+                                                            // the 3x3 variants have none to spare)
 #pragma unroll
     for (int p = 0; p < NPIECE; ++p) piece(0, 0, p);
     if ((dbg & 8) && wave >= 4) __builtin_amdgcn_s_setprio(1);
@@ -232,6 +237,7 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
 #pragma unroll
             for (int a = 0; a < (RD < TM ? RD : TM); ++a) load_res(a);
         }
+        if (HOIST_HI && kt == nk - 1) load_res(0, 1);
         const unsigned char* ta = smem + buf * BUF_BYTES;
         const unsigned char* tb = ta + A_BYTES;
         if (!M16) {
@@ -337,7 +343,7 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
     for (int q = 0; q < 8; ++q) { st1[q] = 0.f; st2[q] = 0.f; }
     if (RES && !HOIST) {
 #pragma unroll
-        for (int a = 0; a < (RD < TM ? RD : TM); ++a) load_res(a);
+        for (int a = 0; a < (RD < TM ? RD : TM); ++a) load_res(a, (HOIST_HI && a == 0) ? 2 : 0);
     }
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
