@@ -38,8 +38,8 @@ PEAK_FP32_MFMA = 157.3                                                # TFLOP/s,
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=6)
-    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--steps", type=int, default=12)
+    p.add_argument("--warmup", type=int, default=4)
     p.add_argument("--batch", type=int, default=8, help="images per GPU per step")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-size", type=int, nargs=2, default=[H, W],
