@@ -591,6 +591,23 @@ def test_wgrad_side_stream_gives_identical_gradients(K):
     assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])   # own kernel: deterministic
 
 
+def test_h2d_async_uploads_through_pinned_staging(K):
+    """kernels.h2d_async: values arrive, dtype/shape kept, an existing device table is refilled in place, and the
+    host array may be overwritten right after the call (the bytes were staged)"""
+    a = np.arange(19, dtype=np.float32) * 0.5
+    t = K.h2d_async(a, torch.device("cuda"))
+    a[:] = -1.0
+    assert t.dtype == torch.float32 and tuple(t.shape) == (19,)
+    assert torch.equal(t.cpu(), torch.arange(19, dtype=torch.float32) * 0.5)
+    table = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    ptr = table.data_ptr()
+    rec = np.arange(8, dtype=np.int64)
+    out = K.h2d_async(rec.view(np.uint8).reshape(-1), table.device, out=table)
+    rec[:] = 0
+    assert out.data_ptr() == ptr
+    assert np.array_equal(table.cpu().numpy().view(np.int64), np.arange(8, dtype=np.int64))
+
+
 @pytest.mark.parametrize("cfg", [(2, 256, 256, 64, 128, 3, 2), (1, 512, 512, 64, 128, 3, 4), (2, 1024, 256, 64, 128, 1, 1),
                                  (1, 256, 1024, 61, 77, 1, 1), (1, 256, 256, 50, 70, 3, 1)])
 def test_conv_wgrad_many_pixel_ranges(K, cfg):

@@ -292,3 +292,31 @@ def test_validator_cpu_config1(tmp_path):
         union += u
     want, _, _ = metrics_ref.miou(inter, union)
     assert abs(miou - want) <= 0.05 / 100 + 1e-12
+
+
+def test_bench_roofline_entries_name_the_binding_roof():
+    """bench.py's roofline bookkeeping (pure host arithmetic): the 3x3 split-plane launch is priced against the dense
+    bf16 MFMA peak / 3, the 256->1024 1x1 (+residual) launch against the 8 TB/s HBM roof; achieved = algorithmic work of
+    one launch / its average duration"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(__file__), "..", "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    # ("igemm", x [B,H,W,PL*Cin], wp [Cout,taps,PL*Cin], PL, stride, dil, has_res, out_f32, has_bn, relu)
+    k3 = ("igemm", (8, 64, 128, 512), (256, 9, 512), 2, 1, 2, False, False, True, True)
+    r = bench.roofline_of(k3, 0.18, 22, 1)
+    flop = 2.0 * 8 * 64 * 128 * 9 * 256 * 256
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["peak"] - 2500.0 / 3) < 1e-9
+    assert abs(r["achieved"] - flop / 0.18e-3 / 1e12) < 1e-6 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["launches_per_step"] == 22
+    k1 = ("igemm", (8, 64, 128, 512), (1024, 1, 512), 2, 1, 1, True, False, True, True)
+    r = bench.roofline_of(k1, 0.17, 23, 1)
+    M = 8 * 64 * 128
+    alg = (M * 512 + 1024 * 512) * 2 + M * 1024 * 4 * 2            # input + weights + (residual + output) hi|lo pairs
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["achieved"] - alg / 0.17e-3 / 1e9) < 1e-3 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12
+    # the pure host path of the step split: the serial switch exists and the JSON contract fields are spelled as the driver reads them
+    src = open(os.path.join(os.path.dirname(__file__), "..", "bench.py")).read()
+    for field in ('"metric"', '"value"', '"unit"', '"n_gpus"', '"steps"', '"warmup"', '"ms_per_step"', '"higher_is_better"',
+                  '"scaling"', '"vs_baseline"', '"dtype"', '"data"', '"config"', '"roofline"', '"cpu_baseline"'):
+        assert field in src, field
