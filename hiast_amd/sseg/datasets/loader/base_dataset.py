@@ -83,6 +83,19 @@ class BaseDataset(Dataset):
             out["copy_paste_mask"] = m if getattr(self, "device_transform", False) else m.long()
         return out
 
+    def _decoded_cache(self):
+        """cfg.dataset.decoded_cache_dir (optional): decoded uint8 arrays are kept as raw files and re-read instead of
+        decoding the PNG again (decoded_cache.py); created lazily, i.e. inside each DataLoader worker"""
+        c = self.__dict__.get("_dcache", False)
+        if c is False:
+            d = getattr(self.cfg.dataset, "decoded_cache_dir", None)
+            c = None
+            if d:
+                from hiast_amd.sseg.datasets.decoded_cache import DecodedCache
+                c = DecodedCache(d, getattr(self.cfg.dataset, "decoded_cache_gb", 16.0))
+            self.__dict__["_dcache"] = c
+        return c
+
     def set_preprocessor(self, preprocessor):
         self.preprocessor = preprocessor
         print("%% use {}".format(type(preprocessor).__name__))
@@ -97,10 +110,17 @@ class BaseDataset(Dataset):
         """-> (uint8 HxWx3 image, uint8 HxW label, image path); with `pseudo_dir`, the label is the
         generator's <stem>_pseudo_label.png (base_dataset.py:158-178)"""
         img_path = self.img_path_list[index]
-        img = np.array(Image.open(img_path).convert("RGB"), dtype=np.uint8)
+        cache = self._decoded_cache()
+        dec_img = lambda p: np.array(Image.open(p).convert("RGB"), dtype=np.uint8)      # noqa: E731
+        dec_lbl = lambda p: np.array(Image.open(p), dtype=np.uint8)                     # noqa: E731
+        img = cache.load(img_path, dec_img) if cache else dec_img(img_path)
         if self.pseudo_dir is not None:
             stem = os.path.splitext(os.path.basename(img_path))[0]
-            lbl = np.array(Image.open(os.path.join(self.pseudo_dir, stem + "_pseudo_label.png")), dtype=np.uint8)
+            lp = os.path.join(self.pseudo_dir, stem + "_pseudo_label.png")
+            lbl = cache.load(lp, dec_lbl) if cache else dec_lbl(lp)
+        elif cache and self.lbl_path_list[index] is not None and os.path.exists(self.lbl_path_list[index]):
+            lbl = cache.load(self.lbl_path_list[index], self.read_label,     # (the id-mapped label, as read_label returns it)
+                             salt="%s/%d" % (type(self).__name__, self.num_classes))
         else:
             lbl = self.read_label(self.lbl_path_list[index])
         if lbl is None:

@@ -129,6 +129,8 @@ model:
 dataset:
   num_classes: 19
   num_workers: 2
+  decoded_cache_dir: null         # (not in the reference) directory for decoded uint8 arrays, e.g. /dev/shm/hiast_cache
+  decoded_cache_gb: 16.0
   source: {type: null, json_path: null, image_dir: null, aug_type: []}
   target: {type: null, json_path: null, image_dir: null, pseudo_dir: null, aug_type: []}
   val: {type: null, json_path: null, image_dir: null, resize_size: null}

@@ -320,3 +320,39 @@ def test_bench_roofline_entries_name_the_binding_roof():
     for field in ('"metric"', '"value"', '"unit"', '"n_gpus"', '"steps"', '"warmup"', '"ms_per_step"', '"higher_is_better"',
                   '"scaling"', '"vs_baseline"', '"dtype"', '"data"', '"config"', '"roofline"', '"cpu_baseline"'):
         assert field in src, field
+
+
+def test_decoded_cache_returns_the_decoded_bytes(tmp_path):
+    """cfg.dataset.decoded_cache_dir: load_data gives the same arrays with and without the cache and on the second
+    (cached) read; entries are private writable copies, follow the source file (a rewritten file is a new entry),
+    different label id maps do not collide, and the size bound is respected"""
+    from PIL import Image
+    from hiast_amd.sseg.datasets.decoded_cache import DecodedCache
+    c = synth_data.synthetic_cfg(str(tmp_path / "data"), n_train=3, n_val=2, h=32, w=64)
+    plain = DATASET["Cityscapes"](c, c.dataset.target.json_path, c.dataset.target.image_dir)
+    want = [plain.load_data(i) for i in range(3)]
+    c.dataset.decoded_cache_dir = str(tmp_path / "cache")
+    ds = DATASET["Cityscapes"](c, c.dataset.target.json_path, c.dataset.target.image_dir)
+    for rnd in range(2):                                    # first round decodes and stores, second reads the cache
+        for i in range(3):
+            img, lbl, path = ds.load_data(i)
+            assert np.array_equal(img, want[i][0]) and np.array_equal(lbl, want[i][1]) and path == want[i][2]
+            assert img.flags.writeable and lbl.flags.writeable and img.dtype == np.uint8
+            img[:] = 0                                      # a private copy: the stored entry is not touched
+        assert len([f for f in os.listdir(c.dataset.decoded_cache_dir) if f.endswith(".npy")]) == 6
+    nine = DATASET["Cityscapes"](c, c.dataset.target.json_path, c.dataset.target.image_dir, num_classes=9)
+    c9 = get_default_cfg()
+    assert np.array_equal(nine.load_data(0)[1], nine.read_label(nine.lbl_path_list[0]))     # 9-class map: own entry
+    assert not np.array_equal(nine.load_data(0)[1], want[0][1])
+    # a rewritten source file is a new entry
+    p = ds.img_path_list[0]
+    new = np.full((32, 64, 3), 7, dtype=np.uint8)
+    st = os.stat(p)
+    Image.fromarray(new).save(p)
+    os.utime(p, ns=(st.st_atime_ns, st.st_mtime_ns + 10 ** 9))
+    assert np.array_equal(ds.load_data(0)[0], new)
+    # size bound: nothing is written beyond it
+    small = DecodedCache(str(tmp_path / "small"), max_gb=1e-6)
+    assert small.load(p, lambda q: np.array(Image.open(q).convert("RGB"), dtype=np.uint8)).shape == (32, 64, 3)
+    assert os.listdir(str(tmp_path / "small")) == []
+    assert c9.dataset.decoded_cache_dir is None             # off unless asked for (the reference has no such feature)

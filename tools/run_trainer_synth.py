@@ -69,26 +69,54 @@ try:
     cfg.cst_training.cst_loss.weight = 0.5
     cfg.preprocessor.type = "CopyPaste"
     cfg.work_dir = os.path.join(root, "work")
-    tr = TRAINER[cfg.trainer](cfg, 0)
-    warm = 6
-    for it in range(1, warm + 1):
-        tr.step(it)
-    torch.cuda.synchronize()
-    t0 = time.time()
-    t_data = 0.0
-    for it in range(warm + 1, warm + iters + 1):
-        tr.step(it)
-    torch.cuda.synchronize()
-    dt = (time.time() - t0) / iters
-    print("ConsistencySelfTrainingTrainer end to end (DataLoader, %d workers, CopyPaste + MS + CCA, bs %d): "
-          "%.1f ms/iter = %.1f images/s" % (nw, bs, dt * 1e3, bs / dt), flush=True)
-    # host data path alone: how fast can the workers deliver batches?
-    t0 = time.time()
-    k = 0
-    for _ in range(iters):
-        tr.next_target_batch()
-        k += 1
-    dl = (time.time() - t0) / k
-    print("DataLoader alone: %.1f ms/batch = %.1f images/s with %d workers" % (dl * 1e3, bs / dl, nw), flush=True)
+    def measure(tag, warm=6):
+        tr = TRAINER[cfg.trainer](cfg, 0)
+        wait = [0.0]
+        fetch = tr.next_target_batch
+
+        def timed_fetch():                      # time the main process spends waiting for / receiving a batch
+            a = time.time()
+            b = fetch()
+            wait[0] += time.time() - a
+            return b
+        tr.next_target_batch = timed_fetch
+        for it in range(1, warm + 1):
+            tr.step(it)
+        torch.cuda.synchronize()
+        wait[0] = 0.0
+        t0 = time.time()
+        for it in range(warm + 1, warm + iters + 1):
+            tr.step(it)
+        t_host = (time.time() - t0) / iters     # host time per iteration (enqueue + data), before the final drain
+        torch.cuda.synchronize()
+        dt = (time.time() - t0) / iters
+        print("  host loop %.1f ms/iter of which %.1f ms in next_target_batch()" % (t_host * 1e3, wait[0] / iters * 1e3),
+              flush=True)
+        del tr.next_target_batch                # (the instance attribute; the class method is back)
+        print("ConsistencySelfTrainingTrainer end to end, %s (DataLoader, %d workers, CopyPaste + MS + CCA, bs %d): "
+              "%.1f ms/iter = %.1f images/s" % (tag, nw, bs, dt * 1e3, bs / dt), flush=True)
+        # host data path alone: how fast can the workers deliver batches?
+        t0 = time.time()
+        for _ in range(iters):
+            tr.next_target_batch()
+        dl = (time.time() - t0) / iters
+        print("DataLoader alone, %s: %.1f ms/batch = %.1f images/s with %d workers" % (tag, dl * 1e3, bs / dl, nw), flush=True)
+        tr.t_iter = tr.t_loader = None          # stop this trainer's worker processes before the next measurement
+        del tr
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+
+    measure("PNG decode per sample (reference behaviour)")
+    # decoded-image cache (cfg.dataset.decoded_cache_dir): every image / pseudo-label is decoded once, then re-read as raw bytes
+    dcache = tempfile.mkdtemp(prefix="hiast_dcache_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    cfg.dataset.decoded_cache_dir = dcache
+    cfg.dataset.decoded_cache_gb = 8.0
+    try:
+        measure("decoded-image cache (the warm-up iterations fill it)", warm=max(6, 2 * N // bs))
+        used = sum(os.path.getsize(os.path.join(dcache, f)) for f in os.listdir(dcache))
+        print("decoded cache: %d files, %.0f MB" % (len(os.listdir(dcache)), used / 1e6), flush=True)
+    finally:
+        shutil.rmtree(dcache, ignore_errors=True)
 finally:
     shutil.rmtree(root, ignore_errors=True)
