@@ -248,7 +248,8 @@ class HotPath:
         """eval forward (fp32-class) + pass 1 + asynchronous read-back of the histogram"""
         from hiast_amd import kernels as K
         net = self.ema if self.teacher else self.model.module     # train.sh generates with the EMA model
-        net.eval()
+        from hiast_amd.utils import utils
+        utils.set_mode(net, False)
         with torch.no_grad():
             logits = net(self.weak, lowres=True)["logits_lowres"]     # fp32, like the reference generator
             mp, am, hist = K.plabel_pass1(logits.contiguous(), H, W)
@@ -281,13 +282,14 @@ class HotPath:
 
     def train_forward(self):
         """EMA-teacher forward (no grad) and student forward of the training step -> (student out, teacher logits)"""
-        self.model.train()
+        from hiast_amd.utils import utils
+        utils.set_mode(self.model, True)
         teacher_lr = None
         main = torch.cuda.current_stream()
         if self.teacher:
             # EMA-teacher forward on a side stream: its MFMA-bound convolutions co-run with the HBM-bound BatchNorm
             # passes of the student forward (ConsistencySelfTrainingTrainer.train_on does the same)
-            self.ema.eval()
+            utils.set_mode(self.ema, False)
             side = self.side if (self.use_side and os.environ.get("HIAST_NO_SIDE_STREAM", "0") != "1") else main
             side.wait_stream(main)
             with torch.cuda.stream(side), torch.no_grad(), torch.autocast("cuda", dtype=self.amp,

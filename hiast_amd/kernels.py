@@ -13,7 +13,9 @@ from ._lib import NBINS, check
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # raw handle of torch's current stream on the current device; torch.cuda.current_stream().cuda_stream builds two
+    # Python objects per call (8.6 us measured, 436 calls per training step)
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def _ptr(t):

@@ -89,6 +89,14 @@ def init_model(cfg, resume_from=None, student_model=None):
     return model
 
 
+def set_mode(module, training):
+    """module.train(training) unless the module is already in that mode: train() / eval() walk every sub-module
+    (~900 per network: 1.7 ms per call), and the trainers call them once per iteration"""
+    if module.training != bool(training):
+        module.train(bool(training))
+    return module
+
+
 class EmaUpdater:
     """update_ema_model (utils.py:115-123): parameters ema = ema*g + p*(1-g) in one HIP launch,
     buffers copied (one foreach copy)."""

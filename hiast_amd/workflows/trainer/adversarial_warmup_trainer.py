@@ -8,6 +8,7 @@ RCCL — the reference's apex DDP likewise delays its all-reduce to the end of b
 import torch
 
 from hiast_amd.sseg.datasets import utils as du
+from hiast_amd.utils import utils
 from hiast_amd.utils.registry.registries import TRAINER
 from hiast_amd.workflows.trainer.base_trainer import BaseTrainer, _Bare
 
@@ -25,7 +26,7 @@ class AdversarialWarmupTrainer(BaseTrainer):
         return _Bare(model)
 
     def train_on(self, s_img, s_lbl, t_img):
-        self.model.train()
+        utils.set_mode(self.model, True)
         with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
             return self.model(s_img, t_img, s_lbl)
 

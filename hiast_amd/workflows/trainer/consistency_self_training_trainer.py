@@ -58,7 +58,7 @@ class ConsistencySelfTrainingTrainer(BaseTrainer):
     def train_on(self, t_weak_img, t_strong_img, t_plbl):
         if self.cfg.cst_training.cst_loss.type != "SoftCE":
             raise NotImplementedError("cst_loss.type %r" % self.cfg.cst_training.cst_loss.type)
-        self.ema_model.eval()
+        utils.set_mode(self.ema_model, False)
         # teacher forward on a side stream: its MFMA-bound convolutions co-run with the HBM-bound BatchNorm passes of
         # the student forward; the loss waits for both
         main = torch.cuda.current_stream()
@@ -69,7 +69,7 @@ class ConsistencySelfTrainingTrainer(BaseTrainer):
         with torch.cuda.stream(side), torch.no_grad(), torch.autocast("cuda", dtype=self.amp_dtype,
                                                                       enabled=self.amp_dtype is not None):
             teacher_lr = self.ema_model(t_weak_img, lowres=True)["logits_lowres"].float()
-        self.model.train()
+        utils.set_mode(self.model, True)
         with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
             out = self.model(t_strong_img, lowres=True)
         main.wait_stream(side)

@@ -4,6 +4,7 @@ low-res logits and the fused loss kernel does the rest."""
 import torch
 
 from hiast_amd.sseg.datasets import utils as du
+from hiast_amd.utils import utils
 from hiast_amd.utils.registry.registries import TRAINER
 from hiast_amd.workflows.trainer.base_trainer import BaseTrainer
 
@@ -17,7 +18,7 @@ class SelfTrainingTrainer(BaseTrainer):
         assert self.cfg.train.resume_from is not None, "self-training should resume_from one state_dict"
 
     def train_on(self, t_img, t_plbl):
-        self.model.train()
+        utils.set_mode(self.model, True)
         with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
             out = self.model(t_img, lowres=True)
         return self.model.module.compute_loss_lowres(out["logits_lowres"], t_plbl, out["size"])

@@ -4,6 +4,7 @@ import torch
 
 from hiast_amd import functional as HF
 from hiast_amd.sseg.datasets import utils as du
+from hiast_amd.utils import utils
 from hiast_amd.utils.registry.registries import TRAINER
 from hiast_amd.workflows.trainer.base_trainer import BaseTrainer
 
@@ -12,7 +13,7 @@ from hiast_amd.workflows.trainer.base_trainer import BaseTrainer
 class SourceOnlyTrainer(BaseTrainer):
 
     def train_on(self, s_img, s_lbl):
-        self.model.train()
+        utils.set_mode(self.model, True)
         with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
             out = self.model(s_img, lowres=True)
         w = self.cfg.model.predictor.seg_loss.source_weight
