@@ -480,6 +480,42 @@ def test_igemm_bf16(K, case):
     assert (np.abs(y - want) <= 2.0 ** -8 * np.abs(want) + 3e-5 * np.abs(want).max()).all()
 
 
+@pytest.mark.parametrize("case", [(2, 13, 21, 256, 1024, 1, 1), (1, 16, 16, 64, 128, 1, 1), (2, 12, 20, 128, 256, 9, 2),
+                                  (1, 9, 11, 512, 64, 1, 1)])
+@pytest.mark.parametrize("mask", [False, True])
+def test_igemm_gated_residual(K, case, mask):
+    """data-gradient flavour of the igemm kernel (plain bf16 GEMM, no BN, no ReLU) with the gated residual of the
+    identity hand-off: y = conv(x) + res * (gate > 0), the gate given as values (GATE = 1) or as the [M][Cout/8] bit
+    mask the BN forward writes (GATE = 2); 256-row tiles with tail rows, every column-tile width; and the argument
+    checks that keep the compile-time variants honest (no gate with ReLU / statistics with a residual)"""
+    B, H, W, Cin, Cout, taps, dil = case
+    kk = 3 if taps == 9 else 1
+    x = _bf16r(synth.normal_f32(330, (B, H, W, Cin)))
+    w = synth.normal_f32(331, (Cout, Cin, kk, kk), (2.0 / (Cin * taps)) ** 0.5)
+    res = _bf16r(synth.normal_f32(332, (B, H, W, Cout)))
+    gate = _bf16r(synth.normal_f32(333, (B, H, W, Cout)))
+    gate[0, 0, :3, :] = 0.0                                     # exact zeros are closed
+    xp, resp = dev(x).bfloat16(), dev(res).bfloat16()
+    wp = K.pack_conv_weight(dev(w), 1)
+    if mask:
+        bits = np.packbits((gate > 0).reshape(B * H * W, Cout // 8, 8), axis=-1, bitorder="little").reshape(B * H * W, Cout // 8)
+        g = dev(bits)
+        assert g.dtype == torch.uint8
+    else:
+        g = dev(gate).bfloat16()
+    y = K.igemm_bn_act(xp, wp, 1, None, resp, False, 1, dil, res_gate=g).float().cpu().numpy()
+    want = _igemm_ref(x, _bf16r(w), None, res * (gate > 0), False, 1, dil, taps)
+    assert (np.abs(y - want) <= 2.0 ** -8 * np.abs(want) + 3e-5 * np.abs(want).max()).all()
+    plain = K.igemm_bn_act(xp, wp, 1, None, resp, False, 1, dil).float().cpu().numpy()        # GATE = 0: everything added
+    want0 = _igemm_ref(x, _bf16r(w), None, res, False, 1, dil, taps)
+    assert (np.abs(plain - want0) <= 2.0 ** -8 * np.abs(want0) + 3e-5 * np.abs(want0).max()).all()
+    from hiast_amd._lib import HiastLibraryError
+    with pytest.raises(HiastLibraryError):
+        K.igemm_bn_act(xp, wp, 1, None, resp, True, 1, dil, res_gate=g)          # gate + ReLU: not a variant
+    with pytest.raises(HiastLibraryError):
+        K.igemm_bn_act(xp, wp, 1, None, resp, False, 1, dil, want_stats=True)    # statistics + residual: not a variant
+
+
 @pytest.mark.parametrize("shape", [(2, 64, 9, 17), (3, 256, 16, 24), (1, 2048, 8, 12), (2, 1024, 5, 7)])
 @pytest.mark.parametrize("res,relu", [(False, True), (True, True), (False, False)])
 def test_bn_nhwc_matches_fp64(K, shape, res, relu):
