@@ -1,6 +1,7 @@
 """bench.py — HIAST self-training hot path on N MI355X of one node.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: under torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+(N>1: either under torch.distributed.run, or bare — it then starts its own N ranks before touching a GPU)
 
 One STEP = one pass of the hot path over one batch of B synthetic 1024x512 (W x H) images per GPU,
 resident in HBM before the timed region:
@@ -392,12 +393,31 @@ def cpu_baseline(cfg, size, threads):
                       % (w, h, scale, t_gen, t_train, cores)}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (the reference's train.py does the
+    same with mp.spawn, code/train.py:52-59,82) as ONE torch.distributed.run child — before this process has made any
+    GPU call — pass its stdout (rank 0's JSON line) through, and exit with its return code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world)
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
     import __graft_entry__ as ge
     if rank == 0 and not os.path.exists(os.path.join(ROOT, "hiast_amd", "csrc", "libhiast_hip.so")):
         ge.build()

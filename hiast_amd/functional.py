@@ -411,8 +411,8 @@ def conv_nhwc_ok(x, conv):
     k = conv.kernel_size
     if k not in ((1, 1), (3, 3)) or conv.stride[0] != conv.stride[1] or conv.in_channels % 64 or conv.out_channels % 64:
         return False
-    if k == (1, 1):
-        return conv.stride == (1, 1) and conv.padding == (0, 0)
+    if k == (1, 1):      # a strided 1x1 (the stage-entry downsample) = the stride-1 kernel on the subsampled input
+        return conv.stride[0] in (1, 2) and conv.padding == (0, 0)
     return conv.padding == conv.dilation and conv.dilation[0] == conv.dilation[1] and conv.stride[0] in (1, 2)
 
 
@@ -423,7 +423,14 @@ def conv_nhwc(x, conv, want_stats=False, box=None):
     adj = conv.__dict__.get("_hiast_packed_adj")
     ok = lambda e: e is not None and e[0] == w._version and e[1] == w.data_ptr()
     packed = (fwd[2] if ok(fwd) else None, adj[2] if ok(adj) else None)
-    return _ConvNhwcFn.apply(x, w, conv.stride[0], conv.dilation[0], bool(want_stats), box, packed)
+    stride = conv.stride[0]
+    if conv.kernel_size == (1, 1) and stride != 1:
+        # strided 1x1: every s-th pixel through the stride-1 kernel (forward, data and weight gradient all stay on the
+        # hand-written path, and dW arrives with the parameter's own strides — the library's channels-last dW made
+        # DDP copy the bucket view); autograd scatters the data gradient back into the skipped pixels
+        x = x[:, :, ::stride, ::stride].contiguous(memory_format=torch.channels_last)
+        stride = 1
+    return _ConvNhwcFn.apply(x, w, stride, conv.dilation[0], bool(want_stats), box, packed)
 
 
 _nbt_batched = [False]      # set by ResNet.forward while it has already advanced every num_batches_tracked at once

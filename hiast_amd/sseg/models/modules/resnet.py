@@ -1,9 +1,11 @@
 """ResNet-101 trunk without avgpool/fc, parameter names identical to the reference
 (sseg/models/modules/resnet.py:58-98,101-190 — torchvision naming: conv1/bn1/layer{1..4}.{i}.
 conv{1,2,3}/bn{1,2,3}/downsample.{0,1}) so released checkpoints load key-for-key.
-Inference forwards (pseudo-label pass in fp32-class split planes, teacher forward in bf16) run every bottleneck
-convolution on the hand-written LDS-DMA implicit-GEMM kernels (hiast_igemm_bn_act); the training forward /
-backward convolutions run on PyTorch-ROCm (MIOpen) around the fused BatchNorm kernels (hiast_bn_*)."""
+Every bottleneck convolution — inference (pseudo-label pass on fp32-class split planes, teacher forward in bf16)
+and the mixed-precision training forward / data gradient / weight gradient — runs on the hand-written LDS-DMA
+implicit-GEMM kernels (hiast_igemm_bn_act, hiast_conv_wgrad_nhwc) between the fused BatchNorm kernels
+(hiast_bn_nhwc_*); PyTorch-ROCm (MIOpen) keeps the 7x7 stem, the 3x3 stride-2 data gradient, the weight gradients
+below 256 channels, and the whole trunk in fp32 (apex_opt O0) training."""
 import os
 
 import torch
@@ -153,7 +155,8 @@ class ResNet(nn.Module):
             convs = [c for c in convs if c.in_channels % 64 == 0 and c.out_channels % 64 == 0 and c.weight.is_cuda]
             if not convs:
                 return
-            plan = K.PackPlan([c.weight for c in convs], PL, [adjoint and c.stride == (1, 1) for c in convs])
+            plan = K.PackPlan([c.weight for c in convs], PL,
+                              [adjoint and (c.stride == (1, 1) or c.kernel_size == (1, 1)) for c in convs])
             ent = (plan, convs)
             plans[(PL, adjoint)] = ent
         plan, convs = ent

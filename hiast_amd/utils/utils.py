@@ -92,8 +92,10 @@ def init_model(cfg, resume_from=None, student_model=None):
 def set_mode(module, training):
     """module.train(training) unless the module is already in that mode: train() / eval() walk every sub-module
     (~900 per network: 1.7 ms per call), and the trainers call them once per iteration"""
-    if module.training != bool(training):
-        module.train(bool(training))
+    training = bool(training)
+    inner = module.module if hasattr(module, "module") else module     # DDP / _Bare wrapper: the net is what counts
+    if module.training != training or inner.training != training:
+        module.train(training)
     return module
 
 
@@ -115,6 +117,9 @@ class EmaUpdater:
         if self._plan is None or not self._plan.still_valid() or len(self._plan.keep[0]) != len(ep):
             self._plan = K.EmaPlan(ep, sp)
         K.ema_update(self._plan, gamma)
+        # the kernel writes through raw pointers: tell autograd (and every cache keyed on Parameter._version — the
+        # packed bf16 / split-plane trunk weights of ResNet.prepack) that the parameters have changed
+        torch.autograd.graph.increment_version(list(ema_model.parameters()))
         eb = [b for b in ema_model.buffers()]
         sb = [b for b in src.buffers()]
         if eb:      # ~300 BatchNorm buffers: one launch instead of one copy kernel per tensor
@@ -173,6 +178,8 @@ class FusedAdam(torch.optim.Optimizer):
                         [st["exp_avg_sq"] for _, _, st in items], [lr for _, lr, _ in items],
                         [1.0 - betas[0] ** k for k in t], [(1.0 - betas[1] ** k) ** 0.5 for k in t], betas[0], betas[1],
                         eps, wd)
+            # raw-pointer writes do not move Parameter._version by themselves; the packed-weight caches key on it
+            torch.autograd.graph.increment_version(ps)
         return loss
 
 

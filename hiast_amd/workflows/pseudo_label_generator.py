@@ -208,10 +208,16 @@ class BasePseudoGenerator:
                 yield data["images"], list(data["image_paths"])
 
     def _exists(self):
-        if self.rank == 0 and len(os.listdir(self.pseudo_label_save_dir)) >= len(self.t_dataset):
+        """rank 0 looks at the directory; every rank takes ITS decision (a rank that went on alone into the
+        collectives of run() would wait for the others forever)"""
+        done = self.rank == 0 and len(os.listdir(self.pseudo_label_save_dir)) >= len(self.t_dataset)
+        if self.world > 1:
+            box = [bool(done)]
+            dist.broadcast_object_list(box, src=0)
+            done = box[0]
+        if done and self.rank == 0:
             print("%% pseudo labels have existed")
-            return True
-        return False
+        return bool(done)
 
     def run(self):
         raise NotImplementedError

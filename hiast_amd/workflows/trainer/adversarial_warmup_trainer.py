@@ -16,6 +16,7 @@ from hiast_amd.workflows.trainer.base_trainer import BaseTrainer, _Bare
 @TRAINER.register("AdversarialWarmupTrainer")
 class AdversarialWarmupTrainer(BaseTrainer):
     manual_allreduce = True
+    wgrad_overlap = False        # seg_model runs twice per step (source, target): two gradients per trunk weight
 
     def assert_cfg(self):
         assert self.cfg.model.discriminator.is_enabled, \

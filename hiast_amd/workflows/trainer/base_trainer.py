@@ -40,6 +40,10 @@ class _Bare(torch.nn.Module):
 
 class BaseTrainer:
     manual_allreduce = False     # True: the trainer all-reduces gradients itself after each backward (no DDP wrapper)
+    # Weight gradients on a side stream are only safe when every weight receives exactly ONE gradient per backward:
+    # with two uses of a weight autograd sums the two tensors on the MAIN stream while the side stream may still be
+    # writing them.  Trainers that run the segmentation net more than once per step switch it off.
+    wgrad_overlap = True
 
     def __init__(self, cfg, gpu_index):
         self.cfg = cfg
@@ -72,14 +76,16 @@ class BaseTrainer:
                                         init_method="tcp://127.0.0.1:{}".format(self.cfg.train.port),
                                         world_size=self.world, rank=self.gpu_index)
         if use_cuda:
-            torch.cuda.set_device(self.gpu_index)
-            self.device = torch.device("cuda", self.gpu_index)
+            # HIAST_SAME_DEVICE=1 (functional tests of the N>1 path on a one-GPU box): every rank uses cuda:0
+            self.device_index = 0 if os.environ.get("HIAST_SAME_DEVICE", "0") == "1" else self.gpu_index
+            torch.cuda.set_device(self.device_index)
+            self.device = torch.device("cuda", self.device_index)
         else:
             raise RuntimeError("training runs on the HIP device; no GPU is visible and there is no CPU fallback")
 
     def _wrap(self, model):
         if self.world > 1:
-            return DDP(model, device_ids=[self.gpu_index], gradient_as_bucket_view=True, bucket_cap_mb=32,
+            return DDP(model, device_ids=[self.device_index], gradient_as_bucket_view=True, bucket_cap_mb=32,
                        broadcast_buffers=False)
         return _Bare(model)
 
@@ -177,7 +183,7 @@ class BaseTrainer:
         there is a 'D_loss', the discriminator step.  bf16 autocast needs no loss scaling."""
         g_loss = sum(torch.mean(v) for k, v in losses.items() if "D_" not in k)
         g_optimizer.zero_grad(set_to_none=True)
-        HF.enable_wgrad_overlap(True)
+        HF.enable_wgrad_overlap(self.wgrad_overlap)
         try:
             g_loss.backward()
         finally:
@@ -212,7 +218,8 @@ class BaseTrainer:
         second one is fused with the argmax (pass-1 kernel) so label-size logits are never stored."""
         from hiast_amd import functional as HF, kernels as K
         net = model.module if hasattr(model, "module") else model
-        net.eval()
+        was_training = net.training
+        model.eval()                 # the WRAPPER, like the reference (base_trainer.py:161): wrapper and net stay in step
         C = self.cfg.dataset.num_classes
         acc = torch.zeros(2, C, dtype=torch.int64, device=self.device)
         for data in self.v_loader:
@@ -226,6 +233,7 @@ class BaseTrainer:
             inter, union = metrics.intersection_union_counts(pred.long(), lbl.long(), C)
             acc[0] += inter
             acc[1] += union
+        model.train(was_training)    # the reference calls model.train() at the top of every iteration
         if self.world > 1:
             dist.all_reduce(acc)       # one 38-element all-reduce instead of two
         acc = acc.cpu().numpy().astype(np.float64)

@@ -47,6 +47,12 @@ def _gen_worker(rank, world, port, root, out):
     if rank == 0:
         np.save(out, gen.class_threshold)
     dist.barrier()
+    # labels exist now: a second run() must return on EVERY rank (rank 0 sees the files, the others take its word) —
+    # a rank that went on alone would block in the histogram all-reduce
+    n_before = len(gen.sample_stats)
+    gen.run()
+    assert len(gen.sample_stats) == n_before
+    dist.barrier()
     dist.destroy_process_group()
 
 

@@ -209,3 +209,27 @@ def test_cli_entry_points(world, monkeypatch):
     _write_yaml(cfg, vy, {"model.type": "SourceOnlySegmentor", "pseudo_policy.save_dir": None})
     miou = val.main(["--config_file", vy, "--resume_from", cfg.validate.resume_from, "--device", "cuda"])
     assert 0.0 <= miou <= 1.0
+
+
+def test_training_resumes_after_validation(world):
+    """iter_val < total_iter: the validation pass switches the WRAPPER to eval() and back (base_trainer.py:161,
+    the reference calls model.train() at the top of every iteration); the iterations after it must run in train mode
+    (batch statistics, losses dict) — they raised NotImplementedError when only the inner module was switched."""
+    from hiast_amd.utils.registry.registries import TRAINER
+    cfg, sd, root = world
+    c = cfg.clone()
+    c.trainer = "SelfTrainingTrainer"
+    c.dataset.target.pseudo_dir = cfg.pseudo_policy.save_dir
+    c.dataset.target.aug_type = ["PRS-%d-%d" % (H, W)]
+    c.train.gpu_num = 1
+    c.train.batch_size = 2
+    c.train.total_iter = 3
+    c.train.iter_report = 1
+    c.train.iter_val = 1
+    c.work_dir = os.path.join(root, "work_st_val")
+    c.freeze()
+    tr = TRAINER[c.trainer](c, 0)
+    tr.run()
+    assert tr.model.training and tr.model.module.training
+    rm = tr.model.module.seg_model.backbone.bn1.num_batches_tracked
+    assert int(rm) == 3, "every iteration must have run BatchNorm in train mode"

@@ -250,3 +250,52 @@ def test_adversarial_warmup_trainer(world, d_loss, entropy_in):
     m2 = utils.load_model(c2, resume_from=os.path.join(c.work_dir, "checkpoints", "model_last.pth"))
     assert torch.equal(m2.state_dict()["seg_model.aspp.conv2d_list.0.weight"],
                        saved["seg_model.aspp.conv2d_list.0.weight"])
+
+
+def test_adversarial_trunk_gradients_do_not_race(world):
+    """seg_model runs twice per adversarial step, so every trunk weight gets two gradients that autograd sums on the
+    main stream: weight gradients must not run on the side stream there (the trainer switches the overlap off).
+    The generator-step gradients equal those of a run with the side stream disabled altogether."""
+    from hiast_amd.utils.registry.registries import TRAINER
+    from hiast_amd import functional as HF
+    cfg, sd, root = world
+    grads = []
+    for tag, env in (("default", None), ("nostream", "1")):
+        c = cfg.clone()
+        c.trainer = "AdversarialWarmupTrainer"
+        c.model.type = "AdversarialWarmupSegmentor"
+        c.model.discriminator.is_enabled = True
+        c.train.total_iter = 1
+        c.train.iter_val = 100
+        c.work_dir = os.path.join(root, "work_adv_race_" + tag)
+        c.freeze()
+        if env is not None:
+            os.environ["HIAST_NO_WGRAD_STREAM"] = env
+        try:
+            tr = TRAINER[c.trainer](c, 0)
+            assert tr.wgrad_overlap is False
+            s_img = torch.from_numpy(synth.normal_f32(61, (2, 3, H, W))).cuda()
+            t_img = torch.from_numpy(synth.normal_f32(62, (2, 3, H, W))).cuda()
+            s_lbl = torch.from_numpy(synth.pseudo_labels(63, 2, H, W, C, 0.1)).cuda()
+            losses = tr.train_on(s_img, s_lbl, t_img)
+            g_loss = sum(torch.mean(v) for k, v in losses.items() if "D_" not in k)
+            tr.g_optimizer.zero_grad(set_to_none=True)
+            HF.enable_wgrad_overlap(tr.wgrad_overlap)
+            try:
+                g_loss.backward()
+            finally:
+                HF.enable_wgrad_overlap(False)
+            HF.wgrad_stream_join()
+            torch.cuda.synchronize()
+            net = tr.model.module.seg_model.backbone
+            grads.append({k: p.grad.detach().float().cpu() for k, p in net.named_parameters()
+                          if p.grad is not None and "layer3" in k and "conv" in k})
+        finally:
+            os.environ.pop("HIAST_NO_WGRAD_STREAM", None)
+    assert len(grads[0]) >= 60
+    # the two runs differ only by the library's atomically accumulated discriminator / strided-conv gradients (a few
+    # 1e-3 of a tensor's largest element by the time they reach layer3); a race leaves stale blocks in dW instead
+    for k in grads[0]:
+        a, b = grads[0][k].double(), grads[1][k].double()
+        assert float((a - b).abs().max()) <= 3e-2 * float(b.abs().max()) + 1e-12, k
+        assert float((a * b).sum() / (a.norm() * b.norm())) >= 0.9995, k

@@ -356,3 +356,15 @@ def test_decoded_cache_returns_the_decoded_bytes(tmp_path):
     assert small.load(p, lambda q: np.array(Image.open(q).convert("RGB"), dtype=np.uint8)).shape == (32, 64, 3)
     assert os.listdir(str(tmp_path / "small")) == []
     assert c9.dataset.decoded_cache_dir is None             # off unless asked for (the reference has no such feature)
+
+
+def test_set_mode_looks_at_the_wrapped_net():
+    from hiast_amd.utils import utils
+    from hiast_amd.workflows.trainer.base_trainer import _Bare
+    net = torch.nn.Sequential(torch.nn.BatchNorm2d(4))
+    wrap = _Bare(net)
+    net.eval()                      # wrapper still says training=True
+    utils.set_mode(wrap, True)
+    assert wrap.training and net.training and net[0].training
+    utils.set_mode(wrap, False)
+    assert not wrap.training and not net[0].training
