@@ -23,6 +23,9 @@ SIGNATURES = {
     "hiast_upsample_bilinear_ac_bwd": (c_int, [c_vp, c_vp] + [c_int] * 6 + [c_vp]),
     "hiast_plabel_pass1": (c_int, [c_vp] + [c_int] * 6 + [c_vp, c_vp, c_vp, c_vp]),
     "hiast_plabel_pass2": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_i64, c_vp, c_vp, c_vp, c_vp]),
+    "hiast_plabel_strided_hist_workspace_bytes": (c_sz, [c_i64, c_int]),
+    "hiast_plabel_strided_hist": (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "hiast_tta_fused": (c_int, [c_vp] * 6 + [c_int] * 5 + [c_vp, c_vp, c_vp]),
     "hiast_dinput_fwd": (c_int, [c_vp, c_int, c_vp] + [c_int] * 6 + [c_vp]),
     "hiast_dinput_bwd": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp] + [c_int] * 6 + [c_vp]),
     "hiast_st_loss_workspace_bytes": (c_sz, [c_int] * 6),

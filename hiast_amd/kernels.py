@@ -113,6 +113,65 @@ def plabel_pass2(maxprob, argmax, thr_up, C, count=None, sumprob_fx=None):
     return plbl, count, sumprob_fx
 
 
+_strided_ws = {}
+
+
+def plabel_strided_hist(maxprob, argmax, C, interval, hist=None, rank_offset=None, want_totals=False):
+    """CBST's confidence sample of ONE batch (hiast_plabel_strided_hist): every `interval`-th pixel of each class in
+    raster order over the batch -> hist int32 [C,NBINS] (accumulated).  rank_offset i64 [C]: class pixels of the
+    same global batch on lower ranks.  -> hist, or (hist, class_total i64 [C])"""
+    _req(maxprob, torch.float32, None, "maxprob")
+    _req(argmax, torch.uint8, None, "argmax")
+    assert maxprob.shape == argmax.shape
+    dev = maxprob.device
+    N = maxprob.numel()
+    if hist is None:
+        hist = torch.zeros((C, NBINS), dtype=torch.int32, device=dev)
+    _req(hist, torch.int32, 2, "hist")
+    assert tuple(hist.shape) == (C, NBINS)
+    tot = torch.zeros((C,), dtype=torch.int64, device=dev) if want_totals else None
+    if rank_offset is not None:
+        _req(rank_offset, torch.int64, 1, "rank_offset")
+        assert rank_offset.numel() == C
+    if N:
+        lib = _lib.load()
+        n = lib.hiast_plabel_strided_hist_workspace_bytes(N, C)
+        ws = _strided_ws.get(dev)
+        if ws is None or ws.numel() * 4 < n:
+            ws = torch.empty((n + 3) // 4, dtype=torch.int32, device=dev)
+            _strided_ws[dev] = ws
+        check(lib.hiast_plabel_strided_hist(_ptr(maxprob), _ptr(argmax), N, int(C), int(interval), _ptr(rank_offset),
+                                            _ptr(tot), _ptr(hist), _ptr(ws), ws.numel() * 4, _stream()),
+              "hiast_plabel_strided_hist")
+    return (hist, tot) if want_totals else hist
+
+
+def tta_fused(zs, zfs, sizes, H, W, want_probs=False, want_label=True):
+    """Validator.get_multi_scale_and_flip_logits (+ argmax) from the low-res head outputs of every (scale, flip)
+    forward: zs / zfs lists of fp32 [B,C,hs,ws] (zfs None = no flip), sizes list of (Hs, Ws) the image was resized to
+    -> (probsum fp32 [B,C,H,W] or None, label u8 [B,H,W] or None)"""
+    n = len(zs)
+    assert n == len(sizes) and n > 0
+    B, C = zs[0].shape[:2]
+    for z in zs:
+        _req(z, torch.float32, 4, "z")
+        assert tuple(z.shape[:2]) == (B, C)
+    if zfs is not None:
+        assert len(zfs) == n
+        for z, zf in zip(zs, zfs):
+            _req(zf, torch.float32, 4, "zf")
+            assert zf.shape == z.shape
+    dev = zs[0].device
+    vp = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+    iv = lambda vs: (ctypes.c_int * n)(*[int(v) for v in vs])
+    probs = torch.empty((B, C, H, W), dtype=torch.float32, device=dev) if want_probs else None
+    label = torch.empty((B, H, W), dtype=torch.uint8, device=dev) if want_label else None
+    check(_lib.load().hiast_tta_fused(vp(zs), vp(zfs) if zfs is not None else None, iv([z.shape[2] for z in zs]),
+                                      iv([z.shape[3] for z in zs]), iv([s[0] for s in sizes]), iv([s[1] for s in sizes]),
+                                      n, B, C, int(H), int(W), _ptr(probs), _ptr(label), _stream()), "hiast_tta_fused")
+    return probs, label
+
+
 # ------------------------------------------------------------------------------- K15 discriminator input
 def dinput_fwd(logits_lr, H, W, entropy):
     """low-res logits [B,C,h,w] -> softmax (or weighted self-information) map [B,C,H,W] of the upsampled logits"""

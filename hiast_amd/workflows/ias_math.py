@@ -100,9 +100,24 @@ def ias_update(hist, thr_prev, alpha, beta, gamma):
     return temp, thr
 
 
-def cbst_threshold(hist, p):
-    """CBST policy (pseudo_label_generator.py:160-163): np.quantile(values_c, 1-p) without the
-    seeded element; classes never predicted keep the reference's NaN (np.quantile of [])."""
+def cbst_threshold(hist, p, arithmetic=None):
+    """CBST policy (pseudo_label_generator.py:160-163): np.quantile(values_c, 1 - p) of the pooled fp16 confidences
+    (no seeded element); classes never predicted get NaN (numpy 1.19's np.quantile([]); numpy >= 1.22 raises there).
+
+    `values_c` is a list of np.float16 scalars, and what np.quantile does with it depends on the numpy version:
+      * arithmetic="float64" (default): index (n-1)q, gamma and the lerp in float64 — numpy 1.19.2, the reference's
+        pin, converts a float16 sample to float64 on the way; the lerp form a+(b-a)g / b-(b-a)(1-g) is numpy 2.2's,
+        like the IAS quantile above;
+      * arithmetic="float16": numpy >= 2.0 keeps the SAMPLE's dtype — q, the virtual index (n-1)q and the lerp are
+        all rounded to float16 (the index of a sample of more than 2048 values is no longer exact, and beyond
+        65504/q it overflows to inf -> the class maximum is returned).  This is what the reference computes under
+        the numpy of this image, reproduced operation by operation; tests/golden/policies.npz holds such values.
+    HIAST_CBST_QUANTILE=float16|float64 selects it when `arithmetic` is None."""
+    import os
+    if arithmetic is None:
+        arithmetic = os.environ.get("HIAST_CBST_QUANTILE", "float64")
+    if arithmetic not in ("float64", "float16"):
+        raise ValueError("cbst_threshold: arithmetic must be 'float64' or 'float16'")
     C = hist.shape[0]
     out = np.ones(C)
     for c in range(C):
@@ -111,14 +126,35 @@ def cbst_threshold(hist, p):
         if n == 0:
             out[c] = np.nan
             continue
-        vi = (n - 1) * (1 - p)
-        lo = int(np.floor(vi))
-        g = vi - lo
-        hi = min(lo + 1, n - 1)
-        a = BIN_VALUE[int(np.searchsorted(cum, lo, side="right"))]
-        b = BIN_VALUE[int(np.searchsorted(cum, hi, side="right"))]
-        d = b - a
-        out[c] = (b - d * (1 - g)) if g >= 0.5 else (a + d * g)
+        kth = lambda k: BIN_VALUE[int(np.searchsorted(cum, k % n, side="right"))]      # k = -1: the maximum
+        if arithmetic == "float64":
+            vi = (n - 1) * (1 - p)
+            lo = int(np.floor(vi))
+            g = vi - lo
+            hi = min(lo + 1, n - 1)
+            a, b = kth(lo), kth(hi)
+            d = b - a
+            out[c] = (b - d * (1 - g)) if g >= 0.5 else (a + d * g)
+            continue
+        # numpy 2.x on a float16 sample (numpy/lib/_function_base_impl.py: quantile, _quantile, _get_indexes, _lerp)
+        q16 = np.asanyarray(1 - p, dtype=np.float16)
+        with np.errstate(over="ignore", invalid="ignore"):
+            vi = np.asanyarray((n - 1) * q16)                  # float16, rounded; inf beyond 65504
+            prev = np.floor(vi)
+            nxt = prev + 1
+            if vi >= n - 1 or np.isnan(vi):
+                lo = hi = -1
+            elif vi < 0:
+                lo = hi = 0
+            else:
+                lo, hi = int(prev), int(nxt)
+            gamma = np.asanyarray(np.asanyarray(vi - np.intp(lo)), dtype=np.float16)
+            a, b = np.float16(kth(lo)), np.float16(kth(hi))
+            diff = np.subtract(b, a)
+            r = np.add(a, diff * gamma)
+            if gamma >= 0.5:
+                r = np.subtract(b, diff * (1 - gamma)).astype(np.float16)
+        out[c] = float(r)
     return out
 
 

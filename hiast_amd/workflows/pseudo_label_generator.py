@@ -74,6 +74,16 @@ class HipPlabelEngine:
         return hist
 
     @torch.no_grad()
+    def strided_hist(self, interval, rank_offset=None):
+        """CBST's sample of the batch pass1() has just seen: every `interval`-th pixel of each class in raster order
+        (offset by the class pixels lower ranks hold in the same global batch) -> hist i32 [C,NBINS]"""
+        from hiast_amd import kernels as K
+        if self._mp is None:
+            return torch.zeros((self.C, ias_math.NBINS), dtype=torch.int32, device=self.device)
+        off = None if rank_offset is None else torch.as_tensor(rank_offset, dtype=torch.int64).to(self.device)
+        return K.plabel_strided_hist(self._mp, self._am, self.C, interval, rank_offset=off)
+
+    @torch.no_grad()
     def pass2(self, thr64):
         """-> (plbl uint8 numpy [b,H,W] or None, count i64 tensor [b,C], sumprob_fx i64 tensor [C])"""
         from hiast_amd import kernels as K
@@ -255,15 +265,26 @@ class NoThresholdPseudoGenerator(ConstantThresholdPseudoGenerator):
 
 @PSEUDO_POLICY.register("CBST")
 class CBSTPseudoGenerator(ConstantThresholdPseudoGenerator):
-    """Global per-class quantile over the whole target set (pseudo_label_generator.py:142-165).
-    The reference subsamples every `sample_interval`-th value to bound host memory; the histogram
-    has no such limit, so every pixel is counted (sample_interval is ignored — documented)."""
+    """Global per-class quantile over the whole target set (pseudo_label_generator.py:142-165): per batch and class,
+    every `sample_interval`-th confidence of the class's pixels in raster order enters the pool (here: the pooled
+    fp16 histogram); the threshold is its (1 - p) quantile.  Sharded runs rank the pixels of a global batch across the
+    ranks (rank r's pixels follow those of ranks < r), so the sample equals the single-process one at
+    batch_size = world x local.  A class that is never predicted gets NaN (numpy 1.19's np.quantile([]); numpy >= 1.22
+    raises there) — no pixel carries that label, so it is never compared."""
 
     def get_constant_threshold(self):
         C = self.cfg.dataset.num_classes
+        interval = int(self.cfg.pseudo_policy.cbst.sample_interval)
         total = torch.zeros((C, ias_math.NBINS), dtype=torch.int64, device=self.engine.device)
         for imgs, _ in self._batches():
-            total += self.engine.pass1(imgs).long()
+            full = self.engine.pass1(imgs)
+            offset = None
+            if self.world > 1:          # class-c pixels of this global batch held by the lower ranks
+                mine = full.long().sum(1)
+                parts = [torch.zeros_like(mine) for _ in range(self.world)]
+                dist.all_gather(parts, mine)
+                offset = torch.stack(parts[:self.rank]).sum(0) if self.rank else torch.zeros_like(mine)
+            total += (full if interval == 1 and offset is None else self.engine.strided_hist(interval, offset)).long()
         total = self._allreduce(total)
         return ias_math.cbst_threshold(total.cpu().numpy(), self.cfg.pseudo_policy.cbst.p)
 

@@ -48,9 +48,29 @@ class Validator:
             assert not os.path.exists(d) or len(os.listdir(d)) == 0
             os.makedirs(d, exist_ok=True)
 
+    def _tta_device(self, imgs, want_probs, want_label):
+        """the softmax-sum TTA on the HIP device: every (scale, flip) forward hands over its LOW-RES head output and
+        one kernel (hiast_tta_fused) does upsample -> softmax -> (+ flipped) -> resample to native -> Σ scales
+        (-> argmax); no full-resolution logits or per-scale probability maps are stored"""
+        from hiast_amd import kernels as K
+        zs, zfs, sizes = [], [], []
+        for size in self.cfg.validate.resize_sizes:
+            assert len(size) == 2 and size[0] <= size[1], \
+                "each resize_size is [height, width] with height <= width, such as [512, 1024]"
+            x = _resample(imgs, size)
+            zs.append(self.model(x, lowres=True)["logits_lowres"].float().contiguous())
+            if self.cfg.validate.is_flip:
+                zfs.append(self.model(torch.flip(x, dims=[3]), lowres=True)["logits_lowres"].float().contiguous())
+            sizes.append((int(size[0]), int(size[1])))
+        H, W = imgs.shape[2:]
+        return K.tta_fused(zs, zfs if self.cfg.validate.is_flip else None, sizes, H, W, want_probs, want_label)
+
     def get_multi_scale_and_flip_logits(self, imgs, is_softmax=True):
         """validator.py:34-55: Σ over scales of softmax(model(resized)) (+ flipped), each resampled
         back to the native size"""
+        if imgs.is_cuda and is_softmax:
+            return self._tta_device(imgs, True, False)[0]
+
         def pred(x):
             y = self.model(x)["logits"]
             return F.softmax(y, dim=1) if is_softmax else y
@@ -91,7 +111,10 @@ class Validator:
         for data in tqdm.tqdm(self.v_loader, desc="Validation", ncols=100):
             imgs = data["images"].to(self.device)
             lbls = data["labels"].to(self.device)
-            pred = self.get_multi_scale_and_flip_logits(imgs).argmax(dim=1)
+            if imgs.is_cuda:     # fused tail: label map straight from the low-res head outputs
+                pred = self._tta_device(imgs, False, True)[1].long()
+            else:
+                pred = self.get_multi_scale_and_flip_logits(imgs).argmax(dim=1)
             inter, union = metrics.intersection_union_counts(pred, lbls, C)
             acc[0] += inter
             acc[1] += union

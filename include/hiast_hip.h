@@ -5,7 +5,9 @@
  * Conventions (all entry points):
  *   - every pointer is a DEVICE pointer into caller-owned memory unless marked "host";
  *     the library never allocates, frees or keeps a pointer after the call returns;
- *   - tensors are contiguous NCHW fp32; label maps are uint8 or int64 (is_i64 flag);
+ *   - head-side tensors (logits, probabilities, ASPP I/O of K1, fp32 BN of K10, K2-K8, K15, K16) are contiguous
+ *     NCHW fp32; the trunk kernels (K1b, K9, K9c, K9d, K10b) take CHANNELS-LAST rows [B,H,W,C] in fp32, bf16 or
+ *     bf16 split planes (hi|lo slabs) as stated per entry point; label maps are uint8 or int64 (is_i64 flag);
  *   - calls only ENQUEUE work on `stream` (a hipStream_t passed as void*); they never
  *     synchronise the device, so a caller's DDP/compute overlap is preserved;
  *   - return value: 0 = ok, <0 = argument error (HIAST_E_*), >0 = a hipError_t;
@@ -77,6 +79,30 @@ int hiast_plabel_pass1(const float* logits_lr, int B, int C, int h, int w, int H
 int hiast_plabel_pass2(const float* maxprob, const uint8_t* argmax, const float* thr_up,
                        int B, int C, int64_t HW, uint8_t* plbl, int64_t* count,
                        uint64_t* sumprob_fx, hiast_stream_t stream);
+
+/* ---- K3b: CBST confidence sample -------------------------------------------------------
+ * CBSTPseudoGenerator.get_constant_threshold, workflows/pseudo_label_generator.py:142-158:
+ *   for c: tmp = probs_pred[lbls_pred == c].astype(float16); list_c.extend(tmp[0:len(tmp):interval])
+ * over ONE batch: maxprob f32 [N], argmax u8 [N] (N = B*H*W, raster order) -> hist u32 [C,HIAST_NBINS] += the
+ * kept pixels' fp16 bins (pixel kept iff (rank_offset[c] + its rank among the batch's class-c pixels) % interval == 0).
+ * rank_offset i64 [C] or NULL (= 0): class-c pixels of this global batch held by lower ranks (sharded generation);
+ * class_total i64 [C] or NULL: out, the batch's per-class pixel counts.  workspace: device scratch of
+ * hiast_plabel_strided_hist_workspace_bytes(N, C). */
+size_t hiast_plabel_strided_hist_workspace_bytes(int64_t N, int C);
+int hiast_plabel_strided_hist(const float* maxprob, const uint8_t* argmax, int64_t N, int C, int interval,
+                              const int64_t* rank_offset, int64_t* class_total, uint32_t* hist,
+                              void* workspace, size_t workspace_bytes, hiast_stream_t stream);
+
+/* ---- K16: multi-scale + flip test-time augmentation, fused tail -------------------------
+ * Validator.get_multi_scale_and_flip_logits + argmax, workflows/validator.py:34-55,92, from the LOW-RES head outputs:
+ *   out = sum_s interp( softmax(interp(z[s] -> Hs[s] x Ws[s])) + flip_w(softmax(interp(zf[s] -> ...))) -> H x W )
+ * z, zf: HOST arrays of n_scales device pointers to [B,C,hs[s],ws[s]] fp32 (zf NULL or zf[s] NULL = no flip);
+ * hs, ws, Hs, Ws: host int arrays.  probsum f32 [B,C,H,W] and/or label u8 [B,H,W] (either may be NULL):
+ * neither full-resolution logits nor per-scale probability maps are stored. */
+#define HIAST_TTA_MAX_SCALES 8
+int hiast_tta_fused(const float* const* z, const float* const* zf, const int* hs, const int* ws, const int* Hs,
+                    const int* Ws, int n_scales, int B, int C, int H, int W, float* probsum, uint8_t* label,
+                    hiast_stream_t stream);
 
 /* ---- K5-K8: fused self-training loss ------------------------------------------------
  * SelfTrainingSegmentor.compute_loss, self_training_segmentor.py:30-53 with

@@ -147,3 +147,22 @@ def ema_update(ema, p, gamma):
     lib().orc_ema_update(_p(ema, _f32p), _p(p, _f32p), ctypes.c_int64(ema.size),
                          ctypes.c_float(np.float32(gamma)), ctypes.c_float(np.float32(1 - gamma)))
     return ema
+
+
+def tta(zs, zfs, sizes, H, W, want_probs=True):
+    """multi-scale + flip TTA from low-res head outputs (orc_tta): zs / zfs lists of [B,C,hs,ws] (zfs entries may be
+    None = no flip), sizes list of (Hs, Ws) -> (probsum f32 [B,C,H,W] or None, label u8 [B,H,W])"""
+    n = len(zs)
+    zs = [_c(z, np.float32) for z in zs]
+    B, C = zs[0].shape[:2]
+    flip = zfs is not None and any(z is not None for z in zfs)
+    zfs = [_c(z, np.float32) if z is not None else None for z in zfs] if flip else None
+    ZP = (_f32p * n)(*[_p(z, _f32p) for z in zs])
+    ZF = (_f32p * n)(*[(_p(z, _f32p) if z is not None else None) for z in zfs]) if flip else None
+    iarr = lambda v: (ctypes.c_int * n)(*[int(x) for x in v])
+    H, W = int(H), int(W)
+    probs = np.empty((B, C, H, W), np.float32) if want_probs else None
+    label = np.empty((B, H, W), np.uint8)
+    lib().orc_tta(ZP, ZF, iarr([z.shape[2] for z in zs]), iarr([z.shape[3] for z in zs]), iarr([s[0] for s in sizes]),
+                  iarr([s[1] for s in sizes]), n, B, C, H, W, _p(probs, _f32p) if want_probs else None, _p(label, _u8p))
+    return probs, label

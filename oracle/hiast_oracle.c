@@ -260,3 +260,75 @@ void orc_ema_update(float* ema, const float* p, int64_t n, float gamma, float om
 {
     for (int64_t i = 0; i < n; ++i) ema[i] = ema[i] * gamma + p[i] * omg;
 }
+
+/* ---- K16: multi-scale + flip test-time augmentation ----------------------------------- */
+/* Validator.get_multi_scale_and_flip_logits (workflows/validator.py:34-55) downstream of the
+ * segmentation net's LOW-RES head outputs, in HIAST-A arithmetic:
+ *   per scale s: P_s = softmax(interp(z_s -> Hs x Ws)) [+ flip_w(softmax(interp(zf_s -> Hs x Ws)))]
+ *                (self_training_segmentor.py:27 + validator.py:37,46-50);
+ *   out = sum_s interp(P_s -> H x W) (:52,55); label = argmax (:92, first max wins).
+ * softmax(v)_c = expA(v_c - m) * (1/sum), sum ascending in c. */
+static void orc_softmax_at(const float* z, int C, int hs, int ws, float sh, float sw, int Y, int X, float* out)
+{
+    int y0, y1, x0, x1; float hl0, hl1, wl0, wl1;
+    orc_src(sh, Y, hs, &y0, &y1, &hl0, &hl1);
+    orc_src(sw, X, ws, &x0, &x1, &wl0, &wl1);
+    float m = 0.0f;
+    for (int c = 0; c < C; ++c) {
+        out[c] = orc_tap4(z + (size_t)c * hs * ws, ws, y0, y1, x0, x1, hl0, hl1, wl0, wl1);
+        if (c == 0 || out[c] > m) m = out[c];
+    }
+    float s = 0.0f;
+    for (int c = 0; c < C; ++c) { out[c] = orc_expf(out[c] - m); s = s + out[c]; }
+    float inv = 1.0f / s;
+    for (int c = 0; c < C; ++c) out[c] = out[c] * inv;
+}
+
+void orc_tta(const float* const* z, const float* const* zf, const int* hs, const int* ws, const int* Hs,
+             const int* Ws, int n_scales, int B, int C, int H, int W, float* probsum, uint8_t* label)
+{
+    float tmp[64], tmp2[64];
+    float* acc = (float*)calloc((size_t)B * C * H * W, sizeof(float));
+    for (int s = 0; s < n_scales; ++s) {
+        int h_ = hs[s], w_ = ws[s], HS = Hs[s], WS = Ws[s];
+        float* P = (float*)malloc((size_t)C * HS * WS * sizeof(float));
+        float sh = orc_scale(h_, HS), sw = orc_scale(w_, WS);
+        float rh = orc_scale(HS, H), rw = orc_scale(WS, W);
+        for (int b = 0; b < B; ++b) {
+            const float* zb = z[s] + (size_t)b * C * h_ * w_;
+            const float* zfb = (zf && zf[s]) ? zf[s] + (size_t)b * C * h_ * w_ : NULL;
+            for (int Y = 0; Y < HS; ++Y)
+                for (int X = 0; X < WS; ++X) {
+                    orc_softmax_at(zb, C, h_, w_, sh, sw, Y, X, tmp);
+                    if (zfb) {
+                        orc_softmax_at(zfb, C, h_, w_, sh, sw, Y, WS - 1 - X, tmp2);
+                        for (int c = 0; c < C; ++c) tmp[c] = tmp[c] + tmp2[c];
+                    }
+                    for (int c = 0; c < C; ++c) P[((size_t)c * HS + Y) * WS + X] = tmp[c];
+                }
+            for (int c = 0; c < C; ++c)
+                for (int Y = 0; Y < H; ++Y) {
+                    int y0, y1; float hl0, hl1;
+                    orc_src(rh, Y, HS, &y0, &y1, &hl0, &hl1);
+                    for (int X = 0; X < W; ++X) {
+                        int x0, x1; float wl0, wl1;
+                        orc_src(rw, X, WS, &x0, &x1, &wl0, &wl1);
+                        size_t o = (((size_t)b * C + c) * H + Y) * W + X;
+                        acc[o] = acc[o] + orc_tap4(P + (size_t)c * HS * WS, WS, y0, y1, x0, x1, hl0, hl1, wl0, wl1);
+                    }
+                }
+        }
+        free(P);
+    }
+    for (int b = 0; b < B; ++b)
+        for (size_t i = 0; i < (size_t)H * W; ++i) {
+            float m = 0.0f; int am = 0;
+            for (int c = 0; c < C; ++c) {
+                float v = acc[((size_t)b * C + c) * H * W + i];
+                if (probsum) probsum[((size_t)b * C + c) * H * W + i] = v;
+                if (c == 0 || v > m) { m = v; am = c; }
+            }
+            if (label) label[(size_t)b * H * W + i] = (uint8_t)am;
+        }
+    free(acc);
+}

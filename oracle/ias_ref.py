@@ -99,3 +99,40 @@ class IASState:
                 self.class_mean_probs[c] = self.class_mean_probs[c] * self.cp_gamma + \
                     mean_value * (1 - self.cp_gamma)
         return plbl.astype(np.uint8)
+
+
+def cbst_lists(batches, num_classes, sample_interval):
+    """pseudo_label_generator.py:146-158: per class the fp16 max-probs of every `sample_interval`-th pixel of that
+    class IN EACH BATCH (raster order over the batch), pooled over the whole target set.
+    batches: iterable of (probs_pred f32 [B,H,W], lbls_pred)."""
+    lists = {c: [] for c in range(num_classes)}
+    for probs_pred, lbls_pred in batches:
+        for c in range(num_classes):
+            tmp = probs_pred[lbls_pred == c].astype(np.float16)
+            lists[c].extend(tmp[0:len(tmp):sample_interval])
+    return lists
+
+
+def cbst_threshold(batches, num_classes, p, sample_interval, as_float64=False):
+    """CBSTPseudoGenerator.get_constant_threshold (pseudo_label_generator.py:142-165): np.quantile(list_c, 1 - p).
+    The lists hold np.float16 scalars: numpy >= 2 (this image: what the fixtures record) evaluates the quantile in
+    float16, numpy 1.19.2 (the reference's pin) in float64 — `as_float64` converts the sample first."""
+    lists = cbst_lists(batches, num_classes, sample_interval)
+    thr = np.ones(num_classes)
+    for c in range(num_classes):
+        if not len(lists[c]):
+            thr[c] = np.nan                    # numpy 1.19: np.quantile([]) = nan; numpy >= 1.22 raises
+            continue
+        thr[c] = np.quantile(np.asarray(lists[c], np.float64) if as_float64 else lists[c], 1 - p)
+    return thr
+
+
+class ConstantPolicyState(IASState):
+    """'CT' / 'NT' / 'CBST' (pseudo_label_generator.py:109-140): one threshold vector (or None) for the whole set."""
+
+    def __init__(self, num_classes, class_threshold, cp_gamma=0.99):
+        super().__init__(num_classes, 0.0, 0.0, 0.0, cp_gamma)
+        self.class_threshold = None if class_threshold is None else np.asarray(class_threshold, np.float64)
+
+    def step(self, probs_pred, lbls_pred, img_paths):
+        return self.select_and_record(probs_pred, lbls_pred, img_paths)

@@ -467,7 +467,188 @@ def g_warmup():
     save("warmup", **out)
 
 
-ALL = {"upsample": g_upsample, "stage_a": g_stage_a, "ias": g_ias, "losses": g_losses,
+
+# ---------------------------------------------------------------------------------- G5b: CT / NT / CBST
+POLICY_SHAPE = (3, 2, 19, 8, 16, 64, 128)          # batches, B, C, h, w, H, W
+POLICY_SEED = 2600
+
+
+class _ListLoader(list):
+    """stands in for the DataLoader: a list of {'images', 'image_paths'} dicts"""
+
+
+class _LogitModel:
+    """stands in for the segmentor: hands out prepared FULL-RES logits batch by batch (call order)"""
+
+    def __init__(self, logits):
+        self.logits, self.i = logits, 0
+
+    def eval(self):
+        return self
+
+    def __call__(self, imgs):
+        out = {"logits": self.logits[self.i % len(self.logits)]}
+        self.i += 1
+        return out
+
+
+def policy_inputs():
+    """low-res logits of every batch (the GPU test feeds the same arrays to the HIP generator)"""
+    nb, B, C, h, w, H, W = POLICY_SHAPE
+    return [synth.smooth_logits_lr(POLICY_SEED + t, B, C, h, w) for t in range(nb)]
+
+
+def g_policies():
+    """ConstantThreshold / NoThreshold / CBST generators (pseudo_label_generator.py:109-165): the reference's own
+    run() on a stub model + list loader; artefacts captured from its cv2.imwrite / save_data."""
+    import tempfile
+    plg = ref_import.ref("workflows.pseudo_label_generator")
+    F = torch.nn.functional
+    nb, B, C, h, w, H, W = POLICY_SHAPE
+    zs = policy_inputs()
+    logits = [F.interpolate(torch.from_numpy(z), size=(H, W), mode="bilinear", align_corners=True) for z in zs]
+    paths = [["data/cityscapes/leftImg8bit/train/x/img_%03d_leftImg8bit.png" % (t * B + b) for b in range(B)]
+             for t in range(nb)]
+    out = {"shape": np.array(POLICY_SHAPE), "seed": np.array(POLICY_SEED)}
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        for tag, cls, pp in (("ct", plg.ConstantThresholdPseudoGenerator, ns(type="CT", ct=ns(threshold=0.9))),
+                             ("nt", plg.NoThresholdPseudoGenerator, ns(type="NT")),
+                             ("cbst", plg.CBSTPseudoGenerator, ns(type="CBST", cbst=ns(p=0.2, sample_interval=4)))):
+            cfg = make_cfg(C)
+            cfg.pseudo_policy = pp
+            gen = object.__new__(cls)
+            gen.cfg = cfg
+            gen.statics_class = np.array([0] * C)
+            gen.sample_stats = []
+            gen.samples_class = {i: [] for i in range(C)}
+            gen.class_mean_probs = np.zeros(C)
+            gen.class_threshold = None
+            with tempfile.TemporaryDirectory() as td:
+                gen.pseudo_label_save_dir = os.path.join(td, "pseudo_labels")
+                os.makedirs(gen.pseudo_label_save_dir)
+                gen.model = _LogitModel(logits)
+                gen.t_dataset = list(range(nb * B))
+                gen.t_loader = _ListLoader({"images": torch.zeros(B, 3, H, W), "image_paths": paths[t]}
+                                           for t in range(nb))
+                ref_import.captured_pngs().clear()
+                gen.run()
+                pngs = ref_import.captured_pngs()
+                plbl = np.stack([pngs[os.path.join(gen.pseudo_label_save_dir,
+                                                   os.path.splitext(os.path.basename(p))[0] + "_pseudo_label.png")]
+                                 for batch in paths for p in batch])
+                root = os.path.join(td)
+                out["statics_" + tag] = np.load(os.path.join(root, "statics_class.npy"))
+                out["mean_" + tag] = np.load(os.path.join(root, "class_mean_probabilities.npy"))
+                if os.path.exists(os.path.join(root, "class_threshold.npy")):
+                    out["thr_" + tag] = np.load(os.path.join(root, "class_threshold.npy"))
+                out["sample_stats_" + tag] = np.array(open(os.path.join(root, "sample_class_stats.json")).read())
+            out["plbl_" + tag] = plbl.astype(np.uint8)
+    finally:
+        torch.Tensor.cuda = orig_cuda
+    save("policies", **out)
+
+
+# ---------------------------------------------------------------------------------- G9: Validator TTA, G7b: SYNTHIA
+TTA_SHAPE = (2, 19, 64, 128)                        # B, C, H, W (native)
+TTA_SIZES = [[48, 96], [64, 128], [80, 160]]
+TTA_SEED = 2700
+
+
+class _HeadModel:
+    """stands in for the segmentor inside Validator: full-res logits = F.interpolate(head(x)) where the "head" is a
+    fixed low-res logit map per (input size, flipped?) — the GPU test feeds the same maps to the fused kernel"""
+
+    def __init__(self, table):
+        self.table = table
+        self.calls = []
+
+    def eval(self):
+        return self
+
+    def cuda(self):
+        return self
+
+    def __call__(self, x):
+        key = (int(x.shape[2]), int(x.shape[3]), bool(x[0, 0, 0, 0] < 0))     # flipped inputs carry a marker
+        self.calls.append(key)
+        z = torch.from_numpy(self.table[key])
+        return {"logits": torch.nn.functional.interpolate(z, size=x.shape[2:], mode="bilinear", align_corners=True)}
+
+
+def tta_inputs():
+    """{(Hs, Ws, flipped): low-res head logits [B,C,Hs/8,Ws/8]}"""
+    B, C, H, W = TTA_SHAPE
+    t = {}
+    for i, (hs, ws) in enumerate(TTA_SIZES):
+        t[(hs, ws, False)] = synth.smooth_logits_lr(TTA_SEED + 2 * i, B, C, hs // 8, ws // 8)
+        t[(hs, ws, True)] = synth.smooth_logits_lr(TTA_SEED + 2 * i + 1, B, C, hs // 8, ws // 8)
+    return t
+
+
+def g_tta():
+    """Validator.get_multi_scale_and_flip_logits (validator.py:34-55) and the mIoU bookkeeping of Validator.run
+    (:78-115) incl. the SYNTHIA 16/13-class rescale, on a stub model."""
+    import contextlib
+    import io
+    import re
+    val = ref_import.ref("workflows.validator")
+    B, C, H, W = TTA_SHAPE
+    table = tta_inputs()
+    out = {"shape": np.array(TTA_SHAPE), "sizes": np.array(TTA_SIZES), "seed": np.array(TTA_SEED)}
+    # images: +1 everywhere, the left column of the ORIGINAL marked with +2 so that the flipped view is recognisable:
+    # after torch.flip the marker sits at the right edge and x[0,0,0,0] ... use sign: original >0, flipped <0 at [0,0]
+    img = torch.ones(B, 3, H, W)
+    img[:, :, :, : W // 2] = 1.0
+    img[:, :, :, W // 2:] = -1.0           # left half positive, right half negative: flipping swaps them
+    for flip in (False, True):
+        v = object.__new__(val.Validator)
+        v.cfg = ns(validate=ns(resize_sizes=TTA_SIZES, is_flip=flip, color_mask_dir_path=None, batch_size=B),
+                   dataset=ns(num_classes=C, source=ns(type="GTAV")))
+        v.model = _HeadModel(table)
+        with torch.no_grad():
+            r = v.get_multi_scale_and_flip_logits(img)
+        tag = "flip" if flip else "noflip"
+        out["probsum_" + tag] = r.numpy()[:, :, ::3, ::5].copy()
+        out["probsum_total_" + tag] = np.array(r.double().sum().item())
+        out["label_" + tag] = r.argmax(1).numpy().astype(np.uint8)
+        out["calls_" + tag] = np.array(json.dumps(v.model.calls))
+    # Validator.run with a SYNTHIA source: prints miou_16 / miou_13 (validator.py:108-113)
+    # ground truth = the TTA prediction itself with 35 % of the pixels re-drawn at random and 15 % ignored, so that the
+    # IoUs are spread over (0, 1); SYNTHIA has no terrain / truck / train (9, 14, 16)
+    pred = out["label_flip"].astype(np.int64)
+    lbl = np.concatenate([pred, pred])
+    noise = np.stack([synth.pseudo_labels(TTA_SEED + 50 + b, 1, H, W, C, 0.15, np.int64)[0] for b in range(2 * B)])
+    redraw = synth.rng(TTA_SEED + 60).random(lbl.shape) < 0.35
+    lbl[redraw] = noise[redraw]
+    lbl[noise == 255] = 255
+    for cdrop in (9, 14, 16):
+        lbl[lbl == cdrop] = 255
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        for src in ("SYNTHIA", "GTAV"):
+            v = object.__new__(val.Validator)
+            v.cfg = ns(validate=ns(resize_sizes=TTA_SIZES, is_flip=True, color_mask_dir_path=None, batch_size=B),
+                       dataset=ns(num_classes=C, source=ns(type=src)))
+            v.model = _HeadModel(table)
+            v.v_loader = [{"images": img, "labels": torch.from_numpy(lbl[i * B:(i + 1) * B]),
+                           "image_paths": ["a.png"] * B} for i in range(2)]
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                v.run()
+            line = [l for l in buf.getvalue().splitlines() if l.startswith("miou")][-1]
+            out["run_line_" + src] = np.array(line)
+            nums = [float(x) for x in re.findall(r"miou(?:_1[36])?: ([0-9.]+)", line)]
+            out["run_miou_" + src] = np.array(nums)
+    finally:
+        torch.Tensor.cuda = orig_cuda
+    out["run_labels"] = lbl.astype(np.uint8)
+    save("tta", **out)
+
+
+ALL = {"policies": g_policies, "tta": g_tta, "upsample": g_upsample, "stage_a": g_stage_a, "ias": g_ias, "losses": g_losses,
        "aspp": g_aspp, "deeplab": g_deeplab, "metrics": g_metrics, "copy_paste": g_copy_paste,
        "ema_optim": g_ema_optim, "warmup": g_warmup}
 

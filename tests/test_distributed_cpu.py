@@ -22,7 +22,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _gen_worker(rank, world, port, root, out):
+def _gen_worker(rank, world, port, root, out, policy="IAS"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -41,8 +41,10 @@ def _gen_worker(rank, world, port, root, out):
     from hiast_amd.utils.default_config import CfgNode
     c = CfgNode(objs[0])
     c.pseudo_policy.batch_size = 2
+    c.pseudo_policy.type = policy
+    c.pseudo_policy.cbst.sample_interval = 3
     c.pseudo_policy.save_dir = os.path.join(root, "pseudo_w%d" % world, "pseudo_labels")
-    gen = PSEUDO_POLICY["IAS"](c, engine=OracleEngine(C, h, w))
+    gen = PSEUDO_POLICY[policy](c, engine=OracleEngine(C, h, w))
     gen.run()
     if rank == 0:
         np.save(out, gen.class_threshold)
@@ -96,6 +98,44 @@ def test_sharded_generator_equals_single_process(tmp_path):
     w1 = json.load(open(os.path.join(d1, "samples_with_class.json")))
     w2 = json.load(open(os.path.join(d2, "samples_with_class.json")))
     assert {k: sorted(v) for k, v in w1.items()} == {k: sorted(v) for k, v in w2.items()}
+
+
+def test_sharded_cbst_equals_single_process(tmp_path):
+    """CBST's strided confidence sample ranks the pixels of a GLOBAL batch across the ranks: 2 ranks x batch 2 give the
+    thresholds (and label maps) of the single process at batch 4, bit for bit, and both equal the reference's
+    list formulation (oracle) driven in the same order"""
+    from hiast_amd.utils.registry import register  # noqa: F401
+    from hiast_amd.utils.registry.registries import PSEUDO_POLICY
+    from hiast_amd.tools import synth_data
+    from oracle import ias_ref
+    from test_host_cpu import OracleEngine
+    root = str(tmp_path)
+    out = os.path.join(root, "thr_w2.npy")
+    mp.spawn(_gen_worker, args=(2, _free_port(), root, out, "CBST"), nprocs=2, join=True)
+    h, w, C = 32, 64, 19
+    c = synth_data.synthetic_cfg(root + "/again", n_train=7, n_val=1, h=h, w=w)
+    c.dataset.target.json_path = os.path.join(root, "data", "cityscapes_train.json")
+    c.dataset.target.image_dir = os.path.join(root, "data", "cityscapes")
+    c.pseudo_policy.type = "CBST"
+    c.pseudo_policy.cbst.sample_interval = 3
+    c.pseudo_policy.batch_size = 4
+    c.pseudo_policy.save_dir = os.path.join(root, "pseudo_w1", "pseudo_labels")
+    gen = PSEUDO_POLICY["CBST"](c, engine=OracleEngine(C, h, w))
+    gen.run()
+    thr2 = np.load(out)
+    assert np.array_equal(thr2.view(np.uint64), gen.class_threshold.view(np.uint64), equal_nan=False) or \
+        np.array_equal(np.nan_to_num(thr2, nan=-1.0), np.nan_to_num(gen.class_threshold, nan=-1.0))
+    # the reference's formulation on the same batches
+    eng = OracleEngine(C, h, w)
+    batches = []
+    for data in gen.t_loader:
+        eng.pass1(data["images"])
+        batches.append((eng.mp, eng.am.astype(np.int64)))
+    want = ias_ref.cbst_threshold(batches, C, c.pseudo_policy.cbst.p, 3, as_float64=True)
+    assert np.array_equal(np.nan_to_num(gen.class_threshold, nan=-1.0), np.nan_to_num(want, nan=-1.0))
+    for f in ("statics_class.npy", "class_mean_probabilities.npy"):
+        a, b = np.load(os.path.join(root, "pseudo_w1", f)), np.load(os.path.join(root, "pseudo_w2", f))
+        assert np.array_equal(a, b), f
 
 
 def test_sharded_batch_sampler_partitions():

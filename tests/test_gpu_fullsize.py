@@ -1,0 +1,94 @@
+"""Parity at BASELINE sizes against the ORACLE (not against this package's other code paths): the fp32-class eval
+forward (split-bf16 planes through 101 layers + ASPP GEMM) at 1x3x512x1024 (configs[1-3]) and 1x3x1024x2048
+(configs[4]) vs oracle/deeplab_ref.py (torch-CPU fp32 functional restatement, pinned by tests/golden/deeplab.npz).
+Contract (BASELINE north_star): logits within 1e-3 relative fp32; argmax label maps equal."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _calibrated_state(seed, scale_to=3.0):
+    """seeded DeepLab_V2 weights whose head is rescaled so that the logits have std ~ scale_to (max-probs spread over
+    (1/C, 1) like a trained net's, instead of the near-uniform softmax of a 0.01-std random head)"""
+    from hiast_amd.utils.registry import register  # noqa: F401
+    from hiast_amd.utils.registry.registries import SEG_MODEL
+    from make_golden import seeded_state_dict
+    m = SEG_MODEL["DeepLab_V2"](19, 256)
+    sd = seeded_state_dict(m, seed)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    x = torch.from_numpy(synth.normal_f32(seed + 1, (1, 3, 128, 256))).cuda()
+    with torch.no_grad():
+        s = scale_to / float(m(x, need_feat=False)[0].std())
+    for i in range(4):
+        sd["aspp.conv2d_list.%d.weight" % i] = sd["aspp.conv2d_list.%d.weight" % i] * s
+        sd["aspp.conv2d_list.%d.bias" % i] = sd["aspp.conv2d_list.%d.bias" % i] * s
+    m.load_state_dict(sd)
+    return m, sd
+
+
+@pytest.mark.parametrize("size", [(512, 1024), (1024, 2048)])
+def test_eval_forward_at_baseline_size_vs_oracle(size):
+    from oracle import deeplab_ref
+    H, W = size
+    m, sd = _calibrated_state(9100)
+    x = torch.from_numpy(synth.normal_f32(9200 + H, (1, 3, H, W)))
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    with torch.no_grad():
+        got, _ = m(x.cuda(), need_feat=False)
+        want, _ = deeplab_ref.deeplab_v2(x, sd)
+    got = got.float().cpu()
+    assert tuple(got.shape) == (1, 19, H // 8, W // 8)
+    err = (got - want).abs()
+    scale = float(want.abs().max())
+    rms = float(want.pow(2).mean().sqrt())
+    # (a) max-norm, (b) per element relative to |ref| + rms (pure per-element relative is meaningless at logits that
+    # happen to be ~0; rms is the natural floor), both against the 1e-3 contract
+    assert float(err.max()) <= 1e-3 * scale, (float(err.max()), scale)
+    rel = err / (want.abs() + rms)
+    assert float(rel.max()) <= 1e-3, float(rel.max())
+    # (c) argmax label map: equal wherever the reference's own top-2 gap exceeds the contract's resolution
+    top2 = want.topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 2e-3 * scale
+    assert float(clear.float().mean()) > 0.95
+    assert torch.equal(got.argmax(1)[clear], want.argmax(1)[clear])
+    differ = float((got.argmax(1) != want.argmax(1)).float().mean())
+    assert differ <= 2e-3, differ
+    print("size %dx%d: max|d|/max|ref| = %.2e, max rel = %.2e, argmax differs on %.2e of the low-res pixels"
+          % (H, W, float(err.max()) / scale, float(rel.max()), differ))
+
+
+def test_generator_labels_from_device_forward_vs_oracle_forward():
+    """the whole pseudo-label chain at 512x1024 with the FORWARD included: device forward -> HIP pass 1 / thresholds /
+    pass 2, against oracle forward (torch CPU) -> oracle stage A -> the reference's list + np.quantile IAS step.
+    Reports the fraction of differing label pixels (threshold-edge and fp16-bin flips caused by the <= 1e-3 logits
+    difference); argmax maps must agree except at near-ties."""
+    from oracle import cref, deeplab_ref, ias_ref
+    from hiast_amd import kernels as K
+    from hiast_amd.workflows import ias_math
+    H, W, C, B = 512, 1024, 19, 2
+    m, sd = _calibrated_state(9300)
+    x = torch.from_numpy(synth.normal_f32(9400, (B, 3, H, W)))
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    with torch.no_grad():
+        z_dev = m(x.cuda(), need_feat=False)[0].float().contiguous()
+        z_ref = deeplab_ref.deeplab_v2(x, sd)[0].numpy()
+    mp, am, hist = K.plabel_pass1(z_dev, H, W)
+    _, thr = ias_math.ias_update(hist.cpu().numpy().view(np.uint32), 0.9 * np.ones(C), 0.5, 0.9, 8.0)
+    plbl, _, _ = K.plabel_pass2(mp, am, K.h2d_async(ias_math.roundup_f32(thr), z_dev.device), C)
+    mp_o, am_o = cref.plabel_stage_a(z_ref, H, W)
+    st = ias_ref.IASState(C, 0.5, 0.9, 8.0)
+    plbl_o = st.step(mp_o, am_o.astype(np.int64), ["a.png", "b.png"])
+    am_diff = float((am.cpu().numpy() != am_o).mean())
+    lbl_diff = float((plbl.cpu().numpy() != plbl_o).mean())
+    thr_diff = float(np.abs(thr - st.class_threshold).max())
+    print("argmax differs on %.2e, pseudo labels on %.2e of %d pixels; thresholds by %.2e" % (am_diff, lbl_diff, plbl_o.size, thr_diff))
+    assert am_diff <= 1e-3 and lbl_diff <= 5e-3 and thr_diff <= 2e-3
+    keep = float((plbl_o != 255).mean())
+    assert 0.05 < keep < 0.95, "the calibrated head should leave a mix of kept and ignored pixels (%.3f)" % keep

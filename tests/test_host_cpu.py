@@ -216,6 +216,19 @@ class OracleEngine:
         self.mp, self.am = self.cref.plabel_stage_a(z, self.H, self.W)
         return torch.from_numpy(self.cref.plabel_hist(self.mp, self.am, self.C).view(np.int32))
 
+    def strided_hist(self, interval, rank_offset=None):
+        """the reference's own formulation: tmp = probs[lbls == c].astype(f16); tmp[first::interval]"""
+        from hiast_amd.workflows import ias_math
+        hist = np.zeros((self.C, ias_math.NBINS), np.int32)
+        if self.mp is None:
+            return torch.from_numpy(hist)
+        off = np.zeros(self.C, np.int64) if rank_offset is None else np.asarray(rank_offset, np.int64)
+        for c in range(self.C):
+            tmp = self.mp[self.am == c].astype(np.float16)
+            first = (-int(off[c])) % interval
+            np.add.at(hist[c], tmp[first::interval].view(np.uint16).astype(np.int64), 1)
+        return torch.from_numpy(hist)
+
     def pass2(self, thr):
         if self.mp is None:
             return None, torch.zeros((0, self.C), dtype=torch.int64), torch.zeros(self.C, dtype=torch.int64)

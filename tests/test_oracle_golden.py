@@ -287,3 +287,105 @@ def test_warmup_losses_vs_reference(golden, tag):
     assert np.allclose(bias, g["gd_bias_" + tag], rtol=1e-4, atol=1e-8)
     dmap = warmup_ref.discriminator_input(zt.detach(), (H, W), cs["entropy_in"]).numpy()[:, ::6]
     assert np.allclose(dmap, g["dmap_" + tag], rtol=1e-5, atol=1e-7)
+
+
+# ---------------------------------------------------------------------------------- CT / NT / CBST, Validator TTA
+def _policy_stage_a_torch():
+    """what the reference generator saw: torch-CPU interpolate + softmax of the fixture's low-res logits"""
+    from make_golden import POLICY_SHAPE, policy_inputs
+    F = torch.nn.functional
+    nb, B, C, h, w, H, W = POLICY_SHAPE
+    out = []
+    for z in policy_inputs():
+        pp, lp = F.softmax(F.interpolate(torch.from_numpy(z), size=(H, W), mode="bilinear", align_corners=True), 1).max(1)
+        out.append((pp.numpy(), lp.numpy()))
+    return out
+
+
+@pytest.mark.parametrize("tag", ["ct", "nt", "cbst"])
+def test_constant_policies_bit_exact(golden, tag):
+    """oracle/ias_ref.py's CT / NT / CBST restatement on the reference's own stage-A values reproduces the reference's
+    run(): label maps, statistics, class means and (CBST) the strided-sample quantile thresholds, bit for bit"""
+    from make_golden import POLICY_SHAPE
+    g = golden("policies")
+    nb, B, C, h, w, H, W = POLICY_SHAPE
+    batches = _policy_stage_a_torch()
+    if tag == "ct":
+        thr = 0.9 * np.ones(C)
+    elif tag == "nt":
+        thr = None
+    else:
+        thr = ias_ref.cbst_threshold(batches, C, 0.2, 4)
+        assert np.array_equal(thr.view(np.uint64), g["thr_cbst"].view(np.uint64))
+    st = ias_ref.ConstantPolicyState(C, thr)
+    plbl = np.concatenate([st.step(pp, lp, ["img_%03d.png" % (t * B + b) for b in range(B)])
+                           for t, (pp, lp) in enumerate(batches)])
+    assert np.array_equal(plbl, g["plbl_" + tag])
+    assert np.array_equal(st.statics_class, g["statics_" + tag])
+    assert np.allclose(st.class_mean_probs, g["mean_" + tag], rtol=1e-12)
+    ref_stats = json.loads(str(g["sample_stats_" + tag]))
+    assert [{k: v for k, v in s.items() if k != "file"} for s in ref_stats] == \
+        [{str(k): v for k, v in s.items() if k != "file"} for s in st.sample_stats]
+
+
+def test_histogram_cbst_equals_list_formulation(golden):
+    """the product's histogram quantile (ias_math.cbst_threshold on the strided-sample histogram) == np.quantile on
+    the reference's lists"""
+    from make_golden import POLICY_SHAPE
+    from hiast_amd.workflows import ias_math
+    g = golden("policies")
+    C = POLICY_SHAPE[2]
+    hist = np.zeros((C, ias_math.NBINS), np.int64)
+    for pp, lp in _policy_stage_a_torch():
+        for c in range(C):
+            tmp = pp[lp == c].astype(np.float16)
+            np.add.at(hist[c], tmp[0:len(tmp):4].view(np.uint16).astype(np.int64), 1)
+    # numpy >= 2 evaluates the quantile of a float16 list IN float16 (the fixture was made under numpy 2.2) ...
+    thr = ias_math.cbst_threshold(hist, 0.2, arithmetic="float16")
+    assert np.array_equal(thr.view(np.uint64), g["thr_cbst"].view(np.uint64))
+    # ... the default reproduces the float64 evaluation of the reference's pinned numpy 1.19 on the same sample
+    thr64 = ias_math.cbst_threshold(hist, 0.2)
+    lists = ias_ref.cbst_lists(_policy_stage_a_torch(), C, 4)
+    want = np.array([np.quantile(np.asarray(lists[c], np.float64), 0.8) for c in range(C)])
+    assert np.array_equal(thr64.view(np.uint64), want.view(np.uint64))
+    assert np.abs(thr64 - g["thr_cbst"]).max() <= 2e-3          # the two differ by float16 index / lerp rounding only
+
+
+@pytest.mark.parametrize("flip", [False, True])
+def test_tta_vs_reference(golden, flip):
+    """oracle TTA (orc_tta, HIAST-A arithmetic on low-res head outputs) vs Validator.get_multi_scale_and_flip_logits of
+    the reference on the same head outputs: summed probabilities <= 1e-5, label maps equal outside near-ties"""
+    from make_golden import TTA_SHAPE, TTA_SIZES, tta_inputs
+    g = golden("tta")
+    B, C, H, W = TTA_SHAPE
+    t = tta_inputs()
+    zs = [t[(hs, ws, False)] for hs, ws in TTA_SIZES]
+    zfs = [t[(hs, ws, True)] for hs, ws in TTA_SIZES] if flip else None
+    probs, label = cref.tta(zs, zfs, TTA_SIZES, H, W)
+    tag = "flip" if flip else "noflip"
+    assert np.abs(probs[:, :, ::3, ::5] - g["probsum_" + tag]).max() <= 1e-5
+    assert abs(float(probs.astype(np.float64).sum()) - float(g["probsum_total_" + tag])) <= 1e-6 * B * H * W
+    top2 = np.sort(probs, axis=1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 1e-5
+    assert clear.mean() > 0.999 and np.array_equal(label[clear], g["label_" + tag][clear])
+
+
+def test_validator_run_miou_vs_reference(golden):
+    """Validator.run's bookkeeping incl. the SYNTHIA 16/13-class rescale (validator.py:95-113), values as printed by
+    the reference (4 decimals)"""
+    from make_golden import TTA_SHAPE
+    g = golden("tta")
+    B, C, H, W = TTA_SHAPE
+    pred = np.concatenate([g["label_flip"], g["label_flip"]]).astype(np.int64)
+    lbl = g["run_labels"].astype(np.int64)
+    inter = np.zeros(C, np.int64)
+    union = np.zeros(C, np.int64)
+    for i in range(2):
+        a, b = metrics_ref.intersection_and_union(pred[i * B:(i + 1) * B], lbl[i * B:(i + 1) * B], C)
+        inter += a
+        union += b
+    m16, m13, iou = metrics_ref.miou(inter.astype(np.float64), union.astype(np.float64), synthia=True)
+    assert abs(m16 - g["run_miou_SYNTHIA"][0]) <= 6e-5 and abs(m13 - g["run_miou_SYNTHIA"][1]) <= 6e-5
+    m19, _, _ = metrics_ref.miou(inter.astype(np.float64), union.astype(np.float64))
+    assert abs(m19 - g["run_miou_GTAV"][0]) <= 6e-5
+    assert iou[9] == 0 and iou[14] == 0 and iou[16] == 0
