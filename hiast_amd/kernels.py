@@ -739,9 +739,11 @@ class PackPlan:
             self.wp.append(wp)
             self.wpt.append(wpt)
             host[i] = (w.data_ptr(), wp.data_ptr(), wpt.data_ptr() if adj else 0, N, K_, taps, planes, 2 if adj else 0, 0)
-            for s0 in range(0, N * K_ * taps, self.CHUNK):
+            if N % 64 or K_ % 64 or taps > 9:
+                raise ValueError("PackPlan: channel counts must be multiples of 64 (got %d x %d)" % (N, K_))
+            for tile in range((N // 64) * (K_ // 64)):      # one block per 64 x 64 (n, k) tile, all taps
                 ct.append(i)
-                cs.append(s0)
+                cs.append(tile)
         self.ptrs = [w.data_ptr() for w in weights]
         self.table = torch.from_numpy(host.view(np.uint8).reshape(-1).copy()).to(dev)
         self.chunk_tensor = torch.tensor(ct, dtype=torch.int32, device=dev)

@@ -265,8 +265,9 @@ int hiast_pack_conv_weight(const float* w, int N, int K, int taps, int planes, i
                            hiast_stream_t stream);
 int hiast_split_planes(float* x, void* planes, int64_t M, int C, int inverse, hiast_stream_t stream);
 /* hiast_pack_conv_weight for a list of weights in ONE launch (a trunk's 104 convolutions after every optimiser / EMA
- * update).  table: device array of records (mode = the `transpose` argument above); chunk tables as for K11: one
- * block per 64Ki-element chunk of one weight. */
+ * update).  table: device array of records (mode = the `transpose` argument above; N, K multiples of 64, taps <= 9);
+ * one block per 64 x 64 (n, k) tile of one weight: chunk_tensor[b] = record index, chunk_start[b] = index of the tile
+ * within that weight, row-major over (N/64, K/64). */
 typedef struct { const float* w; void* wp; void* wpt; int32_t N, K, taps, planes, mode, pad; } hiast_pack_rec;
 int hiast_pack_conv_weight_multi(const hiast_pack_rec* table, const int32_t* chunk_tensor, const int64_t* chunk_start,
                                  int n_chunks, hiast_stream_t stream);

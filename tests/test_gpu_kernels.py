@@ -835,6 +835,36 @@ def test_pack_plan_equals_single_packs(K):
             ws[2].mul_(0.5)
 
 
+def _pack_ref(w, PL, transpose):
+    """the packed operand format spelled out with torch: rows x taps x (PL * reduction channels); bf16 hi (and
+    lo = bf16(v - hi)) in slabs of 32 channels [hi32 | lo32] for split planes; the adjoint form swaps the channel
+    roles and flips the taps"""
+    N, Kc, kh, kw = w.shape
+    if transpose:
+        w = w.flip(2, 3).permute(1, 0, 2, 3)
+        N, Kc = Kc, N
+    v = w.permute(0, 2, 3, 1).reshape(N, kh * kw, Kc).float()
+    hi = v.bfloat16()
+    if PL == 1:
+        return hi
+    lo = (v - hi.float()).bfloat16()
+    return torch.stack([hi.view(N, kh * kw, Kc // 32, 32), lo.view(N, kh * kw, Kc // 32, 32)], 3).reshape(N, kh * kw, 2 * Kc)
+
+
+@pytest.mark.parametrize("shape", [(64, 64, 1, 1), (256, 128, 3, 3), (128, 320, 1, 1), (192, 64, 3, 3), (640, 2048, 1, 1),
+                                   (48, 96, 3, 3)])
+def test_pack_conv_weight_layout(K, shape):
+    """tiled (multiples of 64) and elementwise (anything else) packing kernels against the layout definition"""
+    w = dev(synth.normal_f32(1700 + shape[0], shape))
+    for PL in (1, 2):
+        if PL == 2 and (shape[0] % 32 or shape[1] % 32):
+            continue
+        assert torch.equal(K.pack_conv_weight(w, PL), _pack_ref(w, PL, False))
+        assert torch.equal(K.pack_conv_weight(w, PL, transpose=True), _pack_ref(w, PL, True))
+        f, a = K.pack_conv_weight(w, PL, both=True)
+        assert torch.equal(f, _pack_ref(w, PL, False)) and torch.equal(a, _pack_ref(w, PL, True))
+
+
 def test_ema_bit_exact(K):
     shapes = [(7, 5), (70001,), (3, 2, 3, 3), (64, 2048, 1, 1)]
     e = [synth.normal_f32(70 + i, s) for i, s in enumerate(shapes)]
