@@ -706,6 +706,14 @@ static int launch_igemm_t(const void* x, const void* wp, const float* gamma, con
     return 0;
 }
 
+// K9e (xconv.hip): register-resident-weight kernel for the HBM-bound expanding 1x1 shapes
+int hiast_xconv_ok(int64_t M, int K, int N, int planes, int taps, int out_f32, int has_bn, int has_res, int relu,
+                   int has_gate, int gate_mask, int has_stats);
+int hiast_xconv_stats_rows(int64_t M, int N);
+int hiast_xconv_launch(const void* x, const void* wp, const float* gamma, const float* beta, const float* mean,
+                       const float* var, float eps, const void* res, int relu, void* y, int64_t M, int K, int N,
+                       float* stats, const void* res_gate, hipStream_t st);
+
 // shared launcher (also used by aspp2.hip for the ASPP tap GEMM)
 int hiast_igemm_launch(const void* x, const void* wp, const float* gamma, const float* beta, const float* mean,
                        const float* var, float eps, const void* res, int relu, void* y, int64_t M, int K, int N,
@@ -731,6 +739,9 @@ int hiast_igemm_launch(const void* x, const void* wp, const float* gamma, const 
     }
     // buffer-descriptor addressing: byte offsets and the out-of-range marker need 31 bits
     if (in_pix * planes * K * 2 >= (1ull << 31) || (size_t)N * taps * planes * K * 2 >= (1ull << 31)) return HIAST_E_RANGE;
+    if (hiast_xconv_ok(M, K, N, planes, taps, out_f32, mean != nullptr, res != nullptr, relu, res_gate != nullptr, gate_mask,
+                       stats != nullptr))
+        return hiast_xconv_launch(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, stats, res_gate, st);
     if (planes == 2) {
         if (out_f32) return launch_igemm_t<2, true>(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, stats, res_gate, gate_mask, st);
         return launch_igemm_t<2, false>(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, stats, res_gate, gate_mask, st);
@@ -749,6 +760,13 @@ extern "C" int hiast_igemm_bn_act(const void* x, const void* wp, const float* ga
     const int Ho = taps == 1 ? H : (H - 1) / stride + 1, Wo = taps == 1 ? W : (W - 1) / stride + 1;
     return hiast_igemm_launch(x, wp, gamma, beta, mean, var, eps, res, relu, y, (int64_t)B * Ho * Wo, Cin, Cout, taps, H,
                               W, stride, dil, planes, out_f32, (hipStream_t)stream, stats, res_gate, gate_mask);
+}
+
+extern "C" int hiast_igemm_stats_rows(int64_t M, int Cin, int Cout, int taps, int planes)
+{
+    if (M <= 0 || Cin <= 0 || Cout <= 0) return 0;
+    if (hiast_xconv_ok(M, Cin, Cout, planes, taps, 0, 0, 0, 0, 0, 0, 1)) return hiast_xconv_stats_rows(M, Cout);
+    return (int)((M + hiast::IG_BM - 1) / hiast::IG_BM);
 }
 
 extern "C" int hiast_pack_conv_weight(const float* w, int N, int K, int taps, int planes, int transpose, void* wp,

@@ -769,7 +769,7 @@ def igemm_bn_act(x, wp, planes, bn, res, relu, stride=1, dil=1, out_f32=False, w
     """x: bf16 [B,H,W,planes*Cin] (planes = 2 split planes | 1 plain bf16); wp from pack_conv_weight (same planes);
     bn: BatchNorm2d in eval mode or None (plain GEMM); res: like the output or None
     -> y bf16 [B,Ho,Wo,planes*Cout], or fp32 [B,Ho,Wo,Cout] if out_f32;
-    want_stats (planes = 1): -> (y, partial fp32 [ceil(M/256), Cout, 2]) per-block Σy, Σy² for a following BatchNorm"""
+    want_stats (planes = 1): -> (y, partial fp32 [rows, Cout, 2]) per-block Σy, Σy² for a following BatchNorm"""
     _req(x, torch.bfloat16, 4, "x")
     _req(wp, torch.bfloat16, 3, "wp")
     PL = int(planes)
@@ -808,7 +808,8 @@ def igemm_bn_act(x, wp, planes, bn, res, relu, stride=1, dil=1, out_f32=False, w
     partial = None
     if want_stats:
         assert PL == 1 and not out_f32
-        partial = torch.empty(((B * Ho * Wo + 255) // 256, N, 2), dtype=torch.float32, device=x.device)
+        rows = _lib.load().hiast_igemm_stats_rows(B * Ho * Wo, Cin, N, taps, PL)     # one row per block of the kernel
+        partial = torch.empty((rows, N, 2), dtype=torch.float32, device=x.device)
     check(_lib.load().hiast_igemm_bn_act(_ptr(x), _ptr(wp), g, b, mu, var, eps, _ptr(res), int(bool(relu)), _ptr(y),
                                          B, H, W, Cin, N, taps, int(stride), int(dil), PL, int(bool(out_f32)),
                                          _ptr(partial), _ptr(res_gate), gate_mask, _stream()), "hiast_igemm_bn_act")

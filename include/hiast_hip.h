@@ -261,6 +261,9 @@ int hiast_igemm_bn_act(const void* x, const void* wp, const float* gamma, const 
                        const float* var, float eps, const void* res, int relu, void* y, int B, int H, int W, int Cin,
                        int Cout, int taps, int stride, int dil, int planes, int out_f32, float* stats,
                        const void* res_gate, int gate_mask, hiast_stream_t stream);
+/* host: number of partial-sum rows hiast_igemm_bn_act writes into `stats` [rows][Cout][2] for M = B*Ho*Wo output pixels
+ * (one row per block of the kernel chosen for the shape) */
+int hiast_igemm_stats_rows(int64_t M, int Cin, int Cout, int taps, int planes);
 int hiast_pack_conv_weight(const float* w, int N, int K, int taps, int planes, int transpose, void* wp, void* wpt,
                            hiast_stream_t stream);
 int hiast_split_planes(float* x, void* planes, int64_t M, int C, int inverse, hiast_stream_t stream);

@@ -516,6 +516,51 @@ def test_igemm_gated_residual(K, case, mask):
         K.igemm_bn_act(xp, wp, 1, None, resp, False, 1, dil, want_stats=True)    # statistics + residual: not a variant
 
 
+@pytest.mark.parametrize("M_hw", [(1, 64, 128), (2, 50, 77), (1, 64, 65)])
+def test_xconv_expanding_1x1(K, M_hw, monkeypatch):
+    """K9e (xconv.hip): the register-resident-weight kernel that takes the 256 -> 1024 1x1 launches of layer3 over from
+    the tile kernel — every epilogue variant against float64 on the bf16 operands AND against the tile kernel
+    (HIAST_XCONV=0) on the same inputs; ragged M (tail panel, rows beyond M), statistics of the stored values"""
+    B, H, W = M_hw
+    Cin, Cout = 256, 1024
+    x = _bf16r(synth.normal_f32(340, (B, H, W, Cin)))
+    w = synth.normal_f32(341, (Cout, Cin, 1, 1), (2.0 / Cin) ** 0.5)
+    res = _bf16r(synth.normal_f32(342, (B, H, W, Cout)))
+    gate = synth.normal_f32(343, (B, H, W, Cout))
+    bits = dev(np.packbits((gate > 0).reshape(B * H * W, Cout // 8, 8), axis=-1, bitorder="little").reshape(B * H * W, Cout // 8))
+    bn, bnref = _mk_bn(344, Cout)
+    xp, resp = dev(x).bfloat16(), dev(res).bfloat16()
+    wp = K.pack_conv_weight(dev(w), 1)
+    assert K._lib.load().hiast_igemm_stats_rows(B * H * W, Cin, Cout, 1, 1) != (B * H * W + 255) // 256 or B * H * W < 4096
+    cases = [("plain", dict(bn=None, res=None, relu=False), None),
+             ("bn_relu", dict(bn=bn, res=None, relu=True), bnref),
+             ("bn_res_relu", dict(bn=bn, res=resp, relu=True), bnref),
+             ("bn_res", dict(bn=bn, res=resp, relu=False), bnref),
+             ("res", dict(bn=None, res=resp, relu=False), None),
+             ("gated", dict(bn=None, res=resp, relu=False, res_gate=bits), None)]
+    for name, kw, bref in cases:
+        args = (xp, wp, 1, kw["bn"], kw["res"], kw["relu"], 1, 1)
+        extra = {k: v for k, v in kw.items() if k == "res_gate"}
+        y = K.igemm_bn_act(*args, **extra)
+        monkeypatch.setenv("HIAST_XCONV", "0")
+        y_tile = K.igemm_bn_act(*args, **extra)
+        monkeypatch.delenv("HIAST_XCONV")
+        rr = None if kw["res"] is None else (res * (gate > 0) if name == "gated" else res)
+        want = _igemm_ref(x, _bf16r(w), bref, rr, kw["relu"], 1, 1, 1)
+        got = y.float().cpu().numpy()
+        assert (np.abs(got - want) <= 2.0 ** -8 * np.abs(want) + 3e-5 * np.abs(want).max()).all(), name
+        # the two kernels accumulate k in different orders: equal up to one bf16 rounding of a ~1e-6 difference
+        d = (y.float() - y_tile.float()).abs()
+        assert float((d > 2.0 ** -7 * y_tile.float().abs() + 1e-5).float().mean()) == 0.0, name
+        assert float((d > 0).float().mean()) < 0.02, name
+    y, part = K.igemm_bn_act(xp, wp, 1, None, None, False, 1, 1, want_stats=True)
+    yf = y.float().view(-1, Cout).double()
+    sums = part.double().sum(0)
+    assert torch.allclose(sums[:, 0], yf.sum(0), rtol=1e-5, atol=1e-3) and torch.allclose(sums[:, 1], (yf * yf).sum(0), rtol=1e-5)
+    s64 = K.bn_nhwc_stats_from_partial(part)
+    assert torch.allclose(s64[:, 0], yf.sum(0), rtol=1e-5, atol=1e-3)
+
+
 @pytest.mark.parametrize("shape", [(2, 64, 9, 17), (3, 256, 16, 24), (1, 2048, 8, 12), (2, 1024, 5, 7)])
 @pytest.mark.parametrize("res,relu", [(False, True), (True, True), (False, False)])
 def test_bn_nhwc_matches_fp64(K, shape, res, relu):

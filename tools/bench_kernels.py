@@ -104,6 +104,29 @@ def main():
             med, best = timeit(lambda: torch.nn.functional.conv2d(xn, wb, None, 1, dl if taps == 9 else 0, dl), n=20, warm=5)
             row += " miopen bf16 conv only %7.3f ms" % med
             print(row, flush=True)
+    if "xconv" in which:
+        # the HBM-bound 1x1 launches of layer3 (K9e xconv.hip vs the tile kernel, HIAST_XCONV=0): algorithmic bytes / time
+        Bn, Hh, Ww = B, 64, 128
+        M = Bn * Hh * Ww
+        x = torch.randn(Bn, Hh, Ww, 256, device=dev).bfloat16()
+        wp = K.pack_conv_weight(torch.randn(1024, 256, 1, 1, device=dev) * 0.05, 1)
+        res = torch.randn(Bn, Hh, Ww, 1024, device=dev).bfloat16()
+        bits = torch.randint(0, 256, (M, 128), device=dev, dtype=torch.uint8)
+        bn = torch.nn.BatchNorm2d(1024).to(dev).eval()
+        mb = lambda *t: sum(v.numel() * v.element_size() for v in t) / 1e6
+        out_mb = M * 1024 * 2 / 1e6
+        variants = [("conv3 student (stats)", lambda: K.igemm_bn_act(x, wp, 1, None, None, False, want_stats=True), mb(x) + out_mb),
+                    ("conv3+res+relu teacher", lambda: K.igemm_bn_act(x, wp, 1, bn, res, True), mb(x, res) + out_mb),
+                    ("conv1 dgrad gated res", lambda: K.igemm_bn_act(x, wp, 1, None, res, False, res_gate=bits), mb(x, res, bits) + out_mb),
+                    ("plain", lambda: K.igemm_bn_act(x, wp, 1, None, None, False), mb(x) + out_mb)]
+        for name, fn, mbytes in variants:
+            row = "xconv %-24s %6.0f MB |" % (name, mbytes)
+            for flag in ("1", "0"):
+                os.environ["HIAST_XCONV"] = flag
+                med, best = timeit(fn, n=30, warm=5)
+                row += " %s %7.3f ms (best %6.3f) %5.2f TB/s |" % ("xconv" if flag == "1" else "tile ", med, best, mbytes / med / 1e3)
+            os.environ.pop("HIAST_XCONV", None)
+            print(row, flush=True)
     if "wgrad" in which:
         Bn, Hh, Ww = B, 64, 128
         for name, Cin_, Cout_, k, dl in (("l3.conv1", 1024, 256, 1, 1), ("l3.conv2", 256, 256, 3, 2), ("l3.conv3", 256, 1024, 1, 1),
