@@ -48,7 +48,8 @@ def parse():
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' only for "
                    "functional tests of the N>1 path on a single GPU")
     p.add_argument("--same-device", action="store_true", help="testing: every rank uses cuda:0")
-    p.add_argument("--cpu-threads", type=int, default=32)
+    p.add_argument("--cpu-threads", type=int, default=256, help="upper bound; the usable CPUs of the box decide")
+    p.add_argument("--cpu-reps", type=int, default=3)
     p.add_argument("--trainer", default="ConsistencySelfTrainingTrainer",
                    choices=["ConsistencySelfTrainingTrainer", "SelfTrainingTrainer"])
     return p.parse_args()
@@ -348,49 +349,101 @@ class HotPath:
         return losses, plbl
 
 
-def cpu_baseline(cfg, size, threads):
-    """The reference's CPU path, restated (oracle/): eval forward + list/np.quantile IAS post-processing +
-    one training step (teacher fwd, student fwd, 4-term loss, backward, Adam) on ONE image."""
+def _cpu_info():
+    """CPU model / sockets / physical cores of the host (lscpu), as BASELINE.md §3 asks"""
+    import subprocess
+    info = {"model": None, "sockets": None, "cores_per_socket": None, "threads_per_core": None, "logical": os.cpu_count()}
+    try:
+        out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        for line in out.splitlines():
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "Model name":
+                info["model"] = v
+            elif k == "Socket(s)":
+                info["sockets"] = int(v)
+            elif k == "Core(s) per socket":
+                info["cores_per_socket"] = int(v)
+            elif k == "Thread(s) per core":
+                info["threads_per_core"] = int(v)
+    except Exception:
+        pass
+    if info["sockets"] and info["cores_per_socket"]:
+        info["physical_cores"] = info["sockets"] * info["cores_per_socket"]
+    try:
+        info["usable"] = len(os.sched_getaffinity(0))       # the box's CPU share (cgroup / affinity)
+    except Exception:
+        info["usable"] = os.cpu_count()
+    return info
+
+
+def cpu_baseline(cfg, size, threads, batch=2, reps=3):
+    """The reference's CPU path, restated (oracle/), timed as BASELINE.md §3 prescribes: batch 2, one warm-up + `reps`
+    timed repetitions (median) of (i) eval forward + the list / np.quantile IAS post-processing incl. the per-row
+    threshold map (np.apply_along_axis) and (ii) one self-training step (teacher forward, student forward, 4-term loss,
+    backward, Adam); (iii) the single-threaded host post-processing alone.  Per-image times, scaled to 1024x512 by
+    the pixel ratio when a smaller sample size is asked for."""
     from oracle import deeplab_ref, ias_ref, losses_ref
     from hiast_amd.utils.registry.registries import MODEL
     h, w = size
-    cores = max(1, min(threads, os.cpu_count()))
+    info = _cpu_info()
+    cores = max(1, min(threads, info["usable"] or 1))
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     sd = {k: v.detach().clone() for k, v in MODEL[cfg.model.type](cfg).state_dict().items()}
-    x = torch.randn(1, 3, h, w)
-    t0 = time.time()
-    with torch.no_grad():
-        logits, _, _ = deeplab_ref.segmentor_logits(x, sd)
-        pp, lp = torch.softmax(logits, 1).max(1)
-    t_post0 = time.time()
-    st = ias_ref.IASState(C, 0.5, 0.9, 8.0)
-    plbl = st.step(pp.numpy(), lp.numpy(), ["a.png"])
-    # reference's per-pixel threshold map (np.apply_along_axis over rows, pseudo_label_generator.py:74)
-    np.apply_along_axis(lambda r: [st.class_threshold[e] for e in r], 1, lp.numpy()[0])
-    t_post = time.time() - t_post0          # the reference's host post-processing: single-threaded Python / numpy
-    t_gen = time.time() - t0
-    t0 = time.time()
-    params = {k: v.requires_grad_(v.dtype.is_floating_point and ".bn" not in k and "downsample.1" not in k)
-              for k, v in sd.items()}
-    with torch.no_grad():
-        zt = deeplab_ref.segmentor_logits(x, sd)[1]
-    _, zs, _ = deeplab_ref.segmentor_logits(x, params, train=True)
-    L = losses_ref.st_losses(zs, zt, torch.from_numpy(plbl.astype(np.int64)), (h, w), "ignored",
-                             dtype=torch.float32)
-    sum(v for v in L.values() if torch.isfinite(v)).backward()
-    opt = torch.optim.Adam([p for p in params.values() if p.requires_grad and p.grad is not None], lr=3e-6,
-                           weight_decay=0.0005)
-    opt.step()
-    t_train = time.time() - t0
-    scale = (H * W) / float(h * w)
-    total = (t_gen + t_train) * scale
+    x = torch.randn(batch, 3, h, w)
+    paths = ["img_%d.png" % i for i in range(batch)]
+
+    def generate():
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            logits, _, _ = deeplab_ref.segmentor_logits(x, sd)
+            pp, lp = torch.softmax(logits, 1).max(1)
+        t1 = time.perf_counter()
+        st = ias_ref.IASState(C, 0.5, 0.9, 8.0)
+        plbl = st.step(pp.numpy(), lp.numpy(), paths)
+        for b in range(batch):   # the reference's per-pixel threshold map (np.apply_along_axis over rows, :74)
+            np.apply_along_axis(lambda r: [st.class_threshold[e] for e in r], 1, lp.numpy()[b])
+        t2 = time.perf_counter()
+        return plbl, t1 - t0, t2 - t1
+
+    def train(plbl):
+        t0 = time.perf_counter()
+        params = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point and ".bn" not in k and "downsample.1" not in k)
+                  for k, v in sd.items()}
+        with torch.no_grad():
+            zt = deeplab_ref.segmentor_logits(x, sd)[1]
+        _, zs, _ = deeplab_ref.segmentor_logits(x, params, train=True)
+        L = losses_ref.st_losses(zs, zt, torch.from_numpy(plbl.astype(np.int64)), (h, w), "ignored", dtype=torch.float32)
+        sum(v for v in L.values() if torch.isfinite(v)).backward()
+        opt = torch.optim.Adam([p for p in params.values() if p.requires_grad and p.grad is not None], lr=3e-6,
+                               weight_decay=0.0005)
+        opt.step()
+        return time.perf_counter() - t0
+
+    plbl, _, _ = generate()            # warm-up (first-touch allocations, thread pools)
+    train(plbl)
+    gen, post, trn = [], [], []
+    for _ in range(reps):
+        plbl, tf, tp = generate()
+        gen.append(tf)
+        post.append(tp)
+        trn.append(train(plbl))
+    scale = (H * W) / float(h * w) / batch          # -> seconds per 1024x512 image
+    med = lambda v: float(np.median(v))
+    fwd, pst, tr = med(gen) * scale, med(post) * scale, med(trn) * scale
+    total = fwd + pst + tr
     return {"value": 1.0 / total, "unit": "images/s", "cores": cores, "kind": "port",
-            "detail_s_per_image": {"eval_forward": (t_gen - t_post) * scale, "ias_post_processing_1_thread": t_post * scale,
-                                   "train_step": t_train * scale},
-            "sample": "1 image %dx%d (scaled x%.1f to 1024x512): eval fwd + IAS list/np.quantile post-processing "
-                      "%.1fs, teacher fwd + student fwd/bwd + 4-term loss + Adam %.1fs; torch %d threads"
-                      % (w, h, scale, t_gen, t_train, cores)}
+            "cpu": info,
+            "detail_s_per_image": {"eval_forward": fwd, "ias_post_processing_1_thread": pst, "train_step": tr},
+            "repetitions": {"warmup": 1, "timed": reps, "statistic": "median", "batch": batch,
+                            "eval_forward_s": gen, "ias_post_s": post, "train_step_s": trn},
+            "sample": "batch of %d images %dx%d (per-image times x%.2f to 1024x512), 1 warm-up + %d timed repetitions, "
+                      "median: eval forward %.2f s + IAS list/np.quantile/apply_along_axis post-processing %.2f s "
+                      "(single-threaded, as in the reference) + HIAST training step %.2f s per image; torch %d threads "
+                      "on %s (%s sockets x %s cores, %s usable logical CPUs)"
+                      % (batch, w, h, (H * W) / float(h * w), reps, fwd, pst, tr, cores, info["model"], info["sockets"],
+                         info["cores_per_socket"], info["usable"])}
 
 
 def spawn_ranks(n):
@@ -525,7 +578,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             try:
                 with contextlib.redirect_stdout(sys.stderr):
-                    out["cpu_baseline"] = cpu_baseline(cfg, tuple(args.cpu_size), args.cpu_threads)
+                    out["cpu_baseline"] = cpu_baseline(cfg, tuple(args.cpu_size), args.cpu_threads, reps=args.cpu_reps)
             except Exception as e:      # the baseline must never take the measurement down
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out))

@@ -34,11 +34,32 @@ __device__ __forceinline__ void wg_dma16(__amdgpu_buffer_rsrc_t rs, unsigned cha
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (wg_lds_ptr)lds, 16, voff, soff, 0, 0);
 }
 
-// transposing LDS read (kept out of the kernel template, like the DMA builtin)
-__device__ __forceinline__ wg_s16x4 wg_tr_read(const unsigned char* p)
+// transposing LDS read, as inline asm on the LDS byte address.  Through the builtin the compiler sees an LDS load and
+// orders it behind ALL pending LDS-DMA: it put an s_waitcnt vmcnt(0) in front of the fragment reads that follow each
+// pair of DMA pieces — four full HBM round trips per 64-pixel step during which the wave did nothing (the prefetch of
+// step t+1 was waited for inside step t).  The asm reads are invisible to that rule; wg_wait ties their results to an
+// explicit lgkmcnt wait.
+__device__ __forceinline__ wg_s16x4 wg_tr_read(unsigned addr)
 {
-    typedef wg_s16x4 __attribute__((address_space(3))) * lds_p;
-    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)p);
+    wg_s16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+struct WgFrags {
+    wg_s16x4 a[4][2], b[2][2];          // two transposed halves per fragment
+};
+__device__ __forceinline__ void wg_wait(WgFrags& f)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(f.a[0][0]), "+v"(f.a[0][1]), "+v"(f.a[1][0]), "+v"(f.a[1][1]), "+v"(f.a[2][0]), "+v"(f.a[2][1]),
+                   "+v"(f.a[3][0]), "+v"(f.a[3][1]), "+v"(f.b[0][0]), "+v"(f.b[0][1]), "+v"(f.b[1][0]), "+v"(f.b[1][1]));
+}
+__device__ __forceinline__ wg_bf16x8 wg_join(const wg_s16x4& v0, const wg_s16x4& v1)
+{
+    wg_s16x8 v;
+    v[0] = v0[0]; v[1] = v0[1]; v[2] = v0[2]; v[3] = v0[3];
+    v[4] = v1[0]; v[5] = v1[1]; v[6] = v1[2]; v[7] = v1[3];
+    return __builtin_bit_cast(wg_bf16x8, v);
 }
 
 // [rows][128 x 16-bit] sub-tile with 256-byte rows: 16-byte chunk ch of row r lives at chunk ch ^ swz(r)
@@ -132,17 +153,12 @@ __global__ __launch_bounds__(512) void wgrad_tn_kernel(const unsigned short* __r
     // transposed fragment: 32 columns starting at c0 of a sub-tile, reduction rows kb .. kb+7 for this lane half
     const int grp4 = lane >> 4, t16 = lane & 15;
     const int fq = t16 >> 2, fp = t16 & 3;
-    auto frag = [&](const unsigned char* subtile, int c0, int kk) -> wg_bf16x8 {
+    const unsigned lds0 = (unsigned)(size_t)smem;                // LDS byte address of the stage buffers
+    auto frag = [&](unsigned subtile, int c0, int kk, wg_s16x4& v0, wg_s16x4& v1) {
         const int kb = kk * 16 + 8 * (grp4 >> 1);
         const int ch = ((c0 + 16 * (grp4 & 1)) >> 3) + (fp >> 1);
-        const int o0 = wg_off(kb + fq, ch) + 8 * (fp & 1);
-        const int o1 = wg_off(kb + 4 + fq, ch) + 8 * (fp & 1);
-        const wg_s16x4 v0 = wg_tr_read(subtile + o0);
-        const wg_s16x4 v1 = wg_tr_read(subtile + o1);
-        wg_s16x8 v;
-        v[0] = v0[0]; v[1] = v0[1]; v[2] = v0[2]; v[3] = v0[3];
-        v[4] = v1[0]; v[5] = v1[1]; v[6] = v1[2]; v[7] = v1[3];
-        return __builtin_bit_cast(wg_bf16x8, v);
+        v0 = wg_tr_read(subtile + (unsigned)(wg_off(kb + fq, ch) + 8 * (fp & 1)));
+        v1 = wg_tr_read(subtile + (unsigned)(wg_off(kb + 4 + fq, ch) + 8 * (fp & 1)));
     };
 
     if (nk > 0) {
@@ -154,25 +170,38 @@ __global__ __launch_bounds__(512) void wgrad_tn_kernel(const unsigned short* __r
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const bool more = kt + 1 < nk;
-        const unsigned char* st = smem + buf * WG_STAGE;
-        const unsigned char* ta = st + wm * WG_SUB;                       // dY sub-tile of this wave's 128 n rows
-        const unsigned char* tb = st + 2 * WG_SUB + (wn >> 1) * WG_SUB;   // X sub-tile holding this wave's 64 k cols
+        const unsigned st = lds0 + buf * WG_STAGE;
+        const unsigned ta = st + wm * WG_SUB;                             // dY sub-tile of this wave's 128 n rows
+        const unsigned tb = st + 2 * WG_SUB + (wn >> 1) * WG_SUB;         // X sub-tile holding this wave's 64 k cols
+        auto read_all = [&](WgFrags& f, int kk) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) frag(ta, a * 32, kk, f.a[a][0], f.a[a][1]);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) frag(tb, (wn & 1) * 64 + b * 32, kk, f.b[b][0], f.b[b][1]);
+        };
+        // fragments of sub-step kk + 1 are requested before the MFMAs of sub-step kk
+        WgFrags fr[2];
+        read_all(fr[0], 0);
+        wg_wait(fr[0]);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            wg_bf16x8 fa[4], fb[2];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) fa[a] = frag(ta, a * 32, kk);
-#pragma unroll
-            for (int b = 0; b < 2; ++b) fb[b] = frag(tb, (wn & 1) * 64 + b * 32, kk);
+            WgFrags& cur = fr[kk & 1];
+            if (kk + 1 < 4) read_all(fr[(kk + 1) & 1], kk + 1);
             if (more) {
                 piece(kt + 1, buf ^ 1, 2 * kk);
                 piece(kt + 1, buf ^ 1, 2 * kk + 1);
             }
+            wg_bf16x8 fa[4], fb[2];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) fa[a] = wg_join(cur.a[a][0], cur.a[a][1]);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) fb[b] = wg_join(cur.b[b][0], cur.b[b][1]);
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+            if (kk + 1 < 4) wg_wait(fr[(kk + 1) & 1]);
         }
     }
 
@@ -191,27 +220,43 @@ __global__ __launch_bounds__(512) void wgrad_tn_kernel(const unsigned short* __r
         }
 }
 
-// dW[n][k][tap] (torch [N][K][kh][kw]) = Σ_s P[s][n][tap][k], ascending s; thread = (n, tap, k): the partials are read
-// as they lie (k fastest, fully coalesced), only the small result is written with the tap stride
+// dW[n][k][tap] (torch [N][K][kh][kw]) = Σ_s P[s][n][tap][k], ascending s (fixed order: bitwise reproducible).
+// thread = (n, tap, 4 consecutive k): the partials are read as they lie — 16 bytes per lane, eight splits in flight
+// (the first form, one float per thread and four loads in flight, streamed the 67 MB of a layer3 1x1 at 1.8 TB/s:
+// 38 us x 81 launches per training step) — only the small result is written with the tap stride.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ P, float* __restrict__ dw, int N,
                                                            int K, int taps, int nsplit)
 {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long idx4 = (long long)blockIdx.x * 256 + threadIdx.x;       // index of a float4 along [n][tap][k]
     const size_t per = (size_t)N * taps * K;
-    if (idx >= (long long)per) return;
+    if (idx4 * 4 >= (long long)per) return;
+    const long long idx = idx4 * 4;
     const int k = (int)(idx % K);
     const long long nt = idx / K;
     const int t = (int)(nt % taps), n = (int)(nt / taps);
-    const float* p = P + idx;
-    float acc = 0.f;
+    const float4* p = reinterpret_cast<const float4*>(P + idx);
+    const size_t per4 = per / 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     int s = 0;
-    for (; s + 4 <= nsplit; s += 4) {           // four loads in flight, the additions keep their order
-        const float v0 = p[(size_t)s * per], v1 = p[(size_t)(s + 1) * per], v2 = p[(size_t)(s + 2) * per],
-                    v3 = p[(size_t)(s + 3) * per];
-        acc = (((acc + v0) + v1) + v2) + v3;
+    for (; s + 8 <= nsplit; s += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(s + u) * per4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {           // the additions keep their order
+            acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
+        }
     }
-    for (; s < nsplit; ++s) acc += p[(size_t)s * per];
-    dw[((size_t)n * K + k) * taps + t] = acc;
+    for (; s < nsplit; ++s) {
+        const float4 v = p[(size_t)s * per4];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    float* d = dw + ((size_t)n * K + k) * taps + t;
+    if (taps == 1) {
+        *reinterpret_cast<float4*>(d) = acc;
+    } else {
+        d[0] = acc.x; d[taps] = acc.y; d[2 * taps] = acc.z; d[3 * taps] = acc.w;
+    }
 }
 
 static int wgrad_nsplit(long long M, int tiles, int taps)
@@ -263,7 +308,7 @@ extern "C" int hiast_conv_wgrad_nhwc(const void* dy, const void* x, float* dw, i
         hipLaunchKernelGGL(hiast::wgrad_tn_kernel<9>, grid, dim3(512), 0, st, (const unsigned short*)dy,
                            (const unsigned short*)x, (float*)workspace, (int)M, Cout, Cin, geo, mps);
     HIAST_CHECK_LAUNCH();
-    const long long total = (long long)Cout * Cin * taps;
+    const long long total = (long long)Cout * Cin * taps / 4;           // float4 per thread (Cin % 256 == 0)
     hipLaunchKernelGGL(hiast::wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                        (const float*)workspace, dw, Cout, Cin, taps, nsplit);
     HIAST_CHECK_LAUNCH();
