@@ -70,6 +70,7 @@ SIGNATURES = {
     "hiast_split_planes": (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
     "hiast_ema_update": (c_int, [c_vp, c_vp, c_vp, c_int, c_f32, c_f32, c_vp]),
     "hiast_normalize_u8": (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_vp, c_vp]),
+    "hiast_copy_paste_u8": (c_int, [c_vp] * 6 + [c_int, c_i64, c_vp]),
     "hiast_multi_copy": (c_int, [c_vp, c_int, c_vp]),
     "hiast_adam_step": (c_int, [c_vp, c_vp, c_vp, c_int, ctypes.c_double, ctypes.c_double, c_f32, c_f32, c_vp]),
     "hiast_confusion_hist": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp]),

@@ -14,6 +14,7 @@
 //   bwd_apply  : dx = gamma*invstd*(g - Σg/n - xhat*Σ(g*xhat)/n);  dres = g
 // Between stats and apply the caller may all-reduce `part` sums across ranks (SyncBN).
 #include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
 
 #include "common.h"
 
@@ -67,6 +68,32 @@ template <> struct Vec<__hip_bfloat16> {
     {
         *reinterpret_cast<unsigned short*>(p) = down(v);
     }
+};
+
+// fp16 activations (dtype 2): the reference's apex O1 arithmetic (half-precision convolutions; BatchNorm itself in fp32)
+template <> struct Vec<__half> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void load(const __half* p, float (&v)[8])
+    {
+        const uint4 r = *reinterpret_cast<const uint4*>(p);
+        const unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __half2float(__ushort_as_half((unsigned short)(w[i] & 0xFFFFu)));
+            v[2 * i + 1] = __half2float(__ushort_as_half((unsigned short)(w[i] >> 16)));
+        }
+    }
+    static __device__ __forceinline__ void store(__half* p, const float (&v)[8])
+    {
+        unsigned w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            w[i] = (unsigned)__half_as_ushort(__float2half_rn(v[2 * i])) |
+                   ((unsigned)__half_as_ushort(__float2half_rn(v[2 * i + 1])) << 16);
+        *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    static __device__ __forceinline__ float ld1(const __half* p) { return __half2float(*p); }
+    static __device__ __forceinline__ void st1(__half* p, float v) { *p = __float2half_rn(v); }
 };
 
 __device__ __forceinline__ double block_sum(double v, double* s_red)
@@ -293,7 +320,7 @@ static int bn_check(const void* x, int B, int C, long long HW, int dtype)
 {
     if (!x) return HIAST_E_ARG;
     if (B <= 0 || C <= 0 || HW <= 0) return HIAST_E_ARG;
-    if (B > 65535 || C > 65535 || (dtype != 0 && dtype != 1)) return HIAST_E_RANGE;
+    if (B > 65535 || C > 65535 || (dtype < 0 || dtype > 2)) return HIAST_E_RANGE;
     return 0;
 }
 
@@ -310,7 +337,8 @@ extern "C" int hiast_bn_stats(const void* x, int B, int C, int64_t HW, int dtype
     const bool v = hiast::vec_ok(x, nullptr, nullptr, nullptr, HW, dtype ? 2 : 4);
 #define L(T, V) hipLaunchKernelGGL((hiast::bn_stats_kernel<T, V>), grid, dim3(256), 0, st, (const T*)x, (long long)HW, C, part)
     if (dtype == 0) { if (v) L(float, true); else L(float, false); }
-    else { if (v) L(__hip_bfloat16, true); else L(__hip_bfloat16, false); }
+    else if (dtype == 1) { if (v) L(__hip_bfloat16, true); else L(__hip_bfloat16, false); }
+    else { if (v) L(__half, true); else L(__half, false); }
 #undef L
     HIAST_CHECK_LAUNCH();
     return 0;
@@ -349,9 +377,12 @@ extern "C" int hiast_bn_act_apply(const void* x, const void* res, void* y, const
     if (dtype == 0) {
         if (train) { if (v) A(float, true, 1); else A(float, false, 1); }
         else { if (v) A(float, true, 0); else A(float, false, 0); }
-    } else {
+    } else if (dtype == 1) {
         if (train) { if (v) A(__hip_bfloat16, true, 1); else A(__hip_bfloat16, false, 1); }
         else { if (v) A(__hip_bfloat16, true, 0); else A(__hip_bfloat16, false, 0); }
+    } else {
+        if (train) { if (v) A(__half, true, 1); else A(__half, false, 1); }
+        else { if (v) A(__half, true, 0); else A(__half, false, 0); }
     }
 #undef A
     HIAST_CHECK_LAUNCH();
@@ -374,9 +405,12 @@ extern "C" int hiast_bn_act_bwd_stats(const void* dy, const void* y, const void*
     if (dtype == 0) {
         if (v) { if (relu) L(float, true, true); else L(float, true, false); }
         else { if (relu) L(float, false, true); else L(float, false, false); }
-    } else {
+    } else if (dtype == 1) {
         if (v) { if (relu) L(__hip_bfloat16, true, true); else L(__hip_bfloat16, true, false); }
         else { if (relu) L(__hip_bfloat16, false, true); else L(__hip_bfloat16, false, false); }
+    } else {
+        if (v) { if (relu) L(__half, true, true); else L(__half, true, false); }
+        else { if (relu) L(__half, false, true); else L(__half, false, false); }
     }
 #undef L
     HIAST_CHECK_LAUNCH();
@@ -403,7 +437,8 @@ extern "C" int hiast_bn_act_bwd_apply(const void* dy, const void* y, const void*
     if (relu) { if (dres) L(T, V, true, true); else L(T, V, true, false); } \
     else { if (dres) L(T, V, false, true); else L(T, V, false, false); }
     if (dtype == 0) { if (v) { LL(float, true) } else { LL(float, false) } }
-    else { if (v) { LL(__hip_bfloat16, true) } else { LL(__hip_bfloat16, false) } }
+    else if (dtype == 1) { if (v) { LL(__hip_bfloat16, true) } else { LL(__hip_bfloat16, false) } }
+    else { if (v) { LL(__half, true) } else { LL(__half, false) } }
 #undef LL
 #undef L
     HIAST_CHECK_LAUNCH();

@@ -18,4 +18,5 @@ class GTAVDataset(BaseDataset):
         return utils.preprocess_label(np.array(Image.open(path), dtype=np.uint8), _ID_MAP)
 
     def build_aug_fun(self, aug_type):
-        return common_aug(aug_type)
+        """gtav_dataset.py:18-31"""
+        return common_aug(self, aug_type, ms=(341, 950), dacs=(720, 1280), fda_target=True)

@@ -25,6 +25,5 @@ class OxfordDataset(BaseDataset):
         return utils.preprocess_label(lbl, _ID_MAP)
 
     def build_aug_fun(self, aug_type):
-        if aug_type == "OMS":
-            return augmentations.flip_crop_resize(768, 1024, min_max_height=(341, 900), w2h_ratio=1280 / 960)
-        return common_aug(aug_type)
+        """oxford_dataset.py:24-39"""
+        return common_aug(self, aug_type, oms=(341, 900), color=True, fda_source=True)

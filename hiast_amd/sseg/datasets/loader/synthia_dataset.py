@@ -22,4 +22,5 @@ class SYNTHIADataset(BaseDataset):
         return utils.preprocess_label(lbl.astype(np.uint8), _ID_MAP)
 
     def build_aug_fun(self, aug_type):
-        return common_aug(aug_type)
+        """synthia_dataset.py:20-33"""
+        return common_aug(self, aug_type, ms=(341, 640), dacs=(760, 1280), fda_target=True)

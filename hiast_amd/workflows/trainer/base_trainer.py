@@ -20,8 +20,24 @@ from hiast_amd.utils.result_recorder import ResultRecorder
 
 
 def autocast_dtype(cfg):
-    """apex opt levels -> autocast: O0 = fp32; O1/O2/O3 = reduced-precision convs (bf16 on MI355X)"""
-    return None if cfg.train.apex_opt == "O0" else torch.bfloat16
+    """apex opt levels -> autocast: O0 = fp32; O1/O2/O3 = 16-bit convolutions with fp32 accumulation and fp32 master
+    weights (utils/utils.py:126-132).  cfg.train.amp_dtype picks the 16-bit type: 'bf16' (default: the hand-written
+    channels-last kernels; 8 exponent bits, no loss scaling needed) or 'fp16' (the reference's apex-O1 arithmetic: the
+    library's half-precision convolutions between the fused fp32-statistics BatchNorm kernels, dynamic loss scaling)."""
+    if cfg.train.apex_opt == "O0":
+        return None
+    kind = getattr(cfg.train, "amp_dtype", "bf16")
+    if kind not in ("bf16", "fp16"):
+        raise ValueError("train.amp_dtype must be 'bf16' or 'fp16', got %r" % (kind,))
+    return torch.bfloat16 if kind == "bf16" else torch.float16
+
+
+def make_grad_scaler(amp_dtype):
+    """apex's dynamic loss scaling for fp16 (amp.initialize(..., opt_level='O1'): initial scale 2^16, halved on an
+    overflow — that step is skipped —, doubled after 2000 clean steps); bf16 and fp32 need none"""
+    if amp_dtype is torch.float16:
+        return torch.amp.GradScaler("cuda", init_scale=2.0 ** 16, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000)
+    return None
 
 
 class _Bare(torch.nn.Module):
@@ -95,6 +111,7 @@ class BaseTrainer:
         self.g_optimizer, self.d_optimizer = utils.init_optimizers(self.cfg, model)
         self.schedulers = utils.init_schedulers(self.cfg, self.g_optimizer, self.d_optimizer)
         self.amp_dtype = autocast_dtype(self.cfg)
+        self.scaler = make_grad_scaler(self.amp_dtype)
         self.model = self._wrap(model)
         self.model_recorder = ResultRecorder(self.cfg, self.gpu_index, self.g_optimizer, self.d_optimizer, "model",
                                              self.logger)
@@ -180,22 +197,33 @@ class BaseTrainer:
 
     def update_model(self, g_optimizer, d_optimizer, losses):
         """base_trainer.py:127-141: g_loss = Σ mean(loss_i) over the non-'D_' losses -> generator step; then, when
-        there is a 'D_loss', the discriminator step.  bf16 autocast needs no loss scaling."""
+        there is a 'D_loss', the discriminator step.  fp16 (amp_dtype) goes through the dynamic loss scaler like
+        apex's amp.scale_loss (:129-131); bf16 autocast needs no loss scaling."""
+        scaler = getattr(self, "scaler", None)
         g_loss = sum(torch.mean(v) for k, v in losses.items() if "D_" not in k)
         g_optimizer.zero_grad(set_to_none=True)
         HF.enable_wgrad_overlap(self.wgrad_overlap)
         try:
-            g_loss.backward()
+            (scaler.scale(g_loss) if scaler else g_loss).backward()
         finally:
             HF.enable_wgrad_overlap(False)
         HF.wgrad_stream_join()      # single-process runs issue the trunk's weight gradients on a side stream
         self._sync_grads(g_optimizer)
-        g_optimizer.step()
+        if scaler:
+            scaler.step(g_optimizer)        # unscales, skips the step on inf / NaN gradients
+        else:
+            g_optimizer.step()
         if "D_loss" in losses:
             d_optimizer.zero_grad(set_to_none=True)
-            torch.mean(losses["D_loss"]).backward()
+            d_loss = torch.mean(losses["D_loss"])
+            (scaler.scale(d_loss) if scaler else d_loss).backward()
             self._sync_grads(d_optimizer)
-            d_optimizer.step()
+            if scaler:
+                scaler.step(d_optimizer)
+            else:
+                d_optimizer.step()
+        if scaler:
+            scaler.update()
 
     def train(self):
         raise NotImplementedError

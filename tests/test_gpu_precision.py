@@ -1,0 +1,154 @@
+"""Which 16-bit type may stand in for the reference's apex-O1 training arithmetic?  The same K self-training iterations
+(HIAST setting: EMA teacher, 4-term loss, Adam, cosine schedule) from the same weights on the same fixed batches in
+three arithmetics on the device:
+
+    O0          fp32 everywhere (library convolutions)                       — the yardstick
+    O1 / fp16   the reference's arithmetic: half-precision library convolutions, fp32 BatchNorm statistics / losses,
+                dynamic loss scaling (utils/utils.py:126-132, default_config.py:109)
+    O1 / bf16   this package's fast path: hand-written channels-last bf16 kernels, no loss scaling
+
+and the student's predictions on a held-out image afterwards.  Contract (BASELINE north_star): mIoU on a fixed val set
+equal to the reference's +-0.05 points.  Measured on MI355X (printed by the test, recorded in DESIGN.md §8)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+
+pytestmark = pytest.mark.gpu
+H, W, C, B, K = 96, 192, 19, 2, 12
+
+
+def _trainer(root, apex_opt, amp_dtype):
+    from hiast_amd.utils.registry import register  # noqa: F401
+    from hiast_amd.utils.default_config import get_default_cfg
+    from hiast_amd.workflows.trainer.consistency_self_training_trainer import ConsistencySelfTrainingTrainer
+
+    class StepOnly(ConsistencySelfTrainingTrainer):
+        def assert_cfg(self):
+            pass
+
+        def build_train_data_reader(self):
+            pass
+
+        def build_val_data_reader(self):
+            self.v_loader = None
+
+    c = get_default_cfg()
+    c.trainer = "ConsistencySelfTrainingTrainer"
+    c.model.type = "SelfTrainingSegmentor"
+    c.model.predictor.kld_loss.weight = 0.1
+    c.model.predictor.ent_loss.weight = 1.0
+    c.cst_training.is_enabled = True
+    c.cst_training.cst_loss.weight = 0.5
+    c.cst_training.cst_loss.region = "ignored"
+    c.train.lr, c.train.optimizer, c.train.total_iter = 3e-6, "Adam", K       # configs/sl_1.yaml
+    c.train.apex_opt, c.train.amp_dtype = apex_opt, amp_dtype
+    c.train.gpu_num = 1
+    c.train.resume_from = os.path.join(root, "init.pth")
+    c.work_dir = os.path.join(root, "work_%s_%s" % (apex_opt, amp_dtype))
+    c.freeze()
+    return StepOnly(c, 0)
+
+
+def make_checkpoint(tmp_path_factory):
+    from hiast_amd.utils.registry import register  # noqa: F401
+    from hiast_amd.utils.registry.registries import MODEL
+    from hiast_amd.utils.default_config import get_default_cfg
+    from make_golden import seeded_state_dict
+    root = str(tmp_path_factory.mktemp("prec"))
+    m = MODEL["SelfTrainingSegmentor"](get_default_cfg())
+    sd = {"seg_model." + k: v for k, v in seeded_state_dict(m.seg_model, 790).items()}
+    m.load_state_dict(sd)
+    m = m.cuda()
+    # a checkpoint whose BatchNorm running statistics MATCH its activations, like any trained network's: one fp32
+    # train-mode pass with momentum 1 (seeded running statistics would let the eval-mode teacher's activations grow
+    # block by block — beyond the fp16 range after a few stages, which says nothing about trained checkpoints)
+    bns = [mod for mod in m.modules() if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm)]
+    for mod in bns:
+        mod.momentum = 1.0
+    m.train()
+    with torch.no_grad():
+        m(torch.from_numpy(synth.normal_f32(792, (4, 3, H, W))).cuda(), lowres=True)
+    for mod in bns:
+        mod.momentum = 0.1
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    m.eval()
+    x = torch.from_numpy(synth.normal_f32(791, (1, 3, H, W))).cuda()
+    with torch.no_grad():
+        s = 3.0 / float(m(x, lowres=True)["logits_lowres"].std())
+    for i in range(4):
+        sd["seg_model.aspp.conv2d_list.%d.weight" % i] = sd["seg_model.aspp.conv2d_list.%d.weight" % i] * s
+        sd["seg_model.aspp.conv2d_list.%d.bias" % i] = sd["seg_model.aspp.conv2d_list.%d.bias" % i] * s
+    torch.save(sd, os.path.join(root, "init.pth"))
+    return root
+
+
+@pytest.fixture(scope="module")
+def setup(tmp_path_factory):
+    return make_checkpoint(tmp_path_factory)
+
+
+def _run(root, apex_opt, amp_dtype):
+    tr = _trainer(root, apex_opt, amp_dtype)
+    dev = tr.device
+    batches = []
+    for t in range(3):
+        weak = synth.normal_f32(800 + t, (B, 3, H, W))
+        batches.append((torch.from_numpy(weak).to(dev), torch.from_numpy((weak * 1.05 + 0.02).astype(np.float32)).to(dev),
+                        torch.from_numpy(synth.pseudo_labels(810 + t, B, H, W, C, 0.4)).to(dev)))
+    held = torch.from_numpy(synth.normal_f32(820, (2, 3, H, W))).to(dev)
+    traj = []
+    for it in range(1, K + 1):
+        losses = tr.train_on(*batches[(it - 1) % 3])
+        tr.update_model(tr.g_optimizer, tr.d_optimizer, losses)
+        tr.after_update(it)
+        for s in tr.schedulers:
+            s.step()
+        traj.append(float(sum(torch.mean(v) for v in losses.values())))
+    net = tr.model.module
+    net.eval()
+    with torch.no_grad():          # evaluation in fp32 for every run: what differs is the TRAINED weights
+        z = net(held, lowres=True)["logits_lowres"].float()
+    from hiast_amd import kernels as K_
+    _, pred, _ = K_.plabel_pass1(z.contiguous(), H, W)
+    skipped = 0 if tr.scaler is None else int(round(np.log2(65536.0 / tr.scaler.get_scale())))
+    w = net.seg_model.aspp.conv2d_list[0].weight.detach().float().cpu().numpy().copy()
+    del tr
+    torch.cuda.empty_cache()
+    return np.array(traj), pred.cpu().numpy(), z.cpu().numpy(), skipped, w
+
+
+def test_bf16_and_fp16_training_track_fp32(setup):
+    from oracle import metrics_ref
+    root = setup
+    ref_l, ref_p, ref_z, _, w32 = _run(root, "O0", "bf16")
+    ref2_l, ref2_p, ref2_z, _, _ = _run(root, "O0", "bf16")          # noise floor: the same fp32 run again
+    f16_l, f16_p, f16_z, skipped, w16 = _run(root, "O1", "fp16")
+    b16_l, b16_p, b16_z, _, wb = _run(root, "O1", "bf16")
+
+    def miou(pred):        # the fp32 run's predictions are the ground truth
+        i, u = metrics_ref.intersection_and_union(pred.astype(np.int64), ref_p.astype(np.int64), C)
+        return 100.0 * metrics_ref.miou(i.astype(np.float64), u.astype(np.float64))[0]
+
+    rel = lambda a: float(np.abs(a - ref_l).max() / np.abs(ref_l).max())
+    zrel = lambda z: float(np.abs(z - ref_z).max() / np.abs(ref_z).max())
+    rows = (("fp32 again", ref2_l, ref2_p, ref2_z), ("fp16 (O1)", f16_l, f16_p, f16_z), ("bf16 (O1)", b16_l, b16_p, b16_z))
+    print("loss trajectory fp32       : %s" % np.round(ref_l, 3))
+    for name, l, p_, z in rows:
+        print("loss trajectory %-10s : %s" % (name, np.round(l, 3)))
+    for name, l, p_, z in rows:
+        print("%-10s vs the fp32 run: first-iteration loss %.2e rel, trajectory max %.2e rel, held-out logits %.2e of max, "
+              "pixel agreement %.4f, mIoU %.2f" % (name, abs(l[0] - ref_l[0]) / ref_l[0], rel(l), zrel(z), (p_ == ref_p).mean(), miou(p_)))
+    print("fp16: %d of %d steps skipped by the dynamic loss scaler (initial scale 2^16 halved per overflow, as apex)" % (skipped, K))
+    assert np.isfinite(ref_l).all() and np.isfinite(f16_l).all() and np.isfinite(b16_l).all()
+    # (1) forward arithmetic: the first loss is computed before any update — pure precision of the 16-bit forward
+    assert abs(f16_l[0] - ref_l[0]) / ref_l[0] <= 5e-3 and abs(b16_l[0] - ref_l[0]) / ref_l[0] <= 2e-2
+    # (2) training moves: fp32 and bf16 losses fall from the first step on; fp16 only once the loss scale has come down
+    assert ref_l[-1] < 0.9 * ref_l[0] and b16_l[-1] < 0.9 * b16_l[0]
+    assert skipped >= 1 and f16_l[-1] < f16_l[0]
+    # (3) the bf16 trajectory stays with the fp32 one (this random-init synthetic problem amplifies every rounding: the
+    # two fp32 runs above differ from each other as well, see the printed noise floor)
+    assert rel(b16_l) <= 0.25
