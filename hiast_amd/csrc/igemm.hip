@@ -513,7 +513,7 @@ __global__ __launch_bounds__(256) void pack_conv_weight_kernel(const float* __re
 // Tiled form for channel counts that are multiples of 64 (every trunk convolution, the ASPP tap matrices): one block
 // takes the 64 (n) x 64 (k) x taps tile of one tensor through LDS, so that the source is read in contiguous runs of
 // 64*taps floats per n and BOTH packed forms leave as whole 128-byte lines (forward: 64 k of one (n, tap); adjoint:
-// 64 n of one (k, flipped tap)).  The elementwise kernel above issued 2-byte stores 2*N (adjoint) bytes apart and
+// 64 n of one (k, flipped tap), written as two 64-byte halves by consecutive passes of the same block).  The elementwise kernel above issued 2-byte stores 2*N (adjoint) bytes apart and
 // reached 0.47 TB/s — 0.73 ms per trunk, three trunks per training step once the packs follow every optimiser / EMA
 // step.  PL = 2 walks the n range in two halves (a 32-channel slab holds hi|lo: the same 128-byte line).
 constexpr int PK_PITCH = 72;        // ushorts per (n, tap) row of the LDS tile: 64 + 8 (keeps 16-byte alignment)
@@ -523,9 +523,9 @@ __device__ __forceinline__ void pack_tile(const float* __restrict__ w, unsigned 
                                           unsigned short* __restrict__ wpt, int N, int K, int taps, int mode, int n0,
                                           int k0, unsigned short* lds)
 {
-    constexpr int TN = PL == 1 ? 64 : 32;
-    unsigned short* hi = lds;
-    unsigned short* lo = lds + (PL == 2 ? TN * 9 * PK_PITCH : 0);
+    constexpr int TN = PL == 1 ? 32 : 16;               // rows of n per pass: LDS = TN x taps x 72 x 2 B x PL (41 KiB at 9 taps,
+    unsigned short* hi = lds;                           // 4.6 KiB at 1: several blocks per CU instead of one)
+    unsigned short* lo = lds + (PL == 2 ? TN * taps * PK_PITCH : 0);
     unsigned short* fwd = (mode == 1) ? nullptr : wp;
     unsigned short* adj = (mode == 0) ? nullptr : (mode == 1 ? wp : wpt);
     const int run = 64 * taps;                                   // contiguous floats per n in the source
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(256) void pack_conv_weight_tiled_kernel(const float
                                                                      unsigned short* __restrict__ wpt, int N, int K,
                                                                      int taps, int mode)
 {
-    __shared__ __attribute__((aligned(16))) unsigned short lds[64 * 9 * PK_PITCH];
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds[];       // 32 * taps * PK_PITCH
     const int kt = K / 64;
     pack_tile<PL>(w, wp, wpt, N, K, taps, mode, (int)(blockIdx.x / kt) * 64, (int)(blockIdx.x % kt) * 64, lds);
 }
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(256) void pack_conv_weight_multi_kernel(const hiast
                                                                      const int32_t* __restrict__ chunk_tensor,
                                                                      const int64_t* __restrict__ chunk_start)
 {
-    __shared__ __attribute__((aligned(16))) unsigned short lds[64 * 9 * PK_PITCH];
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds[];       // 32 * max taps of the launch * PK_PITCH
     const hiast_pack_rec r = table[chunk_tensor[blockIdx.x]];
     const int kt = r.K / 64;
     const int tile = (int)chunk_start[blockIdx.x];
@@ -779,11 +779,12 @@ extern "C" int hiast_pack_conv_weight(const float* w, int N, int K, int taps, in
     const long long total = (long long)N * K * taps;
     if (N % 64 == 0 && K % 64 == 0 && taps <= 9 && !((((uintptr_t)wp) | ((uintptr_t)wpt)) & 15)) {
         const dim3 tg((unsigned)((N / 64) * (K / 64)));
+        const size_t lds_bytes = (size_t)32 * taps * hiast::PK_PITCH * sizeof(unsigned short);
         if (planes == 2)
-            hipLaunchKernelGGL(hiast::pack_conv_weight_tiled_kernel<2>, tg, dim3(256), 0, (hipStream_t)stream, w,
+            hipLaunchKernelGGL(hiast::pack_conv_weight_tiled_kernel<2>, tg, dim3(256), lds_bytes, (hipStream_t)stream, w,
                                (unsigned short*)wp, (unsigned short*)wpt, N, K, taps, transpose);
         else
-            hipLaunchKernelGGL(hiast::pack_conv_weight_tiled_kernel<1>, tg, dim3(256), 0, (hipStream_t)stream, w,
+            hipLaunchKernelGGL(hiast::pack_conv_weight_tiled_kernel<1>, tg, dim3(256), lds_bytes, (hipStream_t)stream, w,
                                (unsigned short*)wp, (unsigned short*)wpt, N, K, taps, transpose);
         HIAST_CHECK_LAUNCH();
         return 0;
@@ -818,11 +819,13 @@ extern "C" int hiast_split_planes(float* x, void* planes, int64_t M, int C, int 
 }
 
 extern "C" int hiast_pack_conv_weight_multi(const hiast_pack_rec* table, const int32_t* chunk_tensor,
-                                            const int64_t* chunk_start, int n_chunks, hiast_stream_t stream)
+                                            const int64_t* chunk_start, int n_chunks, int max_taps, hiast_stream_t stream)
 {
     if (!table || !chunk_tensor || !chunk_start) return HIAST_E_ARG;
-    if (n_chunks <= 0) return HIAST_E_ARG;
-    hipLaunchKernelGGL(hiast::pack_conv_weight_multi_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, table,
+    if (n_chunks <= 0 || max_taps <= 0) return HIAST_E_ARG;
+    if (max_taps > 9) return HIAST_E_RANGE;
+    const size_t lds_bytes = (size_t)32 * max_taps * hiast::PK_PITCH * sizeof(unsigned short);
+    hipLaunchKernelGGL(hiast::pack_conv_weight_multi_kernel, dim3(n_chunks), dim3(256), lds_bytes, (hipStream_t)stream, table,
                        chunk_tensor, chunk_start);
     HIAST_CHECK_LAUNCH();
     return 0;

@@ -179,29 +179,29 @@ __global__ __launch_bounds__(512) void wgrad_tn_kernel(const unsigned short* __r
 #pragma unroll
             for (int b = 0; b < 2; ++b) frag(tb, (wn & 1) * 64 + b * 32, kk, f.b[b][0], f.b[b][1]);
         };
-        // fragments of sub-step kk + 1 are requested before the MFMAs of sub-step kk
-        WgFrags fr[2];
-        read_all(fr[0], 0);
-        wg_wait(fr[0]);
+        // One fragment set in flight: with the set of sub-step kk + 1 prefetched as well the kernel needs 254 VGPRs,
+        // i.e. two of its waves fill a SIMD's register file and NOTHING else fits on the CU — the short BatchNorm
+        // kernels of the backward chain on the main stream then queue behind whole wgrad blocks (bnh_finalize: 7 -> 59 us
+        // per launch, x 105 launches per step).  At ~220 VGPRs a small wave still fits beside it.
+        WgFrags fr;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            WgFrags& cur = fr[kk & 1];
-            if (kk + 1 < 4) read_all(fr[(kk + 1) & 1], kk + 1);
+            read_all(fr, kk);
             if (more) {
                 piece(kt + 1, buf ^ 1, 2 * kk);
                 piece(kt + 1, buf ^ 1, 2 * kk + 1);
             }
+            wg_wait(fr);
             wg_bf16x8 fa[4], fb[2];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) fa[a] = wg_join(cur.a[a][0], cur.a[a][1]);
+            for (int a = 0; a < 4; ++a) fa[a] = wg_join(fr.a[a][0], fr.a[a][1]);
 #pragma unroll
-            for (int b = 0; b < 2; ++b) fb[b] = wg_join(cur.b[b][0], cur.b[b][1]);
+            for (int b = 0; b < 2; ++b) fb[b] = wg_join(fr.b[b][0], fr.b[b][1]);
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
-            if (kk + 1 < 4) wg_wait(fr[(kk + 1) & 1]);
         }
     }
 

@@ -747,7 +747,7 @@ class PackPlan:
         self.weights, self.planes = list(weights), int(planes)
         self.wp, self.wpt = [], []
         host = np.zeros(len(weights), dtype=self.REC)
-        ct, cs = [], []
+        lists = {}                     # taps -> ([record index per block], [tile index per block]): one launch per kernel size
         for i, (w, adj) in enumerate(zip(weights, adjoint)):
             _req(w.detach(), torch.float32, 4, "weight")
             N, K_, kh, kw = w.shape
@@ -759,14 +759,14 @@ class PackPlan:
             host[i] = (w.data_ptr(), wp.data_ptr(), wpt.data_ptr() if adj else 0, N, K_, taps, planes, 2 if adj else 0, 0)
             if N % 64 or K_ % 64 or taps > 9:
                 raise ValueError("PackPlan: channel counts must be multiples of 64 (got %d x %d)" % (N, K_))
+            ct, cs = lists.setdefault(taps, ([], []))
             for tile in range((N // 64) * (K_ // 64)):      # one block per 64 x 64 (n, k) tile, all taps
                 ct.append(i)
                 cs.append(tile)
         self.ptrs = [w.data_ptr() for w in weights]
         self.table = torch.from_numpy(host.view(np.uint8).reshape(-1).copy()).to(dev)
-        self.chunk_tensor = torch.tensor(ct, dtype=torch.int32, device=dev)
-        self.chunk_start = torch.tensor(cs, dtype=torch.int64, device=dev)
-        self.n_chunks = len(ct)
+        self.launches = [(taps, torch.tensor(ct, dtype=torch.int32, device=dev), torch.tensor(cs, dtype=torch.int64, device=dev),
+                          len(ct)) for taps, (ct, cs) in sorted(lists.items())]
         self.versions = None
 
     def still_valid(self):
@@ -777,8 +777,9 @@ class PackPlan:
         v = [w._version for w in self.weights]
         if v == self.versions:
             return False
-        check(_lib.load().hiast_pack_conv_weight_multi(_ptr(self.table), _ptr(self.chunk_tensor), _ptr(self.chunk_start),
-                                                       self.n_chunks, _stream()), "hiast_pack_conv_weight_multi")
+        for taps, ct, cs, n in self.launches:        # the 1x1 and the 3x3 weights: LDS tile sized per kernel size
+            check(_lib.load().hiast_pack_conv_weight_multi(_ptr(self.table), _ptr(ct), _ptr(cs), n, taps, _stream()),
+                  "hiast_pack_conv_weight_multi")
         self.versions = v
         return True
 

@@ -270,10 +270,11 @@ int hiast_split_planes(float* x, void* planes, int64_t M, int C, int inverse, hi
 /* hiast_pack_conv_weight for a list of weights in ONE launch (a trunk's 104 convolutions after every optimiser / EMA
  * update).  table: device array of records (mode = the `transpose` argument above; N, K multiples of 64, taps <= 9);
  * one block per 64 x 64 (n, k) tile of one weight: chunk_tensor[b] = record index, chunk_start[b] = index of the tile
- * within that weight, row-major over (N/64, K/64). */
+ * within that weight, row-major over (N/64, K/64).  max_taps >= the largest `taps` of the records a block of this launch
+ * may meet (sizes the LDS tile: list the 1x1 and the 3x3 weights in separate launches to keep the 1x1 blocks small). */
 typedef struct { const float* w; void* wp; void* wpt; int32_t N, K, taps, planes, mode, pad; } hiast_pack_rec;
 int hiast_pack_conv_weight_multi(const hiast_pack_rec* table, const int32_t* chunk_tensor, const int64_t* chunk_start,
-                                 int n_chunks, hiast_stream_t stream);
+                                 int n_chunks, int max_taps, hiast_stream_t stream);
 
 /* ---- K9d: weight gradient of the trunk convolutions on channels-last bf16 activations -------------------------
  * autograd of nn.Conv2d in Bottleneck.forward (resnet.py:78-98) under mixed precision:
