@@ -107,6 +107,11 @@ __global__ __launch_bounds__(512) void wgrad_tn_kernel(const unsigned short* __r
 
     // DMA pieces of one k-step: 64 wave-instructions (4 sub-tiles x 16 groups of 4 rows); wave w issues pieces
     // 8w .. 8w+7: piece = sub*16 + grp.  Lane l supplies row 4*grp + (l >> 4), logical chunk (l & 15) ^ swz(row).
+    // 3x3: the (image, row, column) of a lane's output pixel is decoded ONCE per k-step (piece 0: float reciprocal +
+    // one-step correction, exact for m < 2^24, no integer division) and then walked: consecutive pieces of a wave are
+    // 4 pixels apart.  Decoding every piece cost the X-loading waves ~40 VALU instructions x 8 pieces per k-step —
+    // more than their 32 MFMAs.
+    int d_img = 0, d_yo = 0, d_xo = 0;
     auto piece = [&](int kt, int buf, int pc) {
         const int idx = wave * 8 + pc;
         const int sub = idx >> 4, grp = idx & 15;
@@ -119,13 +124,10 @@ __global__ __launch_bounds__(512) void wgrad_tn_kernel(const unsigned short* __r
             wg_dma16(yrs, dst, voff, 0);
         } else {
             int voff = OOB;
-            if (m < m_end) {
-                if (TAPS == 1) {
-                    voff = (int)(((size_t)m * K + k0 + (sub - 2) * 128) * 2) + ch * 16;
-                } else {
-                    // (image, row, column) of output pixel m without integer divisions (they were ~300 VALU per
-                    // k-step and wave, more than its MFMA time): float reciprocal + one-step correction, exact for
-                    // m < 2^24
+            if (TAPS == 1) {
+                if (m < m_end) voff = (int)(((size_t)m * K + k0 + (sub - 2) * 128) * 2) + ch * 16;
+            } else {
+                if (pc == 0) {
                     const int hw = geo.Ho * geo.Wo;
                     int img = (int)(((float)m + 0.5f) * inv_hw);
                     int r = m - img * hw;
@@ -133,9 +135,17 @@ __global__ __launch_bounds__(512) void wgrad_tn_kernel(const unsigned short* __r
                     int yo = (int)(((float)r + 0.5f) * inv_wo);
                     int xo = r - yo * geo.Wo;
                     if (xo < 0) { --yo; xo += geo.Wo; } else if (xo >= geo.Wo) { ++yo; xo -= geo.Wo; }
-                    const int yy = yo * geo.stride + oy, xx = xo * geo.stride + ox;
+                    d_img = img; d_yo = yo; d_xo = xo;
+                }
+                if (m < m_end) {
+                    const int yy = d_yo * geo.stride + oy, xx = d_xo * geo.stride + ox;
                     if (yy >= 0 && yy < geo.H && xx >= 0 && xx < geo.W)
-                        voff = (int)((((size_t)(img * geo.H + yy) * geo.W + xx) * K + k0 + (sub - 2) * 128) * 2) + ch * 16;
+                        voff = (int)((((size_t)(d_img * geo.H + yy) * geo.W + xx) * K + k0 + (sub - 2) * 128) * 2) + ch * 16;
+                }
+                d_xo += 4;                                   // the next piece of this wave: 4 pixels on
+                while (d_xo >= geo.Wo) {
+                    d_xo -= geo.Wo;
+                    if (++d_yo >= geo.Ho) { d_yo = 0; ++d_img; }
                 }
             }
             wg_dma16(xrs, dst, voff, 0);
