@@ -16,6 +16,9 @@ SHAPES = {
     "l3conv3_pl2": (8, 64, 128, 256, 1024, 1, 1, 2, True),
     "l3conv1_pl2": (8, 64, 128, 1024, 256, 1, 1, 2, False),
     "l3conv2_pl1": (8, 64, 128, 256, 256, 9, 2, 1, False),
+    "l3conv3_pl1": (8, 64, 128, 256, 1024, 1, 1, 1, True),       # K9e xconv: teacher conv3 + BN + residual + ReLU
+    "wgrad_l3conv3": (8, 64, 128, 256, 1024, 1, 1, 1, False),    # K9d: dW of the 256 -> 1024 1x1
+    "wgrad_l3conv2": (8, 64, 128, 256, 256, 9, 2, 1, False),     # K9d: dW of the 3x3, dilation 2
 }
 
 
@@ -24,6 +27,17 @@ def main():
     B, H, W, Cin, Cout, taps, dil, PL, has_res = SHAPES[name]
     dev = torch.device("cuda")
     torch.manual_seed(0)
+    if name.startswith("wgrad"):
+        x = torch.randn(B, H, W, Cin, device=dev).bfloat16()
+        dy = torch.randn(B, H, W, Cout, device=dev).bfloat16()
+        for _ in range(6):
+            K.conv_wgrad_nhwc(dy, x, 3 if taps == 9 else 1, 1, dil)
+        torch.cuda.synchronize()
+        nsplit_bytes = K._lib.load().hiast_conv_wgrad_workspace_bytes(B, H, W, Cin, Cout, taps)
+        alg = (x.numel() + dy.numel()) * 2 + Cout * Cin * taps * 4
+        print("shape %s algorithmic_bytes %d flop %d (+ split partials written and re-read: %d bytes each way)"
+              % (name, alg, 2 * B * H * W * taps * Cin * Cout, nsplit_bytes))
+        return
     kk = 3 if taps == 9 else 1
     w = torch.randn(Cout, Cin, kk, kk, device=dev) * (2.0 / (Cin * taps)) ** 0.5
     bn = torch.nn.BatchNorm2d(Cout).to(dev).eval()
