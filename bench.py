@@ -44,11 +44,12 @@ def parse():
     p.add_argument("--batch", type=int, default=8, help="images per GPU per step")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-size", type=int, nargs=2, default=[H, W],
-                   help="H W of the CPU-baseline sample image (time is scaled to 512x1024 by the pixel ratio)")
+                   help="H W of the CPU-baseline sample images (BASELINE.md §3: the full 512x1024, ~20 s of CPU work on 16 "
+                        "cores; smaller samples are scaled to 512x1024 by the pixel ratio)")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' only for "
                    "functional tests of the N>1 path on a single GPU")
     p.add_argument("--same-device", action="store_true", help="testing: every rank uses cuda:0")
-    p.add_argument("--cpu-threads", type=int, default=256, help="upper bound; the usable CPUs of the box decide")
+    p.add_argument("--cpu-threads", type=int, default=64, help="upper bound; the usable CPUs of the box decide")
     p.add_argument("--cpu-reps", type=int, default=3)
     p.add_argument("--trainer", default="ConsistencySelfTrainingTrainer",
                    choices=["ConsistencySelfTrainingTrainer", "SelfTrainingTrainer"])
@@ -376,9 +377,26 @@ def _cpu_info():
     if info["sockets"] and info["cores_per_socket"]:
         info["physical_cores"] = info["sockets"] * info["cores_per_socket"]
     try:
-        info["usable"] = len(os.sched_getaffinity(0))       # the box's CPU share (cgroup / affinity)
+        usable = len(os.sched_getaffinity(0))
     except Exception:
-        info["usable"] = os.cpu_count()
+        usable = os.cpu_count() or 1
+    # the box's CPU share: a cgroup quota does not show in the affinity mask (256 logical CPUs visible, 16 granted:
+    # 256 torch threads on 16 CPUs ran the baseline 10x slower than 16 threads)
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: (t.split()[0], t.split()[1])),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", None)):
+        try:
+            txt = open(path).read().strip()
+            if parse is not None:
+                quota, period = parse(txt)
+            else:
+                quota, period = txt, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()
+            if quota not in ("max", "-1") and int(period) > 0:
+                usable = max(1, min(usable, int(int(quota) / int(period))))
+                info["cgroup_cpu_quota"] = int(quota) / int(period)
+                break
+        except Exception:
+            continue
+    info["usable"] = usable
     return info
 
 
@@ -426,14 +444,20 @@ def cpu_baseline(cfg, size, threads, batch=2, reps=3):
         opt.step()
         return time.perf_counter() - t0
 
+    def say(msg):                      # progress on stderr: a harness that sees no output for minutes may take the run for hung
+        print("[cpu_baseline] " + msg, file=sys.stderr, flush=True)
+
+    say("%d torch threads on %s; warm-up ..." % (cores, info["model"]))
     plbl, _, _ = generate()            # warm-up (first-touch allocations, thread pools)
     train(plbl)
     gen, post, trn = [], [], []
-    for _ in range(reps):
+    for r in range(reps):
         plbl, tf, tp = generate()
         gen.append(tf)
         post.append(tp)
         trn.append(train(plbl))
+        say("repetition %d/%d: eval forward %.1f s, IAS post-processing %.1f s, training step %.1f s (batch %d, %dx%d)"
+            % (r + 1, reps, tf, tp, trn[-1], batch, w, h))
     scale = (H * W) / float(h * w) / batch          # -> seconds per 1024x512 image
     med = lambda v: float(np.median(v))
     fwd, pst, tr = med(gen) * scale, med(post) * scale, med(trn) * scale
