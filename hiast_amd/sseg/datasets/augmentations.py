@@ -283,19 +283,13 @@ def _gaussian_kernel_cv(ksize, sigma):
 
 
 def _blur_separable(img, kernel):
-    """separable convolution with BORDER_REFLECT_101, float32 accumulation, round to uint8"""
-    r = len(kernel) // 2
+    """separable convolution with BORDER_REFLECT_101 ('mirror'), float32 accumulation, round to uint8
+    (scipy's C loop: 41 taps on a 1024x512 view in ~12 ms, the numpy slice-sum took 65)"""
+    from scipy.ndimage import correlate1d
     x = img.astype(np.float32)
-    for axis in (0, 1):
-        pad = [(0, 0)] * x.ndim
-        pad[axis] = (r, r)
-        xp = np.pad(x, pad, mode="reflect")
-        out = np.zeros_like(x)
-        for i, kv in enumerate(kernel):
-            sl = [slice(None)] * x.ndim
-            sl[axis] = slice(i, i + x.shape[axis])
-            out += kv * xp[tuple(sl)]
-        x = out
+    k = np.asarray(kernel, np.float32)
+    x = correlate1d(x, k, axis=0, mode="mirror")
+    x = correlate1d(x, k, axis=1, mode="mirror")
     return np.clip(np.rint(x), 0, 255).astype(np.uint8)
 
 
@@ -373,17 +367,23 @@ class ColorJitter(_Aug):
 
     @staticmethod
     def _saturation(img, f):
-        g = _gray_cv(img).astype(np.float32)[..., None]
-        return np.clip(img.astype(np.float32) * f + g * (1 - f), 0, 255).astype(np.uint8)
+        g = _gray_cv(img).astype(np.float32)
+        g *= (1 - f)
+        out = img.astype(np.float32)
+        out *= f
+        out += g[..., None]
+        return np.clip(out, 0, 255, out=out).astype(np.uint8)
 
     @staticmethod
     def _hue(img, f):
+        """hue rotation by f turns through an 8-bit HSV image (PIL's C conversion: H in 256 steps where OpenCV has 180 —
+        the numpy conversion of _rgb_to_hsv_u8 reproduces OpenCV's scale but costs 90 ms per 1024x512 view in a worker)"""
         if f == 0:
             return img
-        hsv = _rgb_to_hsv_u8(img)
-        lut = np.mod(np.arange(256, dtype=np.int16) + 180 * f, 180).astype(np.uint8)
+        hsv = np.array(Image.fromarray(img).convert("HSV"))
+        lut = np.mod(np.arange(256, dtype=np.int32) + int(round(256 * f)), 256).astype(np.uint8)
         hsv[..., 0] = lut[hsv[..., 0]]
-        return _hsv_to_rgb_u8(hsv)
+        return np.asarray(Image.fromarray(hsv, "HSV").convert("RGB"))
 
     def apply(self, image, masks, factors, order):
         fns = (self._brightness, self._contrast, self._saturation, self._hue)
