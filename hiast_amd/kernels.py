@@ -440,6 +440,11 @@ class EmaPlan:
         return all(e.data_ptr() == a and p.data_ptr() == b
                    for (e, p, (a, b)) in zip(self.keep[0], self.keep[1], self.ptrs))
 
+    def matches(self, ema_tensors, src_tensors):
+        """the LIVE tensors still sit where the table points (a load_state_dict / .to() may have moved them)"""
+        return len(ema_tensors) == len(self.ptrs) and all(
+            e.data_ptr() == a and p.data_ptr() == b for (e, p, (a, b)) in zip(ema_tensors, src_tensors, self.ptrs))
+
 
 def ema_update(plan, gamma):
     """ema = ema*gamma + p*(1-gamma), the scalars rounded to float32 as torch's tensor*float does"""
@@ -495,6 +500,10 @@ class CopyPlan:
 
     def still_valid(self):
         return all(d.data_ptr() == a and s_.data_ptr() == b for (d, s_, (a, b)) in zip(self.keep[0], self.keep[1], self.ptrs))
+
+    def matches(self, dsts, srcs):
+        return len(dsts) == self.n and all(d.data_ptr() == a and s_.data_ptr() == b
+                                           for (d, s_, (a, b)) in zip(dsts, srcs, self.ptrs))
 
 
 def multi_copy(plan):
