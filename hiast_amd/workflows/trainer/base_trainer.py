@@ -40,6 +40,15 @@ def make_grad_scaler(amp_dtype):
     return None
 
 
+def _worker_init(_worker_id):
+    """DataLoader workers yield the CPU to the main process: beside 10-14 busy workers on a 16-CPU share the main
+    process's launch loop (31 ms of Python per iteration when it runs alone) took 64-88 ms and bound the end-to-end rate"""
+    try:
+        os.nice(10)
+    except OSError:
+        pass
+
+
 class _Bare(torch.nn.Module):
     """`.module` indirection for a single process, so trainers can write model.module.* like under DDP"""
 
@@ -123,7 +132,8 @@ class BaseTrainer:
         sampler = DistributedSampler(ds, num_replicas=self.world, rank=self.gpu_index, shuffle=shuffle)
         return sampler, DataLoader(ds, batch_size, sampler=sampler, num_workers=self.cfg.dataset.num_workers,
                                    pin_memory=True, drop_last=drop_last,
-                                   persistent_workers=self.cfg.dataset.num_workers > 0)
+                                   persistent_workers=self.cfg.dataset.num_workers > 0,
+                                   worker_init_fn=_worker_init if self.cfg.dataset.num_workers > 0 else None)
 
     def build_train_data_reader(self):
         s = self.cfg.dataset.source

@@ -80,10 +80,30 @@ try:
             wait[0] += time.time() - a
             return b
         tr.next_target_batch = timed_fetch
+        # where the main process's time goes (HIAST_E2E_BREAKDOWN=1): wall time inside the parts of an iteration
+        parts = {}
+        if os.environ.get("HIAST_E2E_BREAKDOWN", "0") == "1":
+            from hiast_amd.sseg.datasets import utils as du_
+
+            def wrap(obj, name, key):
+                f = getattr(obj, name)
+
+                def g(*a, **k):
+                    t = time.perf_counter()
+                    r = f(*a, **k)
+                    parts[key] = parts.get(key, 0.0) + time.perf_counter() - t
+                    return r
+                setattr(obj, name, g)
+            wrap(du_, "to_device_batch", "to_device_batch")
+            wrap(tr, "train_on", "train_on (teacher + student forward, loss)")
+            wrap(tr, "update_model", "update_model (backward, Adam)")
+            wrap(tr, "after_update", "after_update (EMA)")
+            wrap(tr.model_recorder, "record_losses", "record_losses")
         for it in range(1, warm + 1):
             tr.step(it)
         torch.cuda.synchronize()
         wait[0] = 0.0
+        parts.clear()
         t0 = time.time()
         for it in range(warm + 1, warm + iters + 1):
             tr.step(it)
@@ -92,6 +112,8 @@ try:
         dt = (time.time() - t0) / iters
         print("  host loop %.1f ms/iter of which %.1f ms in next_target_batch()" % (t_host * 1e3, wait[0] / iters * 1e3),
               flush=True)
+        if parts:
+            print("  breakdown (ms/iter): " + ", ".join("%s %.1f" % (k, v / iters * 1e3) for k, v in parts.items()), flush=True)
         del tr.next_target_batch                # (the instance attribute; the class method is back)
         print("ConsistencySelfTrainingTrainer end to end, %s (DataLoader, %d workers, CopyPaste + MS + CCA, bs %d): "
               "%.1f ms/iter = %.1f images/s" % (tag, nw, bs, dt * 1e3, bs / dt), flush=True)
