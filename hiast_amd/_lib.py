@@ -10,7 +10,7 @@ import os
 import torch  # noqa: F401  (loads libamdhip64 before our library is opened)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libhiast_hip.so")
+LIB_PATH = os.environ.get("HIAST_LIB") or os.path.join(_HERE, "csrc", "libhiast_hip.so")   # HIAST_LIB: A/B of two builds
 
 c_int, c_i64, c_f32, c_sz, c_vp = (ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t,
                                    ctypes.c_void_p)

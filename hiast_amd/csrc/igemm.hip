@@ -17,13 +17,25 @@
 //
 // Structure: 256 x BN block tile (BN = 256 | 128 | 64), 8 waves, one slab of k per step.  A k-step's tile
 // ((256 + BN) rows x 128 B) is written into LDS by the DMA path: each wave-instruction moves 8 whole 128-byte
-// lines (one row slab each: full L2 lines, the 64-byte half lines of a BK=32 bf16 tile measured ~10 TB/s chip-wide)
-// to a wave-uniform LDS address + 16 B x lane; the bank-conflict-free XOR swizzle of the image is therefore
-// applied to each lane's SOURCE chunk and again by the fragment reads.  Out-of-image taps and tail rows use a
-// buffer offset beyond num_records, for which the DMA writes zeros: zero padding costs no instruction.  Two LDS
-// buffers (the DMA of k-step t+1 flies while the MFMAs of k-step t run), one barrier per k-step, no VGPR staging
-// and no VALU in the loop besides address selection.  The 256-row tile halves the L2->LDS bytes per MFMA of a
-// 128 x 128 tile, which is what bounded the earlier kernels (~9 TB/s of L2 reads at 35 % MFMA utilisation).
+// lines (one row slab each: full L2 lines) to a wave-uniform LDS address + 16 B x lane; the bank-conflict-free XOR
+// swizzle of the image is therefore applied to each lane's SOURCE chunk and again by the fragment reads.  Out-of-image
+// taps and tail rows use a buffer offset beyond num_records, for which the DMA writes zeros: zero padding costs no
+// instruction.  No VGPR staging and no VALU in the loop besides address selection.  The 256-row tile halves the L2->LDS
+// bytes per MFMA of a 128 x 128 tile.
+//
+// The k-step loop (round 2; measured with the s_memtime stamps of -DIG_STAMP, tools/igemm_stamps.py):
+//  * three LDS stages of the activation tile, two of the weight tile (160 KiB), counted `s_waitcnt vmcnt` + a bare
+//    `s_barrier` per k-step (behind __syncthreads() the compiler drains vmcnt to 0);
+//  * fragment reads are inline asm (`ds_read_b128` with the tile offset as immediate), waits are explicit: the compiler
+//    orders every LDS load it can see behind ALL pending LDS-DMAs;
+//  * the DMA pieces of the following k-steps are issued one at a time BETWEEN the MFMAs of the 16-row tiles: the CU's
+//    texture path takes 64 B per clock (tools/micro/dma_fill.hip: 64 KiB per ~1000 cycles, 35 TB/s chip-wide from L2),
+//    so a burst of the eight pieces of every wave stalls the issuing waves for ~1000 cycles per k-step;
+//  * no branch in the loop (the last k-steps issue zero fills instead of skipping the DMA);
+//  * the two waves of a SIMD hand the issue priority over in the middle of the k-step (s_setprio): the arbiter serves the
+//    older wave first, which left waves 4-7 ~900 cycles behind at every barrier.
+// Round 1's loop (two stages, compiler-scheduled reads, 20 branches per k-step) held the matrix pipe 54 % busy at the
+// clock the chip runs (3780 cycles per 2048-cycle k-step); this one 63-66 %.
 #include <hip/hip_bf16.h>
 #include <stdlib.h>
 
@@ -36,6 +48,21 @@ typedef __attribute__((ext_vector_type(16))) float ig_f32x16;
 typedef __attribute__((ext_vector_type(4))) float ig_f32x4;
 
 constexpr int IG_BM = 256;
+
+#ifdef IG_STAMP       // diagnostic build (tools/igemm_stamps.py): cycles a wave spends in the parts of a k-step, summed over the loop
+__device__ unsigned ig_stamp_buf[1024 * 8 * 8];
+__device__ __forceinline__ unsigned ig_now()
+{
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return (unsigned)t;
+}
+#define IG_T(var) const unsigned var = ig_now()
+#define IG_ACC(i, a, b) stamp_acc[i] += (b) - (a)
+#else
+#define IG_T(var)
+#define IG_ACC(i, a, b)
+#endif
 
 struct IGeo {
     int H, W, Ho, Wo, stride, dil;
@@ -63,6 +90,57 @@ __device__ __forceinline__ void ig_dma16(__amdgpu_buffer_rsrc_t rs, unsigned cha
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (ig_lds_ptr)lds, 16, voff, soff, 0, 0);
 }
 
+// Fragment reads as inline asm (ds_read_b128, tile offset as the instruction's immediate) with explicit lgkmcnt waits that
+// tie the destination registers: the compiler orders every LDS load it can see behind ALL pending LDS-DMAs
+// (s_waitcnt vmcnt(0)), which would make the DMA of k-step t+1 a wait inside k-step t.
+template <int OFF>
+__device__ __forceinline__ ig_bf16x8 ig_lds_read(unsigned addr)
+{
+    ig_bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+    return v;
+}
+__device__ __forceinline__ void ig_lds_read4(ig_bf16x8 (&f)[4][2], unsigned addr)       // B: four 16-row tiles x two chunks
+{
+    f[0][0] = ig_lds_read<0>(addr);        f[0][1] = ig_lds_read<0>(addr ^ 64u);
+    f[1][0] = ig_lds_read<2048>(addr);     f[1][1] = ig_lds_read<2048>(addr ^ 64u);
+    f[2][0] = ig_lds_read<4096>(addr);     f[2][1] = ig_lds_read<4096>(addr ^ 64u);
+    f[3][0] = ig_lds_read<6144>(addr);     f[3][1] = ig_lds_read<6144>(addr ^ 64u);
+}
+__device__ __forceinline__ void ig_lds_read_a(ig_bf16x8 (&f)[2], unsigned addr, int a)  // A: 16-row tile a (a is a constant
+{                                                                                        // after unrolling)
+    switch (a) {
+    case 1: f[0] = ig_lds_read<1 * 2048>(addr); f[1] = ig_lds_read<1 * 2048>(addr ^ 64u); break;
+    case 2: f[0] = ig_lds_read<2 * 2048>(addr); f[1] = ig_lds_read<2 * 2048>(addr ^ 64u); break;
+    case 3: f[0] = ig_lds_read<3 * 2048>(addr); f[1] = ig_lds_read<3 * 2048>(addr ^ 64u); break;
+    case 4: f[0] = ig_lds_read<4 * 2048>(addr); f[1] = ig_lds_read<4 * 2048>(addr ^ 64u); break;
+    case 5: f[0] = ig_lds_read<5 * 2048>(addr); f[1] = ig_lds_read<5 * 2048>(addr ^ 64u); break;
+    case 6: f[0] = ig_lds_read<6 * 2048>(addr); f[1] = ig_lds_read<6 * 2048>(addr ^ 64u); break;
+    case 7: f[0] = ig_lds_read<7 * 2048>(addr); f[1] = ig_lds_read<7 * 2048>(addr ^ 64u); break;
+    default: f[0] = ig_lds_read<0>(addr); f[1] = ig_lds_read<0>(addr ^ 64u); break;
+    }
+}
+template <int N>
+__device__ __forceinline__ void ig_lds_wait_n(ig_bf16x8 (&f)[2], ig_bf16x8 (&g)[2])    // all but the N youngest LDS reads are done
+{
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f[0]), "+v"(f[1]), "+v"(g[0]), "+v"(g[1]) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void ig_lds_wait_n(ig_bf16x8 (&f)[2])
+{
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f[0]), "+v"(f[1]) : "n"(N));
+}
+__device__ __forceinline__ void ig_lds_wait_a(ig_bf16x8 (&f)[2])
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]));
+}
+__device__ __forceinline__ void ig_lds_wait_b(ig_bf16x8 (&f)[4][2], ig_bf16x8 (&g)[2])
+{
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[1][0]), "+v"(f[1][1]), "+v"(f[2][0]), "+v"(f[2][1]), "+v"(f[3][0]),
+                   "+v"(f[3][1]), "+v"(g[0]), "+v"(g[1]));
+}
+
 // element offset (in bf16 units) of channel c (a multiple of 8) of row m in a [M][C] activation
 template <int PL>
 __device__ __forceinline__ size_t ig_elem(size_t m, int c, int C)
@@ -73,19 +151,19 @@ __device__ __forceinline__ size_t ig_elem(size_t m, int c, int C)
 
 // OUTF32: write fp32 [M][N] — the ASPP tap GEMM; otherwise the output has the input's format.
 // Waves: WM x WN = 8; wave tile (256/WM) x (BN/WN) with BN/WN == 64.
-// M16: build the wave tile from v_mfma_f32_16x16x32_bf16 (16 x 16 output tiles, 32-deep) instead of 32x32x16: the same
-// LDS bytes and MFMA cycles per flop, but the chip holds a higher clock on this shape under load (MI355X_MICROARCH.md,
-// DVFS give-back item 7) — both are built, the launcher picks by measurement (HIAST_IGEMM_MFMA16).
+// The wave tile is built from v_mfma_f32_16x16x32_bf16 (16 x 16 output tiles, 32-deep): the same LDS bytes and MFMA cycles
+// per flop as 32x32x16, but the chip holds a higher clock on this shape under load (MI355X_MICROARCH.md, DVFS give-back
+// item 7; measured 4-10 % on every trunk shape in round 1).
 // GATE (PL = 1, RES, no ReLU): 0 = plain residual; 1 = the residual is kept where the gate tensor Rg (values like R)
 // is > 0; 2 = where bit (n & 7) of byte Rg[m][n / 8] is set.  A compile-time switch: as a run-time test on Rg the
 // gate put ~500 branches and ~300 s_waitcnt into the epilogue of EVERY bf16 residual launch (the teacher forward
 // included), which serialised its residual prefetch.
 // STATS: emit the per-block BatchNorm sums (plain bf16 launches only: the student forward).
-template <int PL, bool OUTF32, int BN, int TAPS, bool RES, bool RELU, bool M16, int GATE = 0, bool STATS = false>
+template <int PL, bool OUTF32, int BN, int TAPS, bool RES, bool RELU, int GATE = 0, bool STATS = false>
 __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
     const unsigned short* __restrict__ X, const unsigned short* __restrict__ Wp, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ var, float eps,
-    const unsigned short* __restrict__ R, void* __restrict__ Yv, int M, int K, int N, IGeo geo, int dbg,
+    const unsigned short* __restrict__ R, void* __restrict__ Yv, int M, int K, int N, IGeo geo,
     float* __restrict__ stats,           // optional [gridDim m-blocks][N][2]: per-block Σy, Σy² of the STORED values
     const unsigned short* __restrict__ Rg)   // GATE != 0: o += gate ? R : 0 (the ReLU-masked gradient of an identity branch)
 {
@@ -93,14 +171,17 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
     constexpr int WN = BN / 64, WM = 8 / WN;
     static_assert(!STATS || (PL == 1 && !OUTF32 && !RES && !RELU), "statistics epilogue: plain bf16 launches only");
     constexpr int TM = IG_BM / WM / 32;                 // 32-row tiles per wave (4 | 2 | 1)
-    constexpr int TN = 2;                               // 32-column tiles per wave
-    constexpr int KK = PL == 2 ? 2 : 4;                 // 16-deep MFMA steps per slab
     constexpr int A_BYTES = IG_BM * 128, B_BYTES = BN * 128;
-    constexpr int BUF_BYTES = A_BYTES + B_BYTES;
+    // LDS: THREE stages of the activation tile and TWO of the weight tile (160 KiB at BN = 256).  The fill rate of a tile
+    // is (bytes in flight) / latency, and with one 64 KiB tile in flight per CU the launches were bound by exactly that
+    // (removing every MFMA left the kernel time unchanged): the activation rows — first touched in HBM — are requested
+    // two k-steps ahead, the weight rows (L2 hits, the same for every block) one.
+    constexpr int NSA = 3, NSB = 2;
+    constexpr int LDS_BYTES = NSA * A_BYTES + NSB * B_BYTES;
     constexpr int BG = BN / 64;                         // 8-row B groups per wave (4 | 2 | 1)
     constexpr int EP = 68;                              // padded row of a wave's private epilogue tile (floats)
-    static_assert(2 * BUF_BYTES >= 8 * 32 * EP * 4, "epilogue staging must fit in the tile buffers");
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * BUF_BYTES];
+    static_assert(LDS_BYTES >= 8 * 32 * EP * 4, "epilogue staging must fit in the tile buffers");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -153,45 +234,39 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
         bvoff[g] = (int)((size_t)(n0 + rl) * TAPS * KS * 128) + ((lane & 7) ^ ((rl >> 1) & 7)) * 16;
     }
 
-    // one DMA piece of k-step kt: p < 4 -> A row group p of this wave, else B row group p - 4
-    constexpr int NPIECE = 4 + BG;
-    auto piece = [&](int kt, int buf, int p) {
-        // k-step order: channel slab OUTER, tap INNER — the nine shifted re-reads of a slab follow each other, so
-        // the set an XCD's 32 blocks re-read (32 x 256 rows x 128 B = 1 MiB + the weights) stays in its 4 MiB L2
-        // (tap-outer order swept the whole 8 MiB image between two uses: 50 % L2 hit rate, 4.8x over-fetch)
+    // DMA pieces of a wave (one instruction = 8 rows x 128 B): p < BG -> its B row group p, else its A row group p - BG.
+    // No branches: an out-of-image tap (or a tail row) selects the out-of-range offset, for which the DMA writes zeros.
+    // k-step order: channel slab OUTER, tap INNER — the nine shifted re-reads of a slab follow each other, so
+    // the set an XCD's 32 blocks re-read (32 x 256 rows x 128 B = 1 MiB + the weights) stays in its 4 MiB L2
+    // (tap-outer order swept the whole 8 MiB image between two uses: 50 % L2 hit rate, 4.8x over-fetch)
+    constexpr int NPIECE = BG + 4;
+    auto dma_a = [&](int kt, int sa, int g, bool on) {       // !on (past the last k-step): a zero fill nobody reads
         const int j = TAPS == 1 ? kt : kt / TAPS;
         const int tap = TAPS == 1 ? 0 : kt - j * TAPS;
-        unsigned char* base = smem + buf * BUF_BYTES;
-        if (p < 4) {
-            const int g = p;
-            int voff;
-            if (TAPS == 1) {
-                voff = aok[g] ? (int)((size_t)an[g] * KS * 128) + achunk[g] : OOB;
-            } else {
-                const int yy = ay[g] + (tap / 3 - 1) * geo.dil, xx = ax[g] + (tap % 3 - 1) * geo.dil;
-                const bool ok = aok[g] && yy >= 0 && yy < geo.H && xx >= 0 && xx < geo.W;
-                const int pix = (an[g] * geo.H + yy) * geo.W + xx;
-                voff = ok ? (int)((size_t)pix * KS * 128) + achunk[g] : OOB;
-            }
-            ig_dma16(xrs, base + (4 * wave + g) * 1024, voff, j * 128);
+        int voff;
+        if (TAPS == 1) {
+            voff = (aok[g] & on) ? an[g] * (KS * 128) + achunk[g] : OOB;
         } else {
-            const int g = p - 4;
-            ig_dma16(wrs, base + A_BYTES + (BG * wave + g) * 1024, bvoff[g], (tap * KS + j) * 128);
+            const int yy = ay[g] + (tap / 3 - 1) * geo.dil, xx = ax[g] + (tap % 3 - 1) * geo.dil;
+            const bool ok = aok[g] & on & ((unsigned)yy < (unsigned)geo.H) & ((unsigned)xx < (unsigned)geo.W);
+            const int pix = (an[g] * geo.H + yy) * geo.W + xx;
+            voff = ok ? pix * (KS * 128) + achunk[g] : OOB;
         }
+        ig_dma16(xrs, smem + sa * A_BYTES + (4 * wave + g) * 1024, voff, j * 128);
+    };
+    auto dma_b = [&](int kt, int sb, int g, bool on) {
+        const int j = TAPS == 1 ? kt : kt / TAPS;
+        const int tap = TAPS == 1 ? 0 : kt - j * TAPS;
+        ig_dma16(wrs, smem + NSA * A_BYTES + sb * B_BYTES + (BG * wave + g) * 1024, on ? bvoff[g] : OOB,
+                 (tap * KS + j) * 128);
     };
 
-    ig_f32x16 acc[M16 ? 1 : TM][M16 ? 1 : TN];          // 32x32 tiles
-    ig_f32x4 acc4[M16 ? 2 * TM : 1][M16 ? 4 : 1];       // 16x16 tiles (M16)
+    constexpr int NA = 2 * TM;                          // 16-row tiles of the wave tile (8 | 4 | 2); 4 column tiles
+    ig_f32x4 acc4[NA][4];
 #pragma unroll
-    for (int a = 0; a < (M16 ? 1 : TM); ++a)
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
-        for (int b = 0; b < (M16 ? 1 : TN); ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-#pragma unroll
-    for (int a = 0; a < (M16 ? 2 * TM : 1); ++a)
-#pragma unroll
-        for (int b = 0; b < (M16 ? 4 : 1); ++b) acc4[a][b] = (ig_f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < 4; ++b) acc4[a][b] = (ig_f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int erow = lane >> 3, ec8 = lane & 7;             // epilogue: lane -> (row of an 8-row group, 8-channel group)
     const int nc = n0 + wn * 64 + ec8 * 8;
@@ -223,114 +298,153 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
     constexpr bool HOIST_HI = RES && PL == 2 && TAPS == 1;   // split planes: the hi rows of the first chunk only (16 registers;
                                                             // the 3x3 variants have none to spare)
 #pragma unroll
-    for (int p = 0; p < NPIECE; ++p) piece(0, 0, p);
-    if ((dbg & 8) && wave >= 4) __builtin_amdgcn_s_setprio(1);
-    const int frow = lane & 31, fh = lane >> 5;
-    constexpr int NSLOT = KK * TM;                      // MFMA groups per k-step; the DMA pieces of the NEXT k-step
-                                                        // are issued between them, not in one burst after the barrier
+    for (int g = 0; g < 4; ++g) dma_a(0, 0, g, true);
+#pragma unroll
+    for (int g = 0; g < BG; ++g) dma_b(0, 0, g, true);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) dma_a(1, 1, g, nk > 1);
+    // Fragment addressing (LDS byte addresses for the asm reads).  Lane l holds row (l & 15), chunk 4*j + (l >> 4) of a
+    // 16-row fragment: j = 0 | 1 is the first | second 32-deep half of a bf16 slab, or the hi | lo plane of a split slab.
+    // Everything but the swizzled chunk has zero low 7 bits, so chunk j = 1 is the j = 0 address XOR 64, tile a (b) is
+    // an instruction offset of a (b) * 2 KiB.
+    const int r16 = lane & 15, kq = lane >> 4;
+    const unsigned fswz = (unsigned)((kq ^ ((r16 >> 1) & 7)) << 4);
+    const unsigned lds_base = (unsigned)(size_t)smem;
+    const unsigned fa0 = lds_base + (unsigned)((wm * (TM * 32) + r16) * 128) + fswz;
+    const unsigned fb0 = lds_base + (unsigned)(NSA * A_BYTES + (wn * 64 + r16) * 128) + fswz;
+    int sa = 0;                                          // A stage of k-step kt (kt % 3)
+#ifdef IG_STAMP
+    unsigned stamp_acc[5] = {0, 0, 0, 0, 0};
+    const unsigned stamp_begin = ig_now();
+#endif
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's share of tile kt has landed
-        __syncthreads();                                          // everyone's has; everyone left buffer buf^1
-        const bool more = kt + 1 < nk && !(dbg & 2);     // dbg: tuning experiments only (HIAST_IGEMM_DEBUG)
+        const int sb = kt & 1;
+        IG_T(t0);
+        // This wave's share of A(kt) and B(kt) has landed once all but its four youngest requests — A(kt+1) — are done
+        // (vector-memory operations complete in issue order: a k-step issues B(kt+1) before A(kt+2)); then everyone's
+        // has, and everyone has left A stage (kt+2) % 3 and B stage sb ^ 1 (last read in k-step kt-1).  A bare s_barrier:
+        // the fragment reads are asm, the DMA waits are counted by hand, and behind __syncthreads() the compiler would
+        // drain vmcnt to 0.
+        asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        IG_T(t1);
+        const int sa2 = sa == 0 ? 2 : sa - 1;             // (kt + 2) % 3
+        const bool more_b = kt + 1 < nk, more_a = kt + 2 < nk;
+        IG_T(t2);
         if (HOIST && kt == nk - 1) {
 #pragma unroll
             for (int a = 0; a < (RD < TM ? RD : TM); ++a) load_res(a);
         }
         if (HOIST_HI && kt == nk - 1) load_res(0, 1);
-        const unsigned char* ta = smem + buf * BUF_BYTES;
-        const unsigned char* tb = ta + A_BYTES;
-        if (!M16) {
-#pragma unroll
-        for (int kk = 0; kk < KK; ++kk) {
-            ig_bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-            for (int a = 0; a < TM; ++a) {
-                const int row = wm * (TM * 32) + a * 32 + frow;
-                ah[a] = *reinterpret_cast<const ig_bf16x8*>(ta + ig_lds_off(row, kk * 2 + fh));
-                if (PL == 2) al[a] = *reinterpret_cast<const ig_bf16x8*>(ta + ig_lds_off(row, 4 + kk * 2 + fh));
+        const unsigned ca = fa0 + (unsigned)(sa * A_BYTES), cb = fb0 + (unsigned)(sb * B_BYTES);
+        sa = sa == 2 ? 0 : sa + 1;
+        // B fragments of the whole k-step stay in registers (32); A fragments go through a ring of two 16-row tiles:
+        // tile a + 1 is requested during the MFMAs of tile a and waited for after them.  Everything that is not an MFMA
+        // (the next tile's reads, the DMA pieces with their address arithmetic) is issued BETWEEN the MFMAs of a tile, in
+        // the shadow of the ones already in the pipe.  The first tile starts as soon as A tile 0 and B tile 0 are there
+        // (counted lgkmcnt waits: LDS reads return in order, and the loop holds no other LGKM operation).
+        ig_bf16x8 fb[4][2], fa[2][2];
+        fa[0][0] = ig_lds_read<0>(ca);
+        fa[0][1] = ig_lds_read<0>(ca ^ 64u);
+        ig_lds_read4(fb, cb);
+        // The two waves of a SIMD (w and w + 4) share its matrix pipe and the arbiter serves the older one first: left
+        // alone, waves 0-3 ran ahead and waves 4-7 finished each k-step ~900 cycles later with the pipe 45 % busy.  The
+        // priority is handed over in the middle of the k-step, so that both finish together.
+        if (wave < 4) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+        IG_T(t3);
+#ifdef IG_STAMP
+        unsigned tile_t[NA + 1];
+#endif
+        auto mfma_col = [&](int a, int cur, int b) {
+#ifndef IG_ABL_NOMFMA
+            if (PL == 2) {      // lo*hi + hi*lo + hi*hi
+                acc4[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[cur][1], fb[b][0], acc4[a][b], 0, 0, 0);
+                acc4[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[cur][0], fb[b][1], acc4[a][b], 0, 0, 0);
+                acc4[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[cur][0], fb[b][0], acc4[a][b], 0, 0, 0);
+            } else {
+                acc4[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[cur][0], fb[b][0], acc4[a][b], 0, 0, 0);
+                acc4[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[cur][1], fb[b][1], acc4[a][b], 0, 0, 0);
             }
+#endif
+        };
 #pragma unroll
-            for (int b = 0; b < TN; ++b) {
-                const int row = wn * 64 + b * 32 + frow;
-                bh[b] = *reinterpret_cast<const ig_bf16x8*>(tb + ig_lds_off(row, kk * 2 + fh));
-                if (PL == 2) bl[b] = *reinterpret_cast<const ig_bf16x8*>(tb + ig_lds_off(row, 4 + kk * 2 + fh));
+        for (int a = 0; a < NA; ++a) {
+            const int cur = a & 1;
+#ifndef IG_FLIP8
+#define IG_FLIP8 4
+#endif
+            if (a == NA * IG_FLIP8 / 8) {
+                if (wave < 4) __builtin_amdgcn_s_setprio(0);
+                else __builtin_amdgcn_s_setprio(1);
             }
+            if (a == 0) ig_lds_wait_n<6>(fa[0], fb[0]);         // outstanding: B tiles 1..3
+            else ig_lds_wait_n<0>(fa[cur]);
+#ifdef IG_STAMP
+            tile_t[a] = ig_now();
+#endif
+            __builtin_amdgcn_sched_barrier(0);          // (the scheduler otherwise sinks MFMA groups below the next wait)
+            mfma_col(a, cur, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (a + 1 < NA) ig_lds_read_a(fa[cur ^ 1], ca, a + 1);
+            if (a == 0) ig_lds_wait_n<6>(fb[1]);                // (+ A tile 1 behind them)
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_col(a, cur, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            // DMA of the next tiles, piece by piece (the CU's texture path takes 64 B per clock: issued in one burst the
+            // eight pieces of a wave cost it ~1000 cycles without an MFMA, and the waves left the burst up to 1500
+            // cycles apart, which the barrier then waited for): first B(kt+1), which must land within this k-step,
+            // then A(kt+2).
+#ifndef IG_ABL_NODMA
 #pragma unroll
-            for (int a = 0; a < TM; ++a) {
-                constexpr int dummy = 0;
-                (void)dummy;
-                const int slot = kk * TM + a;
-                if (more) {
-#pragma unroll
-                    for (int p = 0; p < NPIECE; ++p)
-                        if (p >= slot * NPIECE / NSLOT && p < (slot + 1) * NPIECE / NSLOT) piece(kt + 1, buf ^ 1, p);
-                }
-                if (dbg & 1) continue;
-                if (dbg & 4) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int b = 0; b < TN; ++b) {
-                    if (PL == 2) {
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
-                    }
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
-                }
-                if (dbg & 4) __builtin_amdgcn_s_setprio(0);
+            for (int p = 0; p < NPIECE; ++p) {
+                if (p * NA / NPIECE != a) continue;
+                if (p < BG) dma_b(kt + 1, sb ^ 1, p, more_b);
+                else dma_a(kt + 2, sa2, p - BG, more_a);
             }
+#endif
+            if (a == 0) ig_lds_wait_n<4>(fb[2]);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_col(a, cur, 2);
+            if (a == 0) ig_lds_wait_n<2>(fb[3]);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_col(a, cur, 3);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        } else {
-            // 16x16x32: lane l holds row (l & 15), k = 32*s + 8*(l >> 4) + j of a 16-row fragment (one ds_read_b128)
-            constexpr int KS32 = PL == 2 ? 1 : 2;       // 32-deep steps per slab
-            const int r16 = lane & 15, kq = lane >> 4;
-#pragma unroll
-            for (int s32 = 0; s32 < KS32; ++s32) {
-                ig_bf16x8 ah[2 * TM], al[2 * TM], bh[4], bl[4];
-#pragma unroll
-                for (int a = 0; a < 2 * TM; ++a) {
-                    const int row = wm * (TM * 32) + a * 16 + r16;
-                    ah[a] = *reinterpret_cast<const ig_bf16x8*>(ta + ig_lds_off(row, s32 * 4 + kq));
-                    if (PL == 2) al[a] = *reinterpret_cast<const ig_bf16x8*>(ta + ig_lds_off(row, 4 + kq));
-                }
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int row = wn * 64 + b * 16 + r16;
-                    bh[b] = *reinterpret_cast<const ig_bf16x8*>(tb + ig_lds_off(row, s32 * 4 + kq));
-                    if (PL == 2) bl[b] = *reinterpret_cast<const ig_bf16x8*>(tb + ig_lds_off(row, 4 + kq));
-                }
-#pragma unroll
-                for (int a = 0; a < 2 * TM; ++a) {
-                    const int slot = s32 * 2 * TM + a;
-                    constexpr int NSLOT16 = KS32 * 2 * TM;
-                    if (more) {
-#pragma unroll
-                        for (int p = 0; p < NPIECE; ++p)
-                            if (p >= slot * NPIECE / NSLOT16 && p < (slot + 1) * NPIECE / NSLOT16) piece(kt + 1, buf ^ 1, p);
-                    }
-                    if (dbg & 1) continue;
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        if (PL == 2) {
-                            acc4[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[a], bh[b], acc4[a][b], 0, 0, 0);
-                            acc4[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[a], bl[b], acc4[a][b], 0, 0, 0);
-                        }
-                        acc4[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[a], bh[b], acc4[a][b], 0, 0, 0);
-                    }
-                }
-            }
+        IG_T(t4);
+#ifdef IG_STAMP
+        if (kt == 10 && lane == 0 && blockIdx.x + gridDim.x * blockIdx.y == 5) {      // timeline of one k-step, one block
+            unsigned* o = ig_stamp_buf + 1023 * 64 + wave * 0;                          // (block 1023's slot is unused here)
+            o = ig_stamp_buf + (1000 + wave) * 64;
+            o[0] = t0; o[1] = t1; o[2] = t3;
+            for (int a = 0; a < NA; ++a) o[3 + a] = tile_t[a];
+            o[3 + NA] = t4;
+        }
+#endif
+        IG_ACC(0, t0, t1); IG_ACC(1, t1, t2); IG_ACC(2, t2, t3); IG_ACC(3, t3, t4);
+    }
+#ifdef IG_STAMP
+    {
+        const unsigned stamp_end = ig_now();
+        const int blk = blockIdx.x + gridDim.x * blockIdx.y;
+        if (lane == 0 && blk < 1024) {
+            unsigned* o = ig_stamp_buf + (blk * 8 + wave) * 8;
+            o[0] = stamp_acc[0]; o[1] = stamp_acc[1]; o[2] = stamp_acc[2]; o[3] = stamp_acc[3];
+            o[4] = stamp_end - stamp_begin; o[5] = (unsigned)nk; o[6] = stamp_begin;
         }
     }
+#endif
 
     // ---- epilogue: each wave moves its 32 x 64 sub-tiles through a PRIVATE LDS tile (BN scale/shift applied on
     // the way in), then every lane owns 8 consecutive channels of a row: residual (+), ReLU, conversion and
     // 16-byte stores (hi and lo of a 32-channel slab together fill one 128-byte line).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the zero fills past the last k-step)
     __syncthreads();                                    // all waves are done with the operand tiles
     float* sW = reinterpret_cast<float*>(smem) + wave * (32 * EP);
-    constexpr int NCT = M16 ? 4 : TN;                   // column tiles of the wave tile (16 | 32 wide)
+    constexpr int NCT = 4;                              // 16-wide column tiles of the wave tile
     float sc[NCT], sh[NCT];
 #pragma unroll
     for (int b = 0; b < NCT; ++b) {
-        const int n = n0 + wn * 64 + (M16 ? b * 16 + (lane & 15) : b * 32 + (lane & 31));
+        const int n = n0 + wn * 64 + b * 16 + (lane & 15);
         sc[b] = 1.0f; sh[b] = 0.0f;
         if (mean) {
             const float invstd = 1.0f / sqrtf(var[n] + eps);
@@ -350,24 +464,15 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
         if (RES && a + RD < TM) load_res(a + RD);
         uint4 (&rh)[4] = rhA[a];
         uint4 (&rl4)[4] = rlA[a];
-        if (!M16) {
+        // 16x16 tiles: column = lane & 15, rows 4*(lane >> 4) + r
 #pragma unroll
-            for (int b = 0; b < TN; ++b)
+        for (int ta2 = 0; ta2 < 2; ++ta2)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rl = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    sW[rl * EP + b * 32 + (lane & 31)] = fmaf(acc[M16 ? 0 : a][M16 ? 0 : b][r], sc[b], sh[b]);
-                }
-        } else {         // 16x16 tiles: column = lane & 15, rows 4*(lane >> 4) + r
+            for (int b = 0; b < 4; ++b)
 #pragma unroll
-            for (int ta2 = 0; ta2 < 2; ++ta2)
-#pragma unroll
-                for (int b = 0; b < 4; ++b)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        sW[(ta2 * 16 + 4 * (lane >> 4) + r) * EP + b * 16 + (lane & 15)] =
-                            fmaf(acc4[M16 ? 2 * a + ta2 : 0][M16 ? b : 0][r], sc[M16 ? b : 0], sh[M16 ? b : 0]);
-        }
+                for (int r = 0; r < 4; ++r)
+                    sW[(ta2 * 16 + 4 * (lane >> 4) + r) * EP + b * 16 + (lane & 15)] =
+                        fmaf(acc4[2 * a + ta2][b][r], sc[b], sh[b]);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -654,10 +759,6 @@ static int launch_igemm_t(const void* x, const void* wp, const float* gamma, con
                           const float* var, float eps, const void* res, int relu, void* y, int64_t M, int K, int N,
                           int taps, hiast::IGeo geo, float* stats, const void* res_gate, int gate_mask, hipStream_t st)
 {
-    int dbg = 0;
-    if (const char* env = getenv("HIAST_IGEMM_DEBUG")) dbg = atoi(env);
-    bool m16 = true;       // measured 4-10 % faster than 32x32x16 on every trunk shape (tools/bench_kernels.py igemm)
-    if (const char* env = getenv("HIAST_IGEMM_MFMA16")) m16 = atoi(env) != 0;
     int BN = (N % 256 == 0) ? 256 : ((N % 128 == 0) ? 128 : 64);
     if (const char* env = getenv("HIAST_IGEMM_BN")) {          // tuning override
         const int v = atoi(env);
@@ -666,18 +767,18 @@ static int launch_igemm_t(const void* x, const void* wp, const float* gamma, con
     dim3 grid((unsigned)((M + hiast::IG_BM - 1) / hiast::IG_BM), N / BN);
     const int gate = !res_gate ? 0 : (gate_mask ? 2 : 1);
 #define L(BNV, T, RES, RELU, G)                                                                                      \
-    hipLaunchKernelGGL((hiast::igemm_bn_act_kernel<PL, OUTF32, BNV, T, RES, RELU, MF, G>), grid, dim3(512), 0, st,    \
+    hipLaunchKernelGGL((hiast::igemm_bn_act_kernel<PL, OUTF32, BNV, T, RES, RELU, G>), grid, dim3(512), 0, st,    \
                        (const unsigned short*)x, (const unsigned short*)wp, gamma, beta, mean, var, eps,              \
-                       (const unsigned short*)res, y, (int)M, K, N, geo, dbg, stats, (const unsigned short*)res_gate)
+                       (const unsigned short*)res, y, (int)M, K, N, geo, stats, (const unsigned short*)res_gate)
 #define LG(BNV, T)                                                                      \
     if constexpr (PL == 1 && !OUTF32) {                                                 \
         if (gate == 1) L(BNV, T, true, false, 1); else L(BNV, T, true, false, 2);       \
     }
 #define LS(BNV, T)                                                                      \
     if constexpr (PL == 1 && !OUTF32) {                                                 \
-        hipLaunchKernelGGL((hiast::igemm_bn_act_kernel<PL, OUTF32, BNV, T, false, false, MF, 0, true>), grid, dim3(512), 0, st, \
+        hipLaunchKernelGGL((hiast::igemm_bn_act_kernel<PL, OUTF32, BNV, T, false, false, 0, true>), grid, dim3(512), 0, st, \
                            (const unsigned short*)x, (const unsigned short*)wp, gamma, beta, mean, var, eps,                     \
-                           (const unsigned short*)res, y, (int)M, K, N, geo, dbg, stats, (const unsigned short*)res_gate);       \
+                           (const unsigned short*)res, y, (int)M, K, N, geo, stats, (const unsigned short*)res_gate);       \
     }
 #define LL(BNV, T)                                                                      \
     if (res) {                                                                          \
@@ -690,13 +791,7 @@ static int launch_igemm_t(const void* x, const void* wp, const float* gamma, con
 #define LLL                                                                                                 \
     if (taps == 1) { if (BN == 256) { LL(256, 1) } else if (BN == 128) { LL(128, 1) } else { LL(64, 1) } }  \
     else { if (BN == 256) { LL(256, 9) } else if (BN == 128) { LL(128, 9) } else { LL(64, 9) } }
-    if (m16) {
-        constexpr bool MF = true;
-        LLL
-    } else {
-        constexpr bool MF = false;
-        LLL
-    }
+    LLL
 #undef LLL
 #undef LL
 #undef LS
@@ -761,6 +856,20 @@ extern "C" int hiast_igemm_bn_act(const void* x, const void* wp, const float* ga
     return hiast_igemm_launch(x, wp, gamma, beta, mean, var, eps, res, relu, y, (int64_t)B * Ho * Wo, Cin, Cout, taps, H,
                               W, stride, dil, planes, out_f32, (hipStream_t)stream, stats, res_gate, gate_mask);
 }
+
+#ifdef IG_STAMP
+namespace hiast {
+__global__ void ig_stamp_copy_kernel(unsigned* dst)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 1024 * 8 * 8; i += gridDim.x * blockDim.x) dst[i] = ig_stamp_buf[i];
+}
+}  // namespace hiast
+extern "C" int hiast_igemm_debug_stamps(unsigned* dst_device)
+{
+    hipLaunchKernelGGL(hiast::ig_stamp_copy_kernel, dim3(64), dim3(256), 0, 0, dst_device);
+    return (int)hipDeviceSynchronize();
+}
+#endif
 
 extern "C" int hiast_igemm_stats_rows(int64_t M, int Cin, int Cout, int taps, int planes)
 {
