@@ -20,6 +20,27 @@
 namespace hiast {
 
 constexpr int BNH_MAXBLK = 512;
+// Launch geometry of the elementwise passes (round 2, measured per shape with rocprofv3 on tools/ab_bn.py against torch's
+// copy / add kernels on the same tensors): rows per thread whose loads are all issued before the first is used, rows a
+// block covers per pass, block cap.  What mattered was the block prologue, not the loads in flight: the per-channel
+// parameters were 32 scalar loads behind branches on the nullable gamma / beta, waited for BEFORE the first row was
+// requested — every block began with two serial memory round trips.  Rows first, parameters as 16-byte loads behind
+// them: 256-channel maps 23-32 -> 12-18 us, 1024-channel maps 60-111 -> 42-78 us (torch add: 69 us).
+#ifndef BNH_ROWS_PER_BLOCK_PASS
+#define BNH_ROWS_PER_BLOCK_PASS 16
+#endif
+#ifndef BNH_APPLY_MAXBLK
+#define BNH_APPLY_MAXBLK 65535
+#endif
+#ifndef BNH_UNR_PART
+#define BNH_UNR_PART 8
+#endif
+#ifndef BNH_UNR_APPLY
+#define BNH_UNR_APPLY 4
+#endif
+#ifndef BNH_UNR_BWD
+#define BNH_UNR_BWD 4
+#endif
 
 __device__ __forceinline__ void bnh_unpack8(const uint4 r, float (&v)[8])
 {
@@ -34,6 +55,16 @@ __device__ __forceinline__ void bnh_unpack8(const uint4 r, float (&v)[8])
 __device__ __forceinline__ void bnh_load8(const unsigned short* p, float (&v)[8])
 {
     bnh_unpack8(*reinterpret_cast<const uint4*>(p), v);
+}
+
+// 8 consecutive per-channel floats as two 16-byte loads; p == nullptr -> the constant dflt (selected, not branched on)
+__device__ __forceinline__ void bnh_param8(const float* p, const float* some_valid, int c0, float dflt, float (&v)[8])
+{
+    const float* q = (p ? p : some_valid) + c0;
+    const float4 a = *reinterpret_cast<const float4*>(q), b = *reinterpret_cast<const float4*>(q + 4);
+    const bool has = p != nullptr;
+    v[0] = has ? a.x : dflt; v[1] = has ? a.y : dflt; v[2] = has ? a.z : dflt; v[3] = has ? a.w : dflt;
+    v[4] = has ? b.x : dflt; v[5] = has ? b.y : dflt; v[6] = has ? b.z : dflt; v[7] = has ? b.w : dflt;
 }
 
 __device__ __forceinline__ void bnh_store8(unsigned short* p, const float (&v)[8])
@@ -67,26 +98,22 @@ __global__ __launch_bounds__(256) void bnh_partial_kernel(const unsigned short* 
     const int cg = threadIdx.x % G, rsub = threadIdx.x / G;
     float s1[8], s2[8], mean[8], invstd[8], gsc[8], gsh[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        s1[k] = 0.f; s2[k] = 0.f;
-        mean[k] = BWD ? save_mean[cg * 8 + k] : 0.f;
-        invstd[k] = BWD ? save_invstd[cg * 8 + k] : 0.f;
-        gsc[k] = GATE == 2 ? (gamma ? gamma[cg * 8 + k] : 1.0f) * invstd[k] : 0.f;
-        gsh[k] = GATE == 2 ? fmaf(-mean[k], gsc[k], beta ? beta[cg * 8 + k] : 0.0f) : 0.f;
-    }
-    // UNR rows per thread in flight: with at most BNH_MAXBLK blocks (the partial array and its finalize pass scale with
-    // the block count) one row per iteration left 16 KiB of loads in flight per CU and the pass ran at 2.1-2.6 TB/s;
-    // all loads of UNR rows are issued before the first is used.  The rows are still accumulated in ascending order,
-    // so the sums are bit-identical to the one-row loop.
-    constexpr int UNR = 4;
-    const long long stride = (long long)gridDim.x * RPP;
-    for (long long r0 = (long long)blockIdx.x * RPP + rsub; r0 < M; r0 += stride * UNR) {
-        uint4 ra[UNR], ry[UNR], rx[UNR];
-        unsigned rbits[UNR];
+    for (int k = 0; k < 8; ++k) { s1[k] = 0.f; s2[k] = 0.f; mean[k] = 0.f; invstd[k] = 0.f; gsc[k] = 0.f; gsh[k] = 0.f; }
+    // UNR rows per thread in flight (all loads of a chunk are issued before the first is used); a block walks chunks of
+    // UNR * RPP consecutive rows.  The rows of the FIRST chunk are requested before the per-channel parameters: both
+    // round trips then overlap (with the parameters first, every block started with one exposed latency).  The rows are
+    // accumulated in ascending order within a thread.
+    constexpr int UNR = BNH_UNR_PART;
+    const long long stride = RPP;
+    const long long step = (long long)gridDim.x * (RPP * UNR);
+    long long r0 = (long long)blockIdx.x * (RPP * UNR) + rsub;
+    uint4 ra[UNR], ry[UNR], rx[UNR];
+    unsigned rbits[UNR];
+    auto load_rows = [&](long long rb) {
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            const long long r = r0 + u * stride;
-            const long long rc = r < M ? r : r0;                    // tail: re-read a valid row, not accumulated
+            const long long r = rb + u * stride;
+            const long long rc = r < M ? r : (rb < M ? rb : 0);     // tail: re-read a valid row, not accumulated
             const size_t off = (size_t)rc * C + cg * 8;
             ra[u] = *reinterpret_cast<const uint4*>(a + off);
             if (BWD) {
@@ -95,6 +122,23 @@ __global__ __launch_bounds__(256) void bnh_partial_kernel(const unsigned short* 
                 rx[u] = *reinterpret_cast<const uint4*>(x + off);
             }
         }
+    };
+    load_rows(r0);
+    if (BWD) {
+        float gm[8], bt[8];
+        bnh_param8(save_mean, save_mean, cg * 8, 0.f, mean);
+        bnh_param8(save_invstd, save_mean, cg * 8, 0.f, invstd);
+        if (GATE == 2) {
+            bnh_param8(gamma, save_mean, cg * 8, 1.0f, gm);
+            bnh_param8(beta, save_mean, cg * 8, 0.0f, bt);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                gsc[k] = gm[k] * invstd[k];
+                gsh[k] = fmaf(-mean[k], gsc[k], bt[k]);
+            }
+        }
+    }
+    while (r0 < M) {
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             if (r0 + u * stride >= M) break;
@@ -118,6 +162,8 @@ __global__ __launch_bounds__(256) void bnh_partial_kernel(const unsigned short* 
                 }
             }
         }
+        r0 += step;
+        if (r0 < M) load_rows(r0);
     }
     // fold the RPP row-subsets of each channel group (fixed order)
 #pragma unroll
@@ -230,25 +276,36 @@ __global__ __launch_bounds__(256) void bnh_apply_kernel(const unsigned short* __
 {
     const int G = C >> 3, RPP = 256 / G;
     const int cg = threadIdx.x % G, rsub = threadIdx.x / G;
-    float scale[8], shift[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int c = cg * 8 + k;
-        scale[k] = (gamma ? gamma[c] : 1.0f) * save_invstd[c];
-        shift[k] = fmaf(-save_mean[c], scale[k], beta ? beta[c] : 0.0f);
-    }
-    // two rows per thread in flight (all loads first): the 256-channel maps run 4 blocks per CU
-    constexpr int UNR = 2;
-    const long long stride = (long long)gridDim.x * RPP;
-    for (long long r0 = (long long)blockIdx.x * RPP + rsub; r0 < M; r0 += stride * UNR) {
-        uint4 rx[UNR], rres[UNR];
+    // rows of the first chunk are requested before the per-channel parameters (see bnh_partial_kernel)
+    constexpr int UNR = BNH_UNR_APPLY;
+    const long long stride = RPP;
+    const long long step = (long long)gridDim.x * (RPP * UNR);
+    long long r0 = (long long)blockIdx.x * (RPP * UNR) + rsub;
+    uint4 rx[UNR], rres[UNR];
+    auto load_rows = [&](long long rb) {
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            const long long r = r0 + u * stride;
-            const size_t off = (size_t)(r < M ? r : r0) * C + cg * 8;
+            const long long r = rb + u * stride;
+            const size_t off = (size_t)(r < M ? r : (rb < M ? rb : 0)) * C + cg * 8;
             rx[u] = *reinterpret_cast<const uint4*>(x + off);
             if (RES) rres[u] = *reinterpret_cast<const uint4*>(res + off);
         }
+    };
+    load_rows(r0);
+    float scale[8], shift[8];
+    {
+        float gm[8], bt[8], mn[8], is[8];
+        bnh_param8(gamma, save_mean, cg * 8, 1.0f, gm);
+        bnh_param8(beta, save_mean, cg * 8, 0.0f, bt);
+        bnh_param8(save_mean, save_mean, cg * 8, 0.f, mn);
+        bnh_param8(save_invstd, save_mean, cg * 8, 0.f, is);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            scale[k] = gm[k] * is[k];
+            shift[k] = fmaf(-mn[k], scale[k], bt[k]);
+        }
+    }
+    while (r0 < M) {
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const long long r = r0 + u * stride;
@@ -269,6 +326,8 @@ __global__ __launch_bounds__(256) void bnh_apply_kernel(const unsigned short* __
             bnh_store8(y + off, v);
             if (mask) mask[(size_t)r * G + cg] = (unsigned char)bits;
         }
+        r0 += step;
+        if (r0 < M) load_rows(r0);
     }
 }
 
@@ -282,37 +341,48 @@ __global__ __launch_bounds__(256) void bnh_bwd_apply_kernel(
 {
     const int G = C >> 3, RPP = 256 / G;
     const int cg = threadIdx.x % G, rsub = threadIdx.x / G;
-    float mean[8], invstd[8], k0[8], mg[8], mgx[8], gsh[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int c = cg * 8 + k;
-        const double s1 = sums[2 * c], s2 = sums[2 * c + 1];
-        if (blockIdx.x == 0 && rsub == 0) {
-            if (dbeta) dbeta[c] = (float)s1;
-            if (dgamma) dgamma[c] = (float)s2;
-        }
-        mean[k] = save_mean[c];
-        invstd[k] = save_invstd[c];
-        k0[k] = (gamma ? gamma[c] : 1.0f) * invstd[k];
-        gsh[k] = GATE == 2 ? fmaf(-mean[k], k0[k], beta ? beta[c] : 0.0f) : 0.f;
-        mg[k] = (float)(s1 * inv_count);
-        mgx[k] = (float)(s2 * inv_count);
-    }
-    constexpr int UNR = 2;                               // two rows per thread in flight (all loads first)
-    const long long stride = (long long)gridDim.x * RPP;
-    for (long long r0 = (long long)blockIdx.x * RPP + rsub; r0 < M; r0 += stride * UNR) {
-        uint4 rg[UNR], ry[UNR], rx[UNR];
-        unsigned rbits[UNR];
+    // rows of the first chunk are requested before the per-channel parameters (see bnh_partial_kernel)
+    constexpr int UNR = BNH_UNR_BWD;
+    const long long stride = RPP;
+    const long long step = (long long)gridDim.x * (RPP * UNR);
+    long long r0 = (long long)blockIdx.x * (RPP * UNR) + rsub;
+    uint4 rg[UNR], ry[UNR], rx[UNR];
+    unsigned rbits[UNR];
+    auto load_rows = [&](long long rb) {
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            const long long r = r0 + u * stride;
-            const long long rc = r < M ? r : r0;
+            const long long r = rb + u * stride;
+            const long long rc = r < M ? r : (rb < M ? rb : 0);
             const size_t off = (size_t)rc * C + cg * 8;
             rg[u] = *reinterpret_cast<const uint4*>(dy + off);
             if (GATE == 1) ry[u] = *reinterpret_cast<const uint4*>(y + off);
             rbits[u] = GATE == 3 ? reinterpret_cast<const unsigned char*>(y)[(size_t)rc * G + cg] : 0u;
             rx[u] = *reinterpret_cast<const uint4*>(x + off);
         }
+    };
+    load_rows(r0);
+    float mean[8], invstd[8], k0[8], mg[8], mgx[8], gsh[8];
+    {
+        float gm[8], bt[8];
+        bnh_param8(save_mean, save_mean, cg * 8, 0.f, mean);
+        bnh_param8(save_invstd, save_mean, cg * 8, 0.f, invstd);
+        bnh_param8(gamma, save_mean, cg * 8, 1.0f, gm);
+        bnh_param8(beta, save_mean, cg * 8, 0.0f, bt);
+        const double2* sp = reinterpret_cast<const double2*>(sums) + cg * 8;       // (Σg, Σ g*xhat) per channel
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const double2 ss = sp[k];
+            if (blockIdx.x == 0 && rsub == 0) {
+                if (dbeta) dbeta[cg * 8 + k] = (float)ss.x;
+                if (dgamma) dgamma[cg * 8 + k] = (float)ss.y;
+            }
+            k0[k] = gm[k] * invstd[k];
+            gsh[k] = GATE == 2 ? fmaf(-mean[k], k0[k], bt[k]) : 0.f;
+            mg[k] = (float)(ss.x * inv_count);
+            mgx[k] = (float)(ss.y * inv_count);
+        }
+    }
+    while (r0 < M) {
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const long long r = r0 + u * stride;
@@ -334,6 +404,8 @@ __global__ __launch_bounds__(256) void bnh_bwd_apply_kernel(
             bnh_store8(dx + off, xx);
             if (DRES) bnh_store8(dres + off, g);
         }
+        r0 += step;
+        if (r0 < M) load_rows(r0);
     }
 }
 
@@ -398,8 +470,8 @@ extern "C" int hiast_bn_nhwc_apply(const void* x, const void* res, void* y, cons
     if (!y || !sums || !save_mean || !save_invstd || count <= 0) return HIAST_E_ARG;
     if ((((uintptr_t)y) | ((uintptr_t)res)) & 15) return HIAST_E_RANGE;
     const int rpp = 256 / (C / 8);
-    long long nb = (M + (long long)rpp * 8 - 1) / ((long long)rpp * 8);      // >= 8 rows per thread (4: more blocks, each paying the scale/shift prologue - slower)
-    nb = nb < 1 ? 1 : (nb > 2048 ? 2048 : nb);
+    long long nb = (M + (long long)rpp * BNH_ROWS_PER_BLOCK_PASS - 1) / ((long long)rpp * BNH_ROWS_PER_BLOCK_PASS);
+    nb = nb < 1 ? 1 : (nb > BNH_APPLY_MAXBLK ? BNH_APPLY_MAXBLK : nb);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(hiast::bnh_prep_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, count, momentum, eps,
                        running_mean, running_var, save_mean, save_invstd, C);
@@ -427,8 +499,8 @@ extern "C" int hiast_bn_nhwc_apply_partial(const void* x, const void* res, void*
     if (!y || !partial || !save_mean || !save_invstd || count <= 0 || nblk <= 0) return HIAST_E_ARG;
     if ((((uintptr_t)y) | ((uintptr_t)res)) & 15) return HIAST_E_RANGE;
     const int rpp = 256 / (C / 8);
-    long long nb = (M + (long long)rpp * 8 - 1) / ((long long)rpp * 8);
-    nb = nb < 1 ? 1 : (nb > 2048 ? 2048 : nb);
+    long long nb = (M + (long long)rpp * BNH_ROWS_PER_BLOCK_PASS - 1) / ((long long)rpp * BNH_ROWS_PER_BLOCK_PASS);
+    nb = nb < 1 ? 1 : (nb > BNH_APPLY_MAXBLK ? BNH_APPLY_MAXBLK : nb);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(hiast::bnh_finalize_prep_kernel, dim3(C * 2 / 16), dim3(256), 0, st, partial, nblk, C, count,
                        momentum, eps, running_mean, running_var, save_mean, save_invstd);
@@ -483,8 +555,8 @@ extern "C" int hiast_bn_nhwc_bwd_apply(const void* dy, const void* y, const void
         (relu == 1 && (((uintptr_t)y) & 15)))
         return HIAST_E_RANGE;
     const int rpp = 256 / (C / 8);
-    long long nb = (M + (long long)rpp * 8 - 1) / ((long long)rpp * 8);
-    nb = nb < 1 ? 1 : (nb > 2048 ? 2048 : nb);
+    long long nb = (M + (long long)rpp * BNH_ROWS_PER_BLOCK_PASS - 1) / ((long long)rpp * BNH_ROWS_PER_BLOCK_PASS);
+    nb = nb < 1 ? 1 : (nb > BNH_APPLY_MAXBLK ? BNH_APPLY_MAXBLK : nb);
     hipStream_t st = (hipStream_t)stream;
 #define L(G, DRES)                                                                                                 \
     hipLaunchKernelGGL((hiast::bnh_bwd_apply_kernel<G, DRES>), dim3((unsigned)nb), dim3(256), 0, st,                \
