@@ -294,9 +294,23 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
     // The first RD chunks are requested during the LAST k-step of the main loop: the block's epilogue no longer starts
     // with an exposed HBM round trip (four such rounds per CU on the 256->1024 shapes).  One plane only: with split
     // planes (and with a value gate) the 32 extra live registers spill inside the main loop.
-    constexpr bool HOIST = RES && PL == 1 && GATE != 1;
+    constexpr bool HOIST = RES && PL == 1 && GATE != 1 && !(GATE == 2 && TAPS == 9);   // (3x3 + bit gate: no registers left)
     constexpr bool HOIST_HI = RES && PL == 2 && TAPS == 1;   // split planes: the hi rows of the first chunk only (16 registers;
                                                             // the 3x3 variants have none to spare)
+    // BatchNorm(eval) scale / shift of this lane's accumulator columns: fetched BEFORE the main loop (as the first thing
+    // of the epilogue they cost every block an exposed memory round trip)
+    constexpr int NCT = 4;                              // 16-wide column tiles of the wave tile
+    float sc[NCT], sh[NCT];
+#pragma unroll
+    for (int b = 0; b < NCT; ++b) {
+        const int n = n0 + wn * 64 + b * 16 + (lane & 15);
+        sc[b] = 1.0f; sh[b] = 0.0f;
+        if (GATE == 0 && !STATS && mean) {              // (the gradient / statistics variants are launched without BN)
+            const float invstd = 1.0f / sqrtf(var[n] + eps);
+            sc[b] = (gamma ? gamma[n] : 1.0f) * invstd;
+            sh[b] = fmaf(-mean[n], sc[b], beta ? beta[n] : 0.0f);
+        }
+    }
 #pragma unroll
     for (int g = 0; g < 4; ++g) dma_a(0, 0, g, true);
 #pragma unroll
@@ -440,18 +454,6 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the zero fills past the last k-step)
     __syncthreads();                                    // all waves are done with the operand tiles
     float* sW = reinterpret_cast<float*>(smem) + wave * (32 * EP);
-    constexpr int NCT = 4;                              // 16-wide column tiles of the wave tile
-    float sc[NCT], sh[NCT];
-#pragma unroll
-    for (int b = 0; b < NCT; ++b) {
-        const int n = n0 + wn * 64 + b * 16 + (lane & 15);
-        sc[b] = 1.0f; sh[b] = 0.0f;
-        if (mean) {
-            const float invstd = 1.0f / sqrtf(var[n] + eps);
-            sc[b] = (gamma ? gamma[n] : 1.0f) * invstd;
-            sh[b] = fmaf(-mean[n], sc[b], beta ? beta[n] : 0.0f);
-        }
-    }
     float st1[8], st2[8];                               // BatchNorm statistics of this lane's 8 channels (if asked for)
 #pragma unroll
     for (int q = 0; q < 8; ++q) { st1[q] = 0.f; st2[q] = 0.f; }
@@ -816,6 +818,7 @@ int hiast_igemm_launch(const void* x, const void* wp, const float* gamma, const 
                        float* stats, const void* res_gate, int gate_mask)
 {
     if (stats && (planes != 1 || out_f32 || res || relu)) return HIAST_E_RANGE;
+    if ((stats || res_gate) && mean) return HIAST_E_RANGE;       // the statistics / gradient variants carry no BatchNorm
     if (res_gate && (planes != 1 || !res || relu || out_f32 || (!gate_mask && (((uintptr_t)res_gate) & 15)))) return HIAST_E_RANGE;
     if (!x || !wp || !y || (mean && !var)) return HIAST_E_ARG;
     if (M <= 0 || K <= 0 || N <= 0) return HIAST_E_ARG;
