@@ -196,8 +196,17 @@ __global__ __launch_bounds__(256) void bnh_finalize_kernel(const float* __restri
     const int e = threadIdx.x & 15, j = threadIdx.x >> 4;
     const int i = blockIdx.x * 16 + e;                   // C*2 is a multiple of 16
     double acc = 0.0;
-#pragma unroll 4
-    for (int b = j; b < nblk; b += 16) acc += (double)partial[(size_t)b * C * 2 + i];
+    {   // sixteen rows in flight (a latency chain: with four the launch took 12 us for 2 MB), added in ascending order
+        int b = j;
+        for (; b + 16 * 15 < nblk; b += 16 * 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = partial[(size_t)(b + 16 * u) * C * 2 + i];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc += (double)v[u];
+        }
+        for (; b < nblk; b += 16) acc += (double)partial[(size_t)b * C * 2 + i];
+    }
     s[j][e] = acc;
     __syncthreads();
     if (j == 0) {
@@ -242,8 +251,17 @@ __global__ __launch_bounds__(256) void bnh_finalize_prep_kernel(const float* __r
     const int e = threadIdx.x & 15, j = threadIdx.x >> 4;
     const int i = blockIdx.x * 16 + e;
     double acc = 0.0;
-#pragma unroll 4
-    for (int b = j; b < nblk; b += 16) acc += (double)partial[(size_t)b * C * 2 + i];
+    {   // sixteen rows in flight (a latency chain: with four the launch took 12 us for 2 MB), added in ascending order
+        int b = j;
+        for (; b + 16 * 15 < nblk; b += 16 * 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = partial[(size_t)(b + 16 * u) * C * 2 + i];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc += (double)v[u];
+        }
+        for (; b < nblk; b += 16) acc += (double)partial[(size_t)b * C * 2 + i];
+    }
     s[j][e] = acc;
     __syncthreads();
     if (j == 0 && (e & 1) == 0) {

@@ -50,7 +50,7 @@ typedef __attribute__((ext_vector_type(4))) float ig_f32x4;
 constexpr int IG_BM = 256;
 
 #ifdef IG_STAMP       // diagnostic build (tools/igemm_stamps.py): cycles a wave spends in the parts of a k-step, summed over the loop
-__device__ unsigned ig_stamp_buf[1024 * 8 * 8];
+__device__ unsigned ig_stamp_buf[1024 * 8 * 8 + 32 * 64];
 __device__ __forceinline__ unsigned ig_now()
 {
     unsigned long long t;
@@ -186,6 +186,7 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
+    IG_T(stamp_kernel);
     int bm, bn_;
     {   // XCD-aware tile order (see conv1x1.hip): channel tile fastest, XCD k takes the k-th contiguous eighth
         const int gx = gridDim.x, gy = gridDim.y, total = gx * gy;
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
 #ifdef IG_STAMP
         if (kt == 10 && lane == 0 && blockIdx.x + gridDim.x * blockIdx.y == 5) {      // timeline of one k-step, one block
             unsigned* o = ig_stamp_buf + 1023 * 64 + wave * 0;                          // (block 1023's slot is unused here)
-            o = ig_stamp_buf + (1000 + wave) * 64;
+            o = ig_stamp_buf + (1024 + wave) * 64;
             o[0] = t0; o[1] = t1; o[2] = t3;
             for (int a = 0; a < NA; ++a) o[3 + a] = tile_t[a];
             o[3 + NA] = t4;
@@ -453,6 +454,10 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
     // 16-byte stores (hi and lo of a 32-channel slab together fill one 128-byte line).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the zero fills past the last k-step)
     __syncthreads();                                    // all waves are done with the operand tiles
+    IG_T(stamp_epi);
+#ifdef IG_STAMP
+    unsigned chunk_t[TM];
+#endif
     float* sW = reinterpret_cast<float*>(smem) + wave * (32 * EP);
     float st1[8], st2[8];                               // BatchNorm statistics of this lane's 8 channels (if asked for)
 #pragma unroll
@@ -545,7 +550,21 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef IG_STAMP
+        chunk_t[a] = ig_now();
+#endif
     }
+#ifdef IG_STAMP
+    {
+        const int blk = blockIdx.x + gridDim.x * blockIdx.y;
+        if (lane == 0 && (blk == 5 || blk == 600)) {
+            unsigned* o = ig_stamp_buf + (1032 + (blk == 600 ? 8 : 0) + wave) * 64;
+            o[0] = stamp_kernel; o[1] = stamp_begin; o[2] = stamp_epi;
+            for (int a = 0; a < TM; ++a) o[3 + a] = chunk_t[a];
+            o[3 + TM] = ig_now();
+        }
+    }
+#endif
     if (STATS) {
         // fold the 8 row-lanes of each channel group (lane bits 3..5), then the WM waves that share these columns
         // (fixed order), and store this block's partial sums: the BN forward then needs no pass over Y for them
@@ -864,7 +883,7 @@ extern "C" int hiast_igemm_bn_act(const void* x, const void* wp, const float* ga
 namespace hiast {
 __global__ void ig_stamp_copy_kernel(unsigned* dst)
 {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 1024 * 8 * 8; i += gridDim.x * blockDim.x) dst[i] = ig_stamp_buf[i];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 1024 * 8 * 8 + 32 * 64; i += gridDim.x * blockDim.x) dst[i] = ig_stamp_buf[i];
 }
 }  // namespace hiast
 extern "C" int hiast_igemm_debug_stamps(unsigned* dst_device)
