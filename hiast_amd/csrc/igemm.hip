@@ -158,8 +158,12 @@ __device__ __forceinline__ size_t ig_elem(size_t m, int c, int C)
 // is > 0; 2 = where bit (n & 7) of byte Rg[m][n / 8] is set.  A compile-time switch: as a run-time test on Rg the
 // gate put ~500 branches and ~300 s_waitcnt into the epilogue of EVERY bf16 residual launch (the teacher forward
 // included), which serialised its residual prefetch.
-// STATS: emit the per-block BatchNorm sums (plain bf16 launches only: the student forward).
-template <int PL, bool OUTF32, int BN, int TAPS, bool RES, bool RELU, int GATE = 0, bool STATS = false>
+// STATS (plain bf16 launches only): 1 = emit the per-block BatchNorm sums Σy, Σy² of the stored outputs (the student
+// forward: the BN that follows needs no pass over Y for its statistics); 2 = data-gradient launch whose output dA is the
+// gradient of a BN + ReLU activation A = relu(bn(x)): emit the per-block sums Σg, Σ g*xhat of that BN's backward
+// (g = dA where bn(x) > 0; x is passed as R, its batch mean / invstd as mean / var, gamma / beta as themselves) — the
+// BatchNorm backward then skips its statistics pass (one read of dA and x per layer).
+template <int PL, bool OUTF32, int BN, int TAPS, bool RES, bool RELU, int GATE = 0, int STATS = 0>
 __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
     const unsigned short* __restrict__ X, const unsigned short* __restrict__ Wp, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ var, float eps,
@@ -169,7 +173,8 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
 {
     static_assert(GATE == 0 || (PL == 1 && RES && !RELU && !OUTF32), "gated residual: bf16 data-gradient launches only");
     constexpr int WN = BN / 64, WM = 8 / WN;
-    static_assert(!STATS || (PL == 1 && !OUTF32 && !RES && !RELU), "statistics epilogue: plain bf16 launches only");
+    static_assert(!STATS || (PL == 1 && !OUTF32 && !RES && !RELU && GATE == 0), "statistics epilogue: plain bf16 launches only");
+    constexpr bool XROWS = RES || STATS == 2;           // the epilogue reads rows of R (residual | BN input)
     constexpr int TM = IG_BM / WM / 32;                 // 32-row tiles per wave (4 | 2 | 1)
     constexpr int A_BYTES = IG_BM * 128, B_BYTES = BN * 128;
     // LDS: THREE stages of the activation tile and TWO of the weight tile (160 KiB at BN = 256).  The fill rate of a tile
@@ -295,7 +300,7 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
     // The first RD chunks are requested during the LAST k-step of the main loop: the block's epilogue no longer starts
     // with an exposed HBM round trip (four such rounds per CU on the 256->1024 shapes).  One plane only: with split
     // planes (and with a value gate) the 32 extra live registers spill inside the main loop.
-    constexpr bool HOIST = RES && PL == 1 && GATE != 1 && !(GATE == 2 && TAPS == 9);   // (3x3 + bit gate: no registers left)
+    constexpr bool HOIST = XROWS && PL == 1 && GATE != 1 && !((GATE == 2 || STATS == 2) && TAPS == 9);   // (3x3 + bit gate: no registers left)
     constexpr bool HOIST_HI = RES && PL == 2 && TAPS == 1;   // split planes: the hi rows of the first chunk only (16 registers;
                                                             // the 3x3 variants have none to spare)
     // BatchNorm(eval) scale / shift of this lane's accumulator columns: fetched BEFORE the main loop (as the first thing
@@ -462,13 +467,32 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
     float st1[8], st2[8];                               // BatchNorm statistics of this lane's 8 channels (if asked for)
 #pragma unroll
     for (int q = 0; q < 8; ++q) { st1[q] = 0.f; st2[q] = 0.f; }
-    if (RES && !HOIST) {
+    if (XROWS && !HOIST) {
 #pragma unroll
         for (int a = 0; a < (RD < TM ? RD : TM); ++a) load_res(a, (HOIST_HI && a == 0) ? 2 : 0);
     }
+    float bmean[8], binv[8], bgsc[8], bgsh[8];          // STATS == 2: this lane's 8 channels of the BN whose gradient this is
+    if (STATS == 2) {
+        const float4 m0_ = *reinterpret_cast<const float4*>(mean + nc), m1_ = *reinterpret_cast<const float4*>(mean + nc + 4);
+        const float4 i0_ = *reinterpret_cast<const float4*>(var + nc), i1_ = *reinterpret_cast<const float4*>(var + nc + 4);
+        const float* gp = gamma ? gamma : mean;
+        const float* bp = beta ? beta : mean;
+        const float4 g0_ = *reinterpret_cast<const float4*>(gp + nc), g1_ = *reinterpret_cast<const float4*>(gp + nc + 4);
+        const float4 b0_ = *reinterpret_cast<const float4*>(bp + nc), b1_ = *reinterpret_cast<const float4*>(bp + nc + 4);
+        const float mm[8] = {m0_.x, m0_.y, m0_.z, m0_.w, m1_.x, m1_.y, m1_.z, m1_.w};
+        const float ii[8] = {i0_.x, i0_.y, i0_.z, i0_.w, i1_.x, i1_.y, i1_.z, i1_.w};
+        const float gg[8] = {g0_.x, g0_.y, g0_.z, g0_.w, g1_.x, g1_.y, g1_.z, g1_.w};
+        const float bb[8] = {b0_.x, b0_.y, b0_.z, b0_.w, b1_.x, b1_.y, b1_.z, b1_.w};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            bmean[q] = mm[q]; binv[q] = ii[q];
+            bgsc[q] = (gamma ? gg[q] : 1.0f) * ii[q];
+            bgsh[q] = fmaf(-mm[q], bgsc[q], beta ? bb[q] : 0.0f);
+        }
+    }
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
-        if (RES && a + RD < TM) load_res(a + RD);
+        if (XROWS && a + RD < TM) load_res(a + RD);
         uint4 (&rh)[4] = rhA[a];
         uint4 (&rl4)[4] = rlA[a];
         // 16x16 tiles: column = lane & 15, rows 4*(lane >> 4) + r
@@ -536,10 +560,20 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
                         ig_split(o[2 * q + 1], h1, l1);
                         ph[q] = (unsigned)h0 | ((unsigned)h1 << 16);
                         pl_[q] = (unsigned)l0 | ((unsigned)l1 << 16);
-                        if (STATS) {                     // statistics of what is stored (the bf16 roundings)
+                        if (STATS == 1) {                // statistics of what is stored (the bf16 roundings)
                             const float v0 = __uint_as_float((unsigned)h0 << 16), v1 = __uint_as_float((unsigned)h1 << 16);
                             st1[2 * q] += v0; st2[2 * q] = fmaf(v0, v0, st2[2 * q]);
                             st1[2 * q + 1] += v1; st2[2 * q + 1] = fmaf(v1, v1, st2[2 * q + 1]);
+                        }
+                        if (STATS == 2) {                // Σg, Σ g*xhat with g = stored gradient where bn(x) > 0
+                            const unsigned xw = q == 0 ? rh[ps].x : (q == 1 ? rh[ps].y : (q == 2 ? rh[ps].z : rh[ps].w));
+                            const float x0 = __uint_as_float(xw << 16), x1 = __uint_as_float(xw & 0xFFFF0000u);
+                            const float v0 = __uint_as_float((unsigned)h0 << 16), v1 = __uint_as_float((unsigned)h1 << 16);
+                            const float g0 = fmaf(x0, bgsc[2 * q], bgsh[2 * q]) > 0.f ? v0 : 0.f;
+                            const float g1 = fmaf(x1, bgsc[2 * q + 1], bgsh[2 * q + 1]) > 0.f ? v1 : 0.f;
+                            st1[2 * q] += g0; st2[2 * q] = fmaf(g0, (x0 - bmean[2 * q]) * binv[2 * q], st2[2 * q]);
+                            st1[2 * q + 1] += g1;
+                            st2[2 * q + 1] = fmaf(g1, (x1 - bmean[2 * q + 1]) * binv[2 * q + 1], st2[2 * q + 1]);
                         }
                     }
                     *reinterpret_cast<uint4*>(Y) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
@@ -778,7 +812,8 @@ __global__ __launch_bounds__(256) void from_planes_kernel(const unsigned short* 
 template <int PL, bool OUTF32>
 static int launch_igemm_t(const void* x, const void* wp, const float* gamma, const float* beta, const float* mean,
                           const float* var, float eps, const void* res, int relu, void* y, int64_t M, int K, int N,
-                          int taps, hiast::IGeo geo, float* stats, const void* res_gate, int gate_mask, hipStream_t st)
+                          int taps, hiast::IGeo geo, float* stats, const void* res_gate, int gate_mask, hipStream_t st,
+                          int stats_mode)
 {
     int BN = (N % 256 == 0) ? 256 : ((N % 128 == 0) ? 128 : 64);
     if (const char* env = getenv("HIAST_IGEMM_BN")) {          // tuning override
@@ -797,12 +832,18 @@ static int launch_igemm_t(const void* x, const void* wp, const float* gamma, con
     }
 #define LS(BNV, T)                                                                      \
     if constexpr (PL == 1 && !OUTF32) {                                                 \
-        hipLaunchKernelGGL((hiast::igemm_bn_act_kernel<PL, OUTF32, BNV, T, false, false, 0, true>), grid, dim3(512), 0, st, \
+        if (stats_mode == 2)                                                            \
+        hipLaunchKernelGGL((hiast::igemm_bn_act_kernel<PL, OUTF32, BNV, T, false, false, 0, 2>), grid, dim3(512), 0, st, \
+                           (const unsigned short*)x, (const unsigned short*)wp, gamma, beta, mean, var, eps,                     \
+                           (const unsigned short*)res, y, (int)M, K, N, geo, stats, (const unsigned short*)res_gate);       \
+        else                                                                            \
+        hipLaunchKernelGGL((hiast::igemm_bn_act_kernel<PL, OUTF32, BNV, T, false, false, 0, 1>), grid, dim3(512), 0, st, \
                            (const unsigned short*)x, (const unsigned short*)wp, gamma, beta, mean, var, eps,                     \
                            (const unsigned short*)res, y, (int)M, K, N, geo, stats, (const unsigned short*)res_gate);       \
     }
 #define LL(BNV, T)                                                                      \
-    if (res) {                                                                          \
+    if (stats_mode == 2) { LS(BNV, T) }                                                 \
+    else if (res) {                                                                     \
         if (relu) L(BNV, T, true, true, 0);                                             \
         else if (gate == 0) L(BNV, T, true, false, 0);                                  \
         else { LG(BNV, T) }                                                             \
@@ -830,14 +871,19 @@ int hiast_xconv_launch(const void* x, const void* wp, const float* gamma, const 
                        const float* var, float eps, const void* res, int relu, void* y, int64_t M, int K, int N,
                        float* stats, const void* res_gate, hipStream_t st);
 
-// shared launcher (also used by aspp2.hip for the ASPP tap GEMM)
-int hiast_igemm_launch(const void* x, const void* wp, const float* gamma, const float* beta, const float* mean,
-                       const float* var, float eps, const void* res, int relu, void* y, int64_t M, int K, int N,
-                       int taps, int H, int W, int stride, int dil, int planes, int out_f32, hipStream_t st,
-                       float* stats, const void* res_gate, int gate_mask)
+// stats_mode: 0 none, 1 forward BatchNorm sums of the output (stats), 2 backward BatchNorm sums of the activation whose
+// gradient the output is (data-gradient launches: res = that BN's input x, mean / var = its batch mean / invstd)
+static int igemm_launch_mode(const void* x, const void* wp, const float* gamma, const float* beta, const float* mean,
+                             const float* var, float eps, const void* res, int relu, void* y, int64_t M, int K, int N,
+                             int taps, int H, int W, int stride, int dil, int planes, int out_f32, hipStream_t st,
+                             float* stats, const void* res_gate, int gate_mask, int stats_mode)
 {
-    if (stats && (planes != 1 || out_f32 || res || relu)) return HIAST_E_RANGE;
-    if ((stats || res_gate) && mean) return HIAST_E_RANGE;       // the statistics / gradient variants carry no BatchNorm
+    if (stats_mode == 2) {
+        if (!stats || !res || !mean || !var || planes != 1 || out_f32 || relu || res_gate || N % 8) return HIAST_E_RANGE;
+    } else {
+        if (stats && (planes != 1 || out_f32 || res || relu)) return HIAST_E_RANGE;
+        if ((stats || res_gate) && mean) return HIAST_E_RANGE;   // the statistics / gradient variants carry no BatchNorm
+    }
     if (res_gate && (planes != 1 || !res || relu || out_f32 || (!gate_mask && (((uintptr_t)res_gate) & 15)))) return HIAST_E_RANGE;
     if (!x || !wp || !y || (mean && !var)) return HIAST_E_ARG;
     if (M <= 0 || K <= 0 || N <= 0) return HIAST_E_ARG;
@@ -856,16 +902,45 @@ int hiast_igemm_launch(const void* x, const void* wp, const float* gamma, const 
     }
     // buffer-descriptor addressing: byte offsets and the out-of-range marker need 31 bits
     if (in_pix * planes * K * 2 >= (1ull << 31) || (size_t)N * taps * planes * K * 2 >= (1ull << 31)) return HIAST_E_RANGE;
-    if (hiast_xconv_ok(M, K, N, planes, taps, out_f32, mean != nullptr, res != nullptr, relu, res_gate != nullptr, gate_mask,
+    if (stats_mode != 2 &&
+        hiast_xconv_ok(M, K, N, planes, taps, out_f32, mean != nullptr, res != nullptr, relu, res_gate != nullptr, gate_mask,
                        stats != nullptr))
         return hiast_xconv_launch(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, stats, res_gate, st);
     if (planes == 2) {
-        if (out_f32) return launch_igemm_t<2, true>(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, stats, res_gate, gate_mask, st);
-        return launch_igemm_t<2, false>(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, stats, res_gate, gate_mask, st);
+        if (out_f32) return launch_igemm_t<2, true>(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, stats, res_gate, gate_mask, st, stats_mode);
+        return launch_igemm_t<2, false>(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, stats, res_gate, gate_mask, st, stats_mode);
     }
-    if (out_f32) return launch_igemm_t<1, true>(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, stats, res_gate, gate_mask, st);
-    return launch_igemm_t<1, false>(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, stats, res_gate, gate_mask, st);
+    if (out_f32) return launch_igemm_t<1, true>(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, stats, res_gate, gate_mask, st, stats_mode);
+    return launch_igemm_t<1, false>(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, stats, res_gate, gate_mask, st, stats_mode);
 }
+
+// shared launcher (also used by aspp2.hip for the ASPP tap GEMM)
+int hiast_igemm_launch(const void* x, const void* wp, const float* gamma, const float* beta, const float* mean,
+                       const float* var, float eps, const void* res, int relu, void* y, int64_t M, int K, int N,
+                       int taps, int H, int W, int stride, int dil, int planes, int out_f32, hipStream_t st,
+                       float* stats, const void* res_gate, int gate_mask)
+{
+    return igemm_launch_mode(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, H, W, stride, dil, planes,
+                             out_f32, st, stats, res_gate, gate_mask, stats ? 1 : 0);
+}
+
+// Data gradient of a stride-1 trunk convolution (dy x the adjoint weight, hiast_pack_conv_weight transpose) whose output
+// dA is the gradient of A = relu(bn(x)): also emits the per-block sums (Σg, Σ g*xhat) of that BatchNorm's backward,
+// partial[hiast_igemm_stats_rows][Cout][2] — hiast_bn_nhwc_stats_from_partial turns them into the sums that
+// hiast_bn_nhwc_bwd_apply takes (reference: autograd of conv -> bn -> relu in Bottleneck.forward, resnet.py:78-98).
+extern "C" int hiast_igemm_dgrad_bn_stats(const void* dy, const void* wpt, void* da, int B, int H, int W, int Cin, int Cout,
+                                          int taps, int dil, const void* bn_x, const float* gamma, const float* beta,
+                                          const float* save_mean, const float* save_invstd, float* partial,
+                                          hiast_stream_t stream)
+{
+    if (B <= 0 || H <= 0 || W <= 0) return HIAST_E_ARG;
+    if (!bn_x || !save_mean || !save_invstd || !partial) return HIAST_E_ARG;
+    if ((((uintptr_t)save_mean) | ((uintptr_t)save_invstd) | ((uintptr_t)gamma) | ((uintptr_t)beta)) & 15) return HIAST_E_RANGE;
+    return igemm_launch_mode(dy, wpt, gamma, beta, save_mean, save_invstd, 0.0f, bn_x, 0, da, (int64_t)B * H * W, Cin, Cout,
+                             taps, H, W, 1, dil, 1, 0, (hipStream_t)stream, partial, nullptr, 0, 2);
+}
+
+extern "C" int hiast_igemm_dgrad_bn_stats_rows(int64_t M) { return M <= 0 ? 0 : (int)((M + hiast::IG_BM - 1) / hiast::IG_BM); }
 
 extern "C" int hiast_igemm_bn_act(const void* x, const void* wp, const float* gamma, const float* beta,
                                   const float* mean, const float* var, float eps, const void* res, int relu, void* y,

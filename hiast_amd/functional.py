@@ -231,7 +231,8 @@ class _BnActNhwcFn(torch.autograd.Function):
     kernels, so the student forward / backward needs no NCHW<->NHWC transposes."""
 
     @staticmethod
-    def forward(ctx, x, res, gamma, beta, running_mean, running_var, momentum, eps, relu, world, partial, box):
+    def forward(ctx, x, res, gamma, beta, running_mean, running_var, momentum, eps, relu, world, partial, box,
+                stat_box=None):
         # batch statistics: from the producing convolution's epilogue when it delivered them, else one pass over x
         count = float(x.shape[0] * x.shape[2] * x.shape[3])
         # ReLU gate of the backward: recomputed from x when there is no residual input; with a residual the forward
@@ -258,6 +259,12 @@ class _BnActNhwcFn(torch.autograd.Function):
         # data-gradient epilogue will add the ReLU-masked gradient of the identity branch itself, this backward
         # neither writes that masked copy (dres) nor returns it for autograd to add
         ctx.box = box if (box is not None and box.get("armed") and ctx.gate in (1, 3)) else None
+        # statistics hand-off (see _ConvNhwcFn): the data-gradient launch of the ONE convolution that consumes y can emit
+        # this layer's backward sums (Σg, Σ g*xhat) from its epilogue; it needs x and the batch statistics for that
+        ctx.stat_box = None
+        if stat_box is not None and ctx.gate == 2:
+            stat_box["bn"] = (x.detach(), sm, si, gamma, beta)
+            ctx.stat_box = stat_box
         return y
 
     @staticmethod
@@ -266,7 +273,11 @@ class _BnActNhwcFn(torch.autograd.Function):
         if dy.dtype != x.dtype:
             dy = dy.to(x.dtype)
         dy = dy.contiguous(memory_format=torch.channels_last)
-        sums = K.bn_nhwc_bwd_stats(dy, y, x, gamma, beta, sm, si, ctx.gate)
+        fused = ctx.stat_box.pop("bwd_partial", None) if ctx.stat_box is not None else None
+        if fused is not None:          # per-block sums from the epilogue of the consuming convolution's data gradient
+            sums = K.bn_nhwc_stats_from_partial(fused)
+        else:
+            sums = K.bn_nhwc_bwd_stats(dy, y, x, gamma, beta, sm, si, ctx.gate)
         if ctx.world > 1:
             import torch.distributed as dist
             dist.all_reduce(sums)
@@ -277,7 +288,7 @@ class _BnActNhwcFn(torch.autograd.Function):
         if handoff:
             ctx.box["gated"] = (dy, y)            # (gradient, bit mask): consumed by the block's conv1 backward
         return (dx, dres, dg if ctx.needs_input_grad[2] else None, db if ctx.needs_input_grad[3] else None,
-                None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None)
 
 
 class _ConvNhwcFn(torch.autograd.Function):
@@ -289,8 +300,12 @@ class _ConvNhwcFn(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
-    def forward(ctx, x, weight, stride, dil, want_stats, box, packed):
+    def forward(ctx, x, weight, stride, dil, want_stats, box, packed, in_bn=None):
         xv = x.permute(0, 2, 3, 1)
+        # in_bn: x = relu(bn(x0)) of a BatchNorm that registered itself there (and has no other consumer): the data
+        # gradient of this convolution then also delivers that BatchNorm's backward sums (hiast_igemm_dgrad_bn_stats)
+        ctx.in_bn = in_bn if (in_bn is not None and "bn" in in_bn and stride == 1 and ctx.needs_input_grad[0]
+                              and os.environ.get("HIAST_NO_BN_BWD_FUSION", "0") != "1") else None
         ctx.set_materialize_grads(False)     # no zero tensor for the (non-differentiable) statistics output
         ctx.wpt = None
         ctx.box = None
@@ -316,7 +331,7 @@ class _ConvNhwcFn(torch.autograd.Function):
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dy, _dpartial=None):
         if dy is None:
-            return None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
         x, weight = ctx.saved_tensors
         stride, dil = ctx.geo
         if dy.dtype != torch.bfloat16:
@@ -330,7 +345,13 @@ class _ConvNhwcFn(torch.autograd.Function):
         if need_x and stride == 1:
             wpt = ctx.wpt if ctx.wpt is not None else K.pack_conv_weight(weight, 1, transpose=True)
             gated = ctx.box.pop("gated", None) if ctx.box is not None else None
-            if gated is not None:      # + dy_block * (y_block > 0): the identity branch's gradient, in the epilogue
+            if ctx.in_bn is not None and gated is None:
+                bx, sm, si, gamma, beta = ctx.in_bn["bn"]
+                dxv, bpartial = K.igemm_dgrad_bn_stats(dy.permute(0, 2, 3, 1), wpt, dil, bx.permute(0, 2, 3, 1), gamma, beta,
+                                                       sm, si)
+                ctx.in_bn["bwd_partial"] = bpartial
+                dx = dxv.permute(0, 3, 1, 2)
+            elif gated is not None:    # + dy_block * (y_block > 0): the identity branch's gradient, in the epilogue
                 dx = K.igemm_bn_act(dy.permute(0, 2, 3, 1), wpt, 1, None, gated[0].permute(0, 2, 3, 1), False, 1, dil,
                                     res_gate=(gated[1] if gated[1].dtype == torch.uint8
                                               else gated[1].permute(0, 2, 3, 1))).permute(0, 3, 1, 2)
@@ -368,7 +389,7 @@ class _ConvNhwcFn(torch.autograd.Function):
                                                                 # (DDP compares strides with its bucket view literally)
         if side is not None and dw is not None:
             dw.record_stream(main)
-        return dx, dw, None, None, None, None, None
+        return dx, dw, None, None, None, None, None, None
 
 
 _wgrad_streams = {}
@@ -433,8 +454,9 @@ class _SubsampleClFn(torch.autograd.Function):
         return g, None
 
 
-def conv_nhwc(x, conv, want_stats=False, box=None):
-    """-> y, or (y, partial) with want_stats (see igemm_bn_act); box: identity-branch hand-off of a bottleneck"""
+def conv_nhwc(x, conv, want_stats=False, box=None, in_bn=None):
+    """-> y, or (y, partial) with want_stats (see igemm_bn_act); box: identity-branch hand-off of a bottleneck;
+    in_bn: statistics hand-off of the BatchNorm whose output x is (bn_act(..., stat_box=in_bn))"""
     w = conv.weight
     fwd = conv.__dict__.get("_hiast_packed", {}).get(1)
     adj = conv.__dict__.get("_hiast_packed_adj")
@@ -447,13 +469,13 @@ def conv_nhwc(x, conv, want_stats=False, box=None):
         # DDP copy the bucket view); autograd scatters the data gradient back into the skipped pixels
         x = _SubsampleClFn.apply(x, stride)
         stride = 1
-    return _ConvNhwcFn.apply(x, w, stride, conv.dilation[0], bool(want_stats), box, packed)
+    return _ConvNhwcFn.apply(x, w, stride, conv.dilation[0], bool(want_stats), box, packed, in_bn)
 
 
 _nbt_batched = [False]      # set by ResNet.forward while it has already advanced every num_batches_tracked at once
 
 
-def bn_act(x, bn, res=None, relu=True, partial=None, box=None):
+def bn_act(x, bn, res=None, relu=True, partial=None, box=None, stat_box=None):
     """Fused replacement of `relu(bn(x) [+ res])` for a torch BatchNorm2d / SyncBatchNorm module `bn`
     (which keeps owning the parameters and running statistics)."""
     training = bn.training or (bn.running_mean is None)
@@ -463,6 +485,6 @@ def bn_act(x, bn, res=None, relu=True, partial=None, box=None):
     if (training and x.dtype == torch.bfloat16 and _is_cl(x) and not x.is_contiguous()
             and K.bn_nhwc_supported(x.shape[1]) and (res is None or (res.dtype == x.dtype and _is_cl(res)))):
         return _BnActNhwcFn.apply(x, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, momentum, bn.eps, relu,
-                                  _sync_world(bn), partial, box)
+                                  _sync_world(bn), partial, box, stat_box)
     return _BnActFn.apply(x, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum,
                           bn.eps, relu, _sync_world(bn) if training else 1)

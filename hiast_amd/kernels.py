@@ -844,6 +844,29 @@ def igemm_bn_act(x, wp, planes, bn, res, relu, stride=1, dil=1, out_f32=False, w
     return (y, partial) if want_stats else y
 
 
+def igemm_dgrad_bn_stats(dy, wpt, dil, bn_x, gamma, beta, save_mean, save_invstd):
+    """data gradient of a stride-1 trunk convolution whose input was A = relu(bn(bn_x)):
+    dy bf16 [B,H,W,Cin'], wpt = adjoint packed weight [Cout', taps, Cin'] -> (dA bf16 [B,H,W,Cout'],
+    partial fp32 [rows, Cout', 2] = per-block (Σg, Σ g*xhat) of that BatchNorm's backward; bn_nhwc_stats_from_partial
+    reduces them to the sums bn_nhwc_bwd_apply takes).  bn_x: bf16 [B,H,W,Cout'] (channels-last rows)."""
+    _req(dy, torch.bfloat16, 4, "dy")
+    _req(wpt, torch.bfloat16, 3, "wpt")
+    _req(bn_x, torch.bfloat16, 4, "bn_x")
+    B, H, W, Cin = dy.shape
+    N, taps, KK = wpt.shape
+    assert KK == Cin and taps in (1, 9) and tuple(bn_x.shape) == (B, H, W, N), (tuple(dy.shape), tuple(wpt.shape), tuple(bn_x.shape))
+    _req(save_mean, torch.float32, 1, "save_mean")
+    _req(save_invstd, torch.float32, 1, "save_invstd")
+    lib = _lib.load()
+    da = torch.empty((B, H, W, N), dtype=torch.bfloat16, device=dy.device)
+    rows = lib.hiast_igemm_dgrad_bn_stats_rows(B * H * W)
+    partial = torch.empty((rows, N, 2), dtype=torch.float32, device=dy.device)
+    check(lib.hiast_igemm_dgrad_bn_stats(_ptr(dy), _ptr(wpt), _ptr(da), B, H, W, Cin, N, taps, int(dil), _ptr(bn_x),
+                                         _ptr(gamma), _ptr(beta), _ptr(save_mean), _ptr(save_invstd), _ptr(partial),
+                                         _stream()), "hiast_igemm_dgrad_bn_stats")
+    return da, partial
+
+
 # ------------------------------------------------------------------------------- K10b BN (train) on channels-last bf16
 def _bnh_view(t, name):
     """logical [B,C,H,W] bf16 tensor with channels-last memory -> ([M,C] view, M, C)"""

@@ -33,12 +33,13 @@ def conv(m, x):
     return m(x)
 
 
-def conv_bn_act(cv, bn, x, res=None, relu=True, conv_box=None, bn_box=None):
+def conv_bn_act(cv, bn, x, res=None, relu=True, conv_box=None, bn_box=None, in_bn=None, stat_box=None):
     """relu?(bn(conv(x)) [+ res]).  On the channels-last bf16 training path the convolution's epilogue also
-    delivers the per-block sums the BatchNorm needs (one pass over the activation less)."""
+    delivers the per-block sums the BatchNorm needs (one pass over the activation less); stat_box / in_bn: the same for
+    the BACKWARD sums — this BatchNorm registers itself in stat_box, the next conv_bn_act gets that dict as in_bn."""
     if x.is_cuda and x.dtype == torch.bfloat16 and bn.training and HF.conv_nhwc_ok(x, cv):
-        y, partial = HF.conv_nhwc(x, cv, want_stats=True, box=conv_box)
-        return HF.bn_act(y, bn, res, relu, partial=partial, box=bn_box)
+        y, partial = HF.conv_nhwc(x, cv, want_stats=True, box=conv_box, in_bn=in_bn)
+        return HF.bn_act(y, bn, res, relu, partial=partial, box=bn_box, stat_box=stat_box)
     return bn_act(bn, conv(cv, x), res, relu)
 
 
@@ -87,9 +88,10 @@ class Bottleneck(nn.Module):
         # gradient of the identity branch itself (no masked copy written by bn3's backward, no separate add kernel);
         # `box` is the hand-off between the two autograd nodes of this call
         box = {} if (self.downsample is None and os.environ.get("HIAST_NO_IDT_HANDOFF", "0") != "1") else None
-        o = conv_bn_act(self.conv1, self.bn1, x, conv_box=box)
-        o = conv_bn_act(self.conv2, self.bn2, o)
-        return conv_bn_act(self.conv3, self.bn3, o, res=idt, bn_box=box)        # += identity, ReLU
+        sb1, sb2 = {}, {}       # bn1 -> conv2's data gradient, bn2 -> conv3's: backward statistics from the dgrad epilogue
+        o = conv_bn_act(self.conv1, self.bn1, x, conv_box=box, stat_box=sb1)
+        o = conv_bn_act(self.conv2, self.bn2, o, in_bn=sb1, stat_box=sb2)
+        return conv_bn_act(self.conv3, self.bn3, o, res=idt, bn_box=box, in_bn=sb2)        # += identity, ReLU
 
     def forward_eval_planes(self, x, PL):
         """inference on channels-last 16-bit activations [B,H,W,PL*C] (PL = 2: split planes, fp32-class — the

@@ -264,6 +264,18 @@ int hiast_igemm_bn_act(const void* x, const void* wp, const float* gamma, const 
 /* host: number of partial-sum rows hiast_igemm_bn_act writes into `stats` [rows][Cout][2] for M = B*Ho*Wo output pixels
  * (one row per block of the kernel chosen for the shape) */
 int hiast_igemm_stats_rows(int64_t M, int Cin, int Cout, int taps, int planes);
+/* Data gradient of a stride-1 trunk convolution, dA = conv(dy, adjoint weight) (wpt: hiast_pack_conv_weight with
+ * transpose; Cin = channels of dy, Cout = channels of dA; bf16 channels-last rows), for the case that A = relu(bn(x)):
+ * the epilogue also emits the per-block sums of that BatchNorm's backward pass, partial[rows][Cout][2] = (Σg, Σ g*xhat)
+ * with g = dA where gamma*(x-mean)*invstd + beta > 0 (the stored bf16 dA), xhat = (x-mean)*invstd — what
+ * hiast_bn_nhwc_bwd_stats(relu = 2) computes with one more read of dA and x.  rows = hiast_igemm_dgrad_bn_stats_rows(M);
+ * hiast_bn_nhwc_stats_from_partial reduces them to the sums hiast_bn_nhwc_bwd_apply takes.  gamma / beta may be NULL
+ * (1 / 0).  Replaces the autograd of conv -> bn -> relu (Bottleneck.forward, sseg/models/modules/resnet.py:78-98: cuDNN
+ * data gradient + ATen batch_norm_backward reduce, each a pass of its own). */
+int hiast_igemm_dgrad_bn_stats(const void* dy, const void* wpt, void* da, int B, int H, int W, int Cin, int Cout, int taps,
+                               int dil, const void* bn_x, const float* gamma, const float* beta, const float* save_mean,
+                               const float* save_invstd, float* partial, hiast_stream_t stream);
+int hiast_igemm_dgrad_bn_stats_rows(int64_t M);
 int hiast_pack_conv_weight(const float* w, int N, int K, int taps, int planes, int transpose, void* wp, void* wpt,
                            hiast_stream_t stream);
 int hiast_split_planes(float* x, void* planes, int64_t M, int C, int inverse, hiast_stream_t stream);

@@ -122,3 +122,71 @@ def test_copy_paste_on_device_matches_reference_golden(golden):
     mk = K.copy_paste_u8(da, dl, torch.from_numpy(b).cuda(), torch.from_numpy(lb_).cuda(), hard)
     assert np.array_equal(da.cpu().numpy(), np.where(sel[..., None], b, a))
     assert np.array_equal(dl.cpu().numpy(), np.where(sel, lb_, la)) and np.array_equal(mk.cpu().numpy(), np.where(sel, lb_, 255))
+
+
+@pytest.mark.parametrize("case", [(2, 24, 40, 1024, 256, 1, 1), (1, 20, 36, 256, 256, 9, 2), (2, 9, 13, 128, 64, 9, 1),
+                                  (1, 16, 16, 512, 128, 1, 1)])
+def test_dgrad_epilogue_delivers_bn_backward_sums(case):
+    """hiast_igemm_dgrad_bn_stats: the data gradient is bit-identical to the plain launch, and the per-block sums reduce
+    to what hiast_bn_nhwc_bwd_stats (gate recomputed from x) computes from the same dA and x (fp32 partial sums in another
+    order: 1e-4 of the largest sum); nullable gamma / beta; tail rows of the 256-row tile"""
+    from hiast_amd import kernels as K
+    B, H, W, Cdy, Ca, taps, dil = case          # conv forward: Ca -> Cdy channels; its data gradient: Cdy -> Ca
+    kk = 3 if taps == 9 else 1
+    dev = torch.device("cuda")
+    w = torch.from_numpy(synth.normal_f32(910, (Cdy, Ca, kk, kk), (2.0 / (Ca * taps)) ** 0.5)).to(dev)
+    wpt = K.pack_conv_weight(w, 1, transpose=True)
+    dy = torch.from_numpy(synth.normal_f32(911, (B, H, W, Cdy))).to(dev).bfloat16()
+    x = torch.from_numpy(synth.normal_f32(912, (B, Ca, H, W), 1.5)).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    gamma = torch.from_numpy(synth.normal_f32(913, (Ca,), 0.5)).to(dev) + 1.0
+    beta = torch.from_numpy(synth.normal_f32(914, (Ca,), 0.3)).to(dev)
+    xf = x.float()
+    sm = xf.mean(dim=(0, 2, 3)).contiguous()
+    si = (1.0 / torch.sqrt(xf.var(dim=(0, 2, 3), unbiased=False) + 1e-5)).contiguous()
+    plain = K.igemm_bn_act(dy, wpt, 1, None, None, False, 1, dil)
+    for g, b in ((gamma, beta), (None, None)):
+        da, partial = K.igemm_dgrad_bn_stats(dy, wpt, dil, x.permute(0, 2, 3, 1), g, b, sm, si)
+        assert torch.equal(da, plain)
+        got = K.bn_nhwc_stats_from_partial(partial).cpu().numpy()
+        want = K.bn_nhwc_bwd_stats(da.permute(0, 3, 1, 2), None, x, g, b, sm, si, 2).cpu().numpy()
+        assert np.abs(got - want).max() <= 1e-4 * np.abs(want).max() + 1e-6, np.abs(got - want).max()
+        # and against fp64 on the stored values
+        d64 = da.double().permute(0, 3, 1, 2)
+        xh = (x.double() - sm.double().view(1, -1, 1, 1)) * si.double().view(1, -1, 1, 1)
+        open_ = (x.float() * ((g if g is not None else torch.ones_like(sm)) * si).view(1, -1, 1, 1)
+                 + ((b if b is not None else torch.zeros_like(sm)) - sm * (g if g is not None else torch.ones_like(sm)) * si).view(1, -1, 1, 1)) > 0
+        gg = torch.where(open_, d64, torch.zeros_like(d64))
+        ref = torch.stack([gg.sum(dim=(0, 2, 3)), (gg * xh).sum(dim=(0, 2, 3))], dim=1).cpu().numpy()
+        big = np.abs(ref).max()
+        # (the gate is an fp32 fmaf on the device: elements within an ulp of zero may differ from this reference's gate)
+        assert np.abs(got - ref).max() <= 2e-3 * big, (np.abs(got - ref).max(), big)
+
+
+def test_bottleneck_backward_with_and_without_statistics_fusion(monkeypatch):
+    """a training-mode bottleneck on channels-last bf16: input gradient and weight gradients with the BatchNorm backward
+    sums taken from the data-gradient epilogues equal the run that computes them in a pass of their own"""
+    from hiast_amd.sseg.models.modules.resnet import Bottleneck
+    torch.manual_seed(5)
+    blk = Bottleneck(1024, 256, stride=1, dilation=2, downsample=None).cuda().train()
+    x0 = torch.from_numpy(synth.normal_f32(920, (2, 1024, 24, 40))).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+    gout = torch.from_numpy(synth.normal_f32(921, (2, 1024, 24, 40))).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("HIAST_NO_BN_BWD_FUSION", flag)
+        for p in blk.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = blk(x)
+        y.backward(gout)
+        from hiast_amd import functional as HF
+        HF.wgrad_stream_join()
+        torch.cuda.synchronize()
+        res[flag] = (x.grad.float().cpu().numpy(), {n: p.grad.float().cpu().numpy() for n, p in blk.named_parameters() if p.grad is not None})
+    gx0, gw0 = res["0"]
+    gx1, gw1 = res["1"]
+    assert np.abs(gx0 - gx1).max() <= 2e-2 * np.abs(gx1).max()
+    assert float((gx0 * gx1).sum() / np.sqrt((gx0 ** 2).sum() * (gx1 ** 2).sum())) >= 0.9999
+    for n in gw1:
+        c = float((gw0[n] * gw1[n]).sum() / np.sqrt((gw0[n] ** 2).sum() * (gw1[n] ** 2).sum() + 1e-30))
+        assert c >= 0.9995, (n, c)

@@ -88,6 +88,8 @@ int main()
     CHECK(hipMemset(r, 1, bytes));
     CHECK(hipMemset(y, 0, bytes));
     // 1 KiB variant covers: rows_per_wave = 256/8 = 32 instr... make sure every element is touched exactly once
+    run<4, false>(r, y, "run 64 B (16 rows/instr: the xconv epilogue)");
+    run<4, true>(r, y, "run 64 B, 1 block/CU");
     run<8, false>(r, y, "run 128 B (8 rows/instr)");
     run<32, false>(r, y, "run 512 B (2 rows/instr)");
     run<64, false>(r, y, "run 1 KiB (1 row/instr)");
