@@ -13,6 +13,12 @@
 // pixels; two LDS stages (the DMA of step t+1 flies during the MFMAs of step t).  Pixel ranges are reduced in a fixed
 // order by wgrad_reduce_kernel (bitwise reproducible, no float atomics), which also writes torch's [N][K][kh][kw]
 // layout.
+// The k-step (second form of round 2): the LDS-DMA is issued through inline asm and the transposing reads stay builtins —
+// the compiler then folds their offsets into the instructions, keeps the two halves of a fragment in one register tuple
+// and counts lgkmcnt itself, where the first form (asm reads, builtin DMA) spent ~600 VALU / branch instructions per
+// k-step on addresses, joins and bounds tests for 32 MFMAs.  Out-of-range rows come from the descriptor's size, per-piece
+// constants ride in the scalar offset, the 3x3 pixel walk is branch-free, fragments are double-buffered across the four
+// sub-steps (182 / 209 VGPRs).  layer3 3x3 0.124 -> 0.105 ms, layer4 3x3 0.408 -> 0.319 ms (with the reduce pass).
 #include <hip/hip_bf16.h>
 
 #include "common.h"
@@ -29,37 +35,39 @@ struct WGeo {
     int H, W, Ho, Wo, stride, dil;
 };
 
-__device__ __forceinline__ void wg_dma16(__amdgpu_buffer_rsrc_t rs, unsigned char* lds, int voff, int soff)
+typedef int wg_i32x4 __attribute__((ext_vector_type(4)));
+
+// LDS-DMA as INLINE ASM (64 lanes x 16 bytes from buffer offset voff + soff to LDS address lds + 16*lane).  The compiler
+// orders every LDS load it can see behind ALL pending LDS-DMAs it knows of (s_waitcnt vmcnt(0)); round 2 first hid the
+// loads (asm ds_read_b64_tr_b16), which left it with ~100 register copies per k-step joining the two halves of every
+// fragment and 48 address computations.  Hiding the DMA instead keeps the transposing reads as builtins: the compiler
+// folds their tile offsets into the instruction, allocates the halves of a fragment as one register tuple and counts
+// lgkmcnt itself; the DMA waits are counted by hand (s_waitcnt vmcnt below).
+__device__ __forceinline__ void wg_dma16(wg_i32x4 rs, unsigned lds, int voff, int soff)
 {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (wg_lds_ptr)lds, 16, voff, soff, 0, 0);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 ::"s"(lds), "v"(voff), "s"(rs), "s"(soff)
+                 : "memory");
+}
+__device__ __forceinline__ wg_i32x4 wg_rsrc(const void* base, unsigned bytes)
+{
+    const unsigned long long a = (unsigned long long)base;
+    wg_i32x4 r;
+    r[0] = (int)(unsigned)a;
+    r[1] = (int)((a >> 32) & 0xFFFFu);
+    r[2] = (int)bytes;
+    r[3] = 0x00020000;
+    return r;
 }
 
-// transposing LDS read, as inline asm on the LDS byte address.  Through the builtin the compiler sees an LDS load and
-// orders it behind ALL pending LDS-DMA: it put an s_waitcnt vmcnt(0) in front of the fragment reads that follow each
-// pair of DMA pieces — four full HBM round trips per 64-pixel step during which the wave did nothing (the prefetch of
-// step t+1 was waited for inside step t).  The asm reads are invisible to that rule; wg_wait ties their results to an
-// explicit lgkmcnt wait.
-__device__ __forceinline__ wg_s16x4 wg_tr_read(unsigned addr)
+__device__ __forceinline__ wg_s16x4 wg_tr_read(const unsigned char* p)
 {
-    wg_s16x4 v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
-    return v;
-}
-struct WgFrags {
-    wg_s16x4 a[4][2], b[2][2];          // two transposed halves per fragment
-};
-__device__ __forceinline__ void wg_wait(WgFrags& f)
-{
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(f.a[0][0]), "+v"(f.a[0][1]), "+v"(f.a[1][0]), "+v"(f.a[1][1]), "+v"(f.a[2][0]), "+v"(f.a[2][1]),
-                   "+v"(f.a[3][0]), "+v"(f.a[3][1]), "+v"(f.b[0][0]), "+v"(f.b[0][1]), "+v"(f.b[1][0]), "+v"(f.b[1][1]));
+    typedef wg_s16x4 __attribute__((address_space(3))) * lds_p;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)p);
 }
 __device__ __forceinline__ wg_bf16x8 wg_join(const wg_s16x4& v0, const wg_s16x4& v1)
 {
-    wg_s16x8 v;
-    v[0] = v0[0]; v[1] = v0[1]; v[2] = v0[2]; v[3] = v0[3];
-    v[4] = v1[0]; v[5] = v1[1]; v[6] = v1[2]; v[7] = v1[3];
-    return __builtin_bit_cast(wg_bf16x8, v);
+    return __builtin_bit_cast(wg_bf16x8, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
 // [rows][128 x 16-bit] sub-tile with 256-byte rows: 16-byte chunk ch of row r lives at chunk ch ^ swz(r)
@@ -94,7 +102,7 @@ __global__ __launch_bounds__(512) void wgrad_tn_kernel(const unsigned short* __r
     const int tap = t % TAPS; t /= TAPS;
     const int k0 = (t % kt_tiles) * 256, n0 = (t / kt_tiles) * 256;
     const int split = lid / (int)gridDim.x;
-    const int m_begin = split * m_per_split;
+    const int m_begin = split * m_per_split;              // a multiple of 64
     const int m_end = (m_begin + m_per_split < M) ? m_begin + m_per_split : M;
     const int nk = (m_end - m_begin + WG_ROWS - 1) / WG_ROWS;
     const int oy = TAPS == 1 ? 0 : (tap / 3 - 1) * geo.dil, ox = TAPS == 1 ? 0 : (tap % 3 - 1) * geo.dil;
@@ -102,53 +110,61 @@ __global__ __launch_bounds__(512) void wgrad_tn_kernel(const unsigned short* __r
     constexpr int OOB = (int)0x80000000;
     const float inv_hw = 1.0f / (float)(geo.Ho * geo.Wo), inv_wo = 1.0f / (float)geo.Wo;
     const size_t in_pix = (TAPS == 1) ? (size_t)M : (size_t)(M / (geo.Ho * geo.Wo)) * geo.H * geo.W;
-    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)dY, 0, (int)((size_t)M * N * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)(in_pix * K * 2), 0x00020000);
+    // Buffer descriptors that END at this block's last pixel row: the tail rows of the last k-step are out of range and
+    // arrive as zeros without a per-lane test (3x3: X is addressed per input pixel and keeps its own bounds select).
+    const wg_i32x4 yrs = wg_rsrc(dY, (unsigned)((size_t)m_end * N * 2));
+    const wg_i32x4 xrs = wg_rsrc(X, (unsigned)((TAPS == 1 ? (size_t)m_end : in_pix) * K * 2));
 
-    // DMA pieces of one k-step: 64 wave-instructions (4 sub-tiles x 16 groups of 4 rows); wave w issues pieces
-    // 8w .. 8w+7: piece = sub*16 + grp.  Lane l supplies row 4*grp + (l >> 4), logical chunk (l & 15) ^ swz(row).
-    // 3x3: the (image, row, column) of a lane's output pixel is decoded ONCE per k-step (piece 0: float reciprocal +
-    // one-step correction, exact for m < 2^24, no integer division) and then walked: consecutive pieces of a wave are
-    // 4 pixels apart.  Decoding every piece cost the X-loading waves ~40 VALU instructions x 8 pieces per k-step —
-    // more than their 32 MFMAs.
-    int d_img = 0, d_yo = 0, d_xo = 0;
-    auto piece = [&](int kt, int buf, int pc) {
-        const int idx = wave * 8 + pc;
-        const int sub = idx >> 4, grp = idx & 15;
-        const int row = 4 * grp + (lane >> 4);
-        const int ch = (lane & 15) ^ wg_swz(row);
-        const int m = m_begin + kt * WG_ROWS + row;
-        unsigned char* dst = smem + buf * WG_STAGE + sub * WG_SUB + grp * 1024;
-        if (sub < 2) {
-            const int voff = m < m_end ? (int)(((size_t)m * N + n0 + sub * 128) * 2) + ch * 16 : OOB;
-            wg_dma16(yrs, dst, voff, 0);
+    // DMA pieces of one k-step: 64 wave-instructions (4 sub-tiles x 16 groups of 4 rows).  Wave w owns sub-tile w >> 1
+    // (0, 1: dY columns n0.. / n0+128..; 2, 3: X columns k0.. / k0+128..) and its row groups 8*(w & 1) + pc, pc = 0..7:
+    // row = 32*(w & 1) + 4*pc + (lane >> 4), logical chunk (lane & 15) ^ swz(row) with swz(row) = ((lane>>4 & 3) << 2) |
+    // (pc & 3).  Everything that depends on pc or on the k-step but not on the lane goes into the instruction's scalar
+    // offset: four per-lane offsets (pc & 3) serve all pieces.
+    const int sub = wave >> 1, l4 = lane >> 4;
+    const bool is_x = sub >= 2;
+    const int pitch2 = (is_x ? K : N) * 2;                                    // bytes per pixel row of this wave's operand
+    const int col2 = (is_x ? k0 + (sub - 2) * 128 : n0 + sub * 128) * 2;
+    const int row0 = 32 * (wave & 1) + l4;
+    int pv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        pv[j] = (m_begin + row0) * pitch2 + col2 + 16 * ((lane & 15) ^ (((l4 & 3) << 2) | j));
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    const unsigned dst0 = lds0 + (unsigned)(sub * WG_SUB + (wave & 1) * 8 * 1024);
+    // 3x3: (image, row, column) of the output pixel of this lane's row in piece 0 of k-step kt — decoded once per k-step
+    // (float reciprocal + one-step correction: exact for m < 2^24, no integer division) and walked 4 pixels per piece
+    auto issue = [&](int kt, int buf, int pc, bool on, int& d_img, int& d_yo, int& d_xo) {
+        const unsigned dst = dst0 + (unsigned)(buf * WG_STAGE + pc * 1024);
+        if (TAPS == 1 || !is_x) {
+            wg_dma16(is_x ? xrs : yrs, dst, on ? pv[pc & 3] : OOB, (kt * WG_ROWS + 4 * pc) * pitch2);
         } else {
-            int voff = OOB;
-            if (TAPS == 1) {
-                if (m < m_end) voff = (int)(((size_t)m * K + k0 + (sub - 2) * 128) * 2) + ch * 16;
-            } else {
-                if (pc == 0) {
-                    const int hw = geo.Ho * geo.Wo;
-                    int img = (int)(((float)m + 0.5f) * inv_hw);
-                    int r = m - img * hw;
-                    if (r < 0) { --img; r += hw; } else if (r >= hw) { ++img; r -= hw; }
-                    int yo = (int)(((float)r + 0.5f) * inv_wo);
-                    int xo = r - yo * geo.Wo;
-                    if (xo < 0) { --yo; xo += geo.Wo; } else if (xo >= geo.Wo) { ++yo; xo -= geo.Wo; }
-                    d_img = img; d_yo = yo; d_xo = xo;
-                }
-                if (m < m_end) {
-                    const int yy = d_yo * geo.stride + oy, xx = d_xo * geo.stride + ox;
-                    if (yy >= 0 && yy < geo.H && xx >= 0 && xx < geo.W)
-                        voff = (int)((((size_t)(d_img * geo.H + yy) * geo.W + xx) * K + k0 + (sub - 2) * 128) * 2) + ch * 16;
-                }
-                d_xo += 4;                                   // the next piece of this wave: 4 pixels on
-                while (d_xo >= geo.Wo) {
-                    d_xo -= geo.Wo;
-                    if (++d_yo >= geo.Ho) { d_yo = 0; ++d_img; }
-                }
+            if (pc == 0) {
+                const int m = m_begin + kt * WG_ROWS + row0;
+                const int hw = geo.Ho * geo.Wo;
+                int img = (int)(((float)m + 0.5f) * inv_hw);
+                int r = m - img * hw;
+                const bool lo = r < 0, hi = r >= hw;
+                img += hi ? 1 : (lo ? -1 : 0);
+                r += lo ? hw : (hi ? -hw : 0);
+                int yo = (int)(((float)r + 0.5f) * inv_wo);
+                int xo = r - yo * geo.Wo;
+                const bool lo2 = xo < 0, hi2 = xo >= geo.Wo;
+                yo += hi2 ? 1 : (lo2 ? -1 : 0);
+                xo += lo2 ? geo.Wo : (hi2 ? -geo.Wo : 0);
+                d_img = img; d_yo = yo; d_xo = xo;
             }
-            wg_dma16(xrs, dst, voff, 0);
+            const int m = m_begin + kt * WG_ROWS + row0 + 4 * pc;
+            const int yy = d_yo * geo.stride + oy, xx = d_xo * geo.stride + ox;
+            const bool ok = on & (m < m_end) & ((unsigned)yy < (unsigned)geo.H) & ((unsigned)xx < (unsigned)geo.W);
+            const int voff = ((d_img * geo.H + yy) * geo.W + xx) * pitch2 + col2 + 16 * ((lane & 15) ^ (((l4 & 3) << 2) | (pc & 3)));
+            wg_dma16(xrs, dst, ok ? voff : OOB, 0);
+            d_xo += 4;                                   // the next piece of this wave: 4 pixels on (Wo >= 4)
+            const bool wrap = d_xo >= geo.Wo;
+            d_xo -= wrap ? geo.Wo : 0;
+            d_yo += wrap ? 1 : 0;
+            const bool wrap2 = d_yo >= geo.Ho;
+            d_yo = wrap2 ? 0 : d_yo;
+            d_img += wrap2 ? 1 : 0;
         }
     };
 
@@ -160,58 +176,57 @@ __global__ __launch_bounds__(512) void wgrad_tn_kernel(const unsigned short* __r
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    // transposed fragment: 32 columns starting at c0 of a sub-tile, reduction rows kb .. kb+7 for this lane half
+    // transposed fragment: 32 columns starting at c0 of a sub-tile, reduction rows kb .. kb+7 for this lane half.
+    // Per-lane byte offsets of the two halves (v0: rows kb + fq, v1: rows kb + 4 + fq) for kk = 0; sub-step kk adds
+    // 16 rows = 4096 bytes (the swizzle of a row does not depend on kk).
     const int grp4 = lane >> 4, t16 = lane & 15;
     const int fq = t16 >> 2, fp = t16 & 3;
-    const unsigned lds0 = (unsigned)(size_t)smem;                // LDS byte address of the stage buffers
-    auto frag = [&](unsigned subtile, int c0, int kk, wg_s16x4& v0, wg_s16x4& v1) {
-        const int kb = kk * 16 + 8 * (grp4 >> 1);
+    auto frag_off = [&](int c0, int half) {
+        const int kb = 8 * (grp4 >> 1) + 4 * half;
         const int ch = ((c0 + 16 * (grp4 & 1)) >> 3) + (fp >> 1);
-        v0 = wg_tr_read(subtile + (unsigned)(wg_off(kb + fq, ch) + 8 * (fp & 1)));
-        v1 = wg_tr_read(subtile + (unsigned)(wg_off(kb + 4 + fq, ch) + 8 * (fp & 1)));
+        return wg_off(kb + fq, ch) + 8 * (fp & 1);
     };
-
-    if (nk > 0) {
+    int oa[4][2], ob[2][2];
 #pragma unroll
-        for (int pc = 0; pc < 8; ++pc) piece(0, 0, pc);
-    }
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) oa[a][h] = wm * WG_SUB + frag_off(a * 32, h);
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) ob[b][h] = 2 * WG_SUB + (wn >> 1) * WG_SUB + frag_off((wn & 1) * 64 + b * 32, h);
+
+    int d_img = 0, d_yo = 0, d_xo = 0;
+#pragma unroll
+    for (int pc = 0; pc < 8; ++pc) issue(0, 0, pc, nk > 0, d_img, d_yo, d_xo);
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's pieces of k-step kt have landed
+        __syncthreads();                                          // everyone's have; everyone left stage buf ^ 1
         const bool more = kt + 1 < nk;
-        const unsigned st = lds0 + buf * WG_STAGE;
-        const unsigned ta = st + wm * WG_SUB;                             // dY sub-tile of this wave's 128 n rows
-        const unsigned tb = st + 2 * WG_SUB + (wn >> 1) * WG_SUB;         // X sub-tile holding this wave's 64 k cols
-        auto read_all = [&](WgFrags& f, int kk) {
+        const unsigned char* st = smem + buf * WG_STAGE;
+        wg_bf16x8 fa[2][4], fb[2][2];                             // fragments of sub-steps kk (even | odd set)
+        auto read_set = [&](int set, int kk) {
 #pragma unroll
-            for (int a = 0; a < 4; ++a) frag(ta, a * 32, kk, f.a[a][0], f.a[a][1]);
+            for (int a = 0; a < 4; ++a)
+                fa[set][a] = wg_join(wg_tr_read(st + oa[a][0] + kk * 4096), wg_tr_read(st + oa[a][1] + kk * 4096));
 #pragma unroll
-            for (int b = 0; b < 2; ++b) frag(tb, (wn & 1) * 64 + b * 32, kk, f.b[b][0], f.b[b][1]);
+            for (int b = 0; b < 2; ++b)
+                fb[set][b] = wg_join(wg_tr_read(st + ob[b][0] + kk * 4096), wg_tr_read(st + ob[b][1] + kk * 4096));
         };
-        // One fragment set in flight: with the set of sub-step kk + 1 prefetched as well the kernel needs 254 VGPRs,
-        // i.e. two of its waves fill a SIMD's register file and NOTHING else fits on the CU — the short BatchNorm
-        // kernels of the backward chain on the main stream then queue behind whole wgrad blocks (bnh_finalize: 7 -> 59 us
-        // per launch, x 105 launches per step).  At ~220 VGPRs a small wave still fits beside it.
-        WgFrags fr;
+        read_set(0, 0);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            read_all(fr, kk);
-            if (more) {
-                piece(kt + 1, buf ^ 1, 2 * kk);
-                piece(kt + 1, buf ^ 1, 2 * kk + 1);
-            }
-            wg_wait(fr);
-            wg_bf16x8 fa[4], fb[2];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) fa[a] = wg_join(fr.a[a][0], fr.a[a][1]);
-#pragma unroll
-            for (int b = 0; b < 2; ++b) fb[b] = wg_join(fr.b[b][0], fr.b[b][1]);
+            // two DMA pieces of the next k-step, then the fragments of the next sub-step, then this sub-step's MFMAs:
+            // reads and DMA issue ride in the shadow of the MFMAs
+            issue(kt + 1, buf ^ 1, 2 * kk, more, d_img, d_yo, d_xo);
+            issue(kt + 1, buf ^ 1, 2 * kk + 1, more, d_img, d_yo, d_xo);
+            if (kk + 1 < 4) read_set((kk + 1) & 1, kk + 1);
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1][a], fb[kk & 1][b], acc[a][b], 0, 0, 0);
         }
     }
 
