@@ -102,12 +102,22 @@ try:
         for it in range(1, warm + 1):
             tr.step(it)
         torch.cuda.synchronize()
+        if os.environ.get("HIAST_SYNC_DEBUG", "0") == "1":       # report every implicitly synchronising call of an iteration
+            torch.cuda.set_sync_debug_mode("warn")
+            tr.step(warm + 1)
+            torch.cuda.set_sync_debug_mode("default")
+            torch.cuda.synchronize()
         wait[0] = 0.0
         parts.clear()
         t0 = time.time()
+        idle = 0                                # iterations at whose end the device had already finished everything enqueued
         for it in range(warm + 1, warm + iters + 1):
             tr.step(it)
+            ev = torch.cuda.Event()
+            ev.record()
+            idle += int(ev.query())
         t_host = (time.time() - t0) / iters     # host time per iteration (enqueue + data), before the final drain
+        print("  device already idle at the end of %d of %d iterations (host-bound iterations)" % (idle, iters), flush=True)
         torch.cuda.synchronize()
         dt = (time.time() - t0) / iters
         print("  host loop %.1f ms/iter of which %.1f ms in next_target_batch()" % (t_host * 1e3, wait[0] / iters * 1e3),
