@@ -239,36 +239,41 @@ __global__ __launch_bounds__(256) void bnh_prep_fwd_kernel(const double* __restr
     }
 }
 
-// finalize + prep in one launch (single-rank forward: no all-reduce between them): a block owns 8 channels = 16
-// consecutive (Σx, Σx²) entries; the even lane of each pair derives mean / invstd / running statistics
+// finalize + prep in one launch (single-rank forward: no all-reduce between them): a block owns 2 channels = 4
+// consecutive (Σx, Σx²) entries and folds the partial rows with 64 row-lanes per entry (rows j, j + 64, ... per lane, then
+// the lanes in ascending order: a fixed order).  The 16-entry / 16-lane form of round 1 left a 256-channel layer with 32
+// blocks of 16 dependent loads each: 11 us for a launch that moves 0.5 MB, 103 times per step.
 __global__ __launch_bounds__(256) void bnh_finalize_prep_kernel(const float* __restrict__ partial, int nblk, int C,
                                                                 double count, float momentum, float eps,
                                                                 float* __restrict__ run_mean, float* __restrict__ run_var,
                                                                 float* __restrict__ save_mean,
                                                                 float* __restrict__ save_invstd)
 {
-    __shared__ double s[16][17];
-    const int e = threadIdx.x & 15, j = threadIdx.x >> 4;
-    const int i = blockIdx.x * 16 + e;
+    __shared__ double s[64][5];
+    const int e = threadIdx.x & 3, j = threadIdx.x >> 2;
+    const int i = blockIdx.x * 4 + e;
+    // the two threads that finish a channel ask for its running statistics now, not after the reduction
+    const int c = blockIdx.x * 2 + (int)threadIdx.x;
+    float rm = 0.f, rv = 0.f;
+    if (threadIdx.x < 2 && run_mean) { rm = run_mean[c]; rv = run_var[c]; }
     double acc = 0.0;
-    {   // sixteen rows in flight (a latency chain: with four the launch took 12 us for 2 MB), added in ascending order
+    {
         int b = j;
-        for (; b + 16 * 15 < nblk; b += 16 * 16) {
-            float v[16];
+        for (; b + 64 * 3 < nblk; b += 64 * 4) {        // four rows in flight per lane
+            float v[4];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = partial[(size_t)(b + 16 * u) * C * 2 + i];
+            for (int u = 0; u < 4; ++u) v[u] = partial[(size_t)(b + 64 * u) * C * 2 + i];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) acc += (double)v[u];
+            for (int u = 0; u < 4; ++u) acc += (double)v[u];
         }
-        for (; b < nblk; b += 16) acc += (double)partial[(size_t)b * C * 2 + i];
+        for (; b < nblk; b += 64) acc += (double)partial[(size_t)b * C * 2 + i];
     }
     s[j][e] = acc;
     __syncthreads();
-    if (j == 0 && (e & 1) == 0) {
+    if (threadIdx.x < 2) {
         double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) { s1 += s[q][e]; s2 += s[q][e + 1]; }
-        const int c = i >> 1;
+#pragma unroll 8
+        for (int q = 0; q < 64; ++q) { s1 += s[q][2 * threadIdx.x]; s2 += s[q][2 * threadIdx.x + 1]; }
         const double m = s1 / count;
         double var = s2 / count - m * m;
         var = var < 0.0 ? 0.0 : var;
@@ -277,8 +282,8 @@ __global__ __launch_bounds__(256) void bnh_finalize_prep_kernel(const float* __r
         save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
         if (run_mean) {
             const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-            run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * mean;
-            run_var[c] = (1.0f - momentum) * run_var[c] + momentum * (float)unb;
+            run_mean[c] = (1.0f - momentum) * rm + momentum * mean;
+            run_var[c] = (1.0f - momentum) * rv + momentum * (float)unb;
         }
     }
 }
@@ -520,7 +525,7 @@ extern "C" int hiast_bn_nhwc_apply_partial(const void* x, const void* res, void*
     long long nb = (M + (long long)rpp * BNH_ROWS_PER_BLOCK_PASS - 1) / ((long long)rpp * BNH_ROWS_PER_BLOCK_PASS);
     nb = nb < 1 ? 1 : (nb > BNH_APPLY_MAXBLK ? BNH_APPLY_MAXBLK : nb);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(hiast::bnh_finalize_prep_kernel, dim3(C * 2 / 16), dim3(256), 0, st, partial, nblk, C, count,
+    hipLaunchKernelGGL(hiast::bnh_finalize_prep_kernel, dim3(C / 2), dim3(256), 0, st, partial, nblk, C, count,
                        momentum, eps, running_mean, running_var, save_mean, save_invstd);
     HIAST_CHECK_LAUNCH();
 #define L(RES, RELU)                                                                                              \
