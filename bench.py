@@ -518,6 +518,8 @@ def main():
     cfg = make_cfg(world, args.trainer)
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):        # the package's progress prints ("%% freeze all BN layers" ...)
+        from hiast_amd.utils import utils as _u
+        _u.limit_cpu_threads()      # (N ranks per node: N OpenMP pools sized for the whole machine otherwise)
         hp = HotPath(cfg, device, rank, world, args.batch)   # must not precede the ONE JSON line on stdout
     timer = KernelTimer()
     timer.install()

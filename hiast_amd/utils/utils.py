@@ -25,6 +25,17 @@ def seed_everything(seed=888):
         torch.cuda.manual_seed(seed)
 
 
+def limit_cpu_threads(default=4):
+    """Cap torch's intra-op (OpenMP) pool in a process whose arithmetic runs on the device.  torch sizes the pool by the
+    machine's logical CPUs (256 on an MI355X host) whatever the process may use; after every small CPU op those threads
+    spin for a while, and beside the DataLoader workers they took the main thread's launch loop from 27 to 50-60 ms per
+    iteration (end-to-end trainer 131 -> 154 images/s with the cap, `profiles/r02_trainer_end_to_end.txt`) — with eight
+    ranks per node it is eight such pools.  HIAST_CPU_THREADS overrides the cap (0 = leave torch's default)."""
+    n = int(os.environ.get("HIAST_CPU_THREADS", default))
+    if n > 0 and torch.get_num_threads() > n:
+        torch.set_num_threads(n)
+
+
 def create_dir(path):
     if os.path.exists(path):
         warnings.warn("%s has existed" % path)

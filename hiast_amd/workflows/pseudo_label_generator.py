@@ -100,6 +100,8 @@ class BasePseudoGenerator:
 
     def __init__(self, cfg, engine=None, dataset=None):
         self.cfg = cfg
+        if torch.cuda.is_available():
+            utils.limit_cpu_threads()
         C = cfg.dataset.num_classes
         self.statics_class = np.zeros(C, dtype=np.int64)
         self.sample_stats = []

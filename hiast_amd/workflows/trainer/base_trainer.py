@@ -85,6 +85,8 @@ class BaseTrainer:
     # ---------------------------------------------------------------- setup
     def initialize(self):
         utils.seed_everything(self.cfg.train.random_seed)
+        if torch.cuda.is_available():
+            utils.limit_cpu_threads()
         self.world = self.cfg.train.gpu_num
         self.logger = None
         if self.gpu_index == 0:

@@ -35,6 +35,8 @@ class Validator:
     def __init__(self, cfg, device=None):
         self.cfg = cfg
         self.device = device if device is not None else utils.get_device()
+        if self.device.type == "cuda":
+            utils.limit_cpu_threads()
         self.initialize()
 
     def initialize(self):
