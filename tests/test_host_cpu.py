@@ -381,3 +381,26 @@ def test_set_mode_looks_at_the_wrapped_net():
     assert wrap.training and net.training and net[0].training
     utils.set_mode(wrap, False)
     assert not wrap.training and not net[0].training
+
+
+def test_limit_cpu_threads_caps_and_respects_override(monkeypatch):
+    """utils.limit_cpu_threads: torch's intra-op pool is capped (never raised), HIAST_CPU_THREADS overrides, 0 leaves it"""
+    import torch
+    from hiast_amd.utils import utils
+    before = torch.get_num_threads()
+    try:
+        torch.set_num_threads(6)
+        monkeypatch.setenv("HIAST_CPU_THREADS", "0")
+        utils.limit_cpu_threads()
+        assert torch.get_num_threads() == 6
+        monkeypatch.setenv("HIAST_CPU_THREADS", "8")
+        utils.limit_cpu_threads()
+        assert torch.get_num_threads() == 6            # a cap, not a setting
+        monkeypatch.delenv("HIAST_CPU_THREADS")
+        utils.limit_cpu_threads()
+        assert torch.get_num_threads() == 4
+        monkeypatch.setenv("HIAST_CPU_THREADS", "2")
+        utils.limit_cpu_threads()
+        assert torch.get_num_threads() == 2
+    finally:
+        torch.set_num_threads(before)
