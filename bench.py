@@ -259,7 +259,8 @@ class HotPath:
         from hiast_amd.utils import utils
         utils.set_mode(net, False)
         with torch.no_grad():
-            logits = net(self.weak, lowres=True)["logits_lowres"]     # fp32, like the reference generator
+            from hiast_amd import functional as HF
+            logits = HF.eval_forward_split(net, self.weak)["logits_lowres"]     # fp32, like the reference generator
             mp, am, hist = K.plabel_pass1(logits.contiguous(), H, W)
             hist = self._allreduce(hist)
             if self._hist_host is None:

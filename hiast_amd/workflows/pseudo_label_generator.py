@@ -68,7 +68,8 @@ class HipPlabelEngine:
         if imgs.dtype == torch.uint8:        # dataset.device_transform: ToTensor + Normalize here, on the device
             from hiast_amd.sseg.datasets.utils import MEAN, STD
             imgs = K.normalize_u8(imgs, MEAN, STD)
-        out = self.model(imgs, lowres=True)
+        from hiast_amd import functional as HF
+        out = HF.eval_forward_split(self.model, imgs)
         H, W = out["size"]
         self._mp, self._am, hist = K.plabel_pass1(out["logits_lowres"].float().contiguous(), H, W)
         return hist

@@ -190,3 +190,32 @@ def test_bottleneck_backward_with_and_without_statistics_fusion(monkeypatch):
     for n in gw1:
         c = float((gw0[n] * gw1[n]).sum() / np.sqrt((gw0[n] ** 2).sum() * (gw1[n] ** 2).sum() + 1e-30))
         assert c >= 0.9995, (n, c)
+
+
+def test_eval_forward_in_sub_batches(monkeypatch):
+    """HF.eval_forward_split: the fp32-class inference forward of 8 images as two / four sub-batches on their own streams
+    equals one forward up to the library's batch-dependent choice of the stem convolution's algorithm (3e-5 of max on this
+    random-init net; argmax equal) — also right after the weights changed (the packed copies are refreshed before the
+    streams fork: a stale or half-written copy would be off by far more than rounding)"""
+    from hiast_amd import functional as HF
+    cfg, net = _model(781)
+    net.eval()
+    x = torch.from_numpy(synth.normal_f32(930, (8, 3, 64, 128))).cuda()
+
+    def close(a, b):
+        return bool((a - b).abs().max() <= 2e-4 * b.abs().max()) and float((a.argmax(1) == b.argmax(1)).float().mean()) >= 0.999
+
+    with torch.no_grad():
+        ref = net(x, lowres=True)["logits_lowres"].clone()
+        for parts in (2, 4):
+            out = HF.eval_forward_split(net, x, parts)["logits_lowres"]
+            torch.cuda.synchronize()
+            assert close(out, ref)
+        # weights move (as after an EMA update): every sub-batch must see the new packed copies
+        for p in net.parameters():
+            p.data.mul_(1.01)
+        torch.autograd.graph.increment_version(list(net.parameters()))
+        out = HF.eval_forward_split(net, x, 2)["logits_lowres"].clone()
+        ref2 = net(x, lowres=True)["logits_lowres"]
+        torch.cuda.synchronize()
+        assert close(out, ref2) and not close(ref2, ref)
