@@ -294,3 +294,29 @@ def test_config5_synthia_source_round(tmp_path):
     w16, w13, iou = metrics_ref.miou(inter.astype(np.float64), union.astype(np.float64), synthia=True)
     assert abs(100 * miou16 - 100 * w16) <= 0.05 and abs(100 * v.miou_13 - 100 * w13) <= 0.05, (miou16, w16, v.miou_13, w13)
     assert iou[9] == 0 and iou[14] == 0 and iou[16] == 0 and w16 > 0
+
+
+def test_bench_pseudo_label_pass_on_its_own_stream_gives_the_same_labels(monkeypatch):
+    """bench.py enqueues the pseudo-label forward on a stream of its own beside the training forwards; the label map, the
+    thresholds and the per-class statistics equal those of the in-order pass (same kernels, same batch, same weights)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod_e2e", os.path.join(os.path.dirname(__file__), "..", "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    torch.cuda.set_device(0)
+    cfg = bench.make_cfg(1, "ConsistencySelfTrainingTrainer")
+    hp = bench.HotPath(cfg, torch.device("cuda", 0), 0, 1, 8)
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("HIAST_BENCH_PL_STREAM", flag)
+        hp.thr = 0.9 * np.ones(19)
+        mp, am = hp.plabel_begin_async()
+        out, teacher = hp.train_forward()                  # the forwards that run beside it in a step
+        plbl = hp.plabel_finish(mp, am)
+        torch.cuda.synchronize()
+        res[flag] = (plbl.cpu().numpy().copy(), hp.thr.copy(), [t.cpu().numpy().copy() for t in hp._stats])
+        assert hp._pl_join == (flag == "1")
+    assert np.array_equal(res["0"][0], res["1"][0])
+    assert np.array_equal(res["0"][1].view(np.uint64), res["1"][1].view(np.uint64))
+    for a, b in zip(res["0"][2], res["1"][2]):
+        assert np.array_equal(a, b)
