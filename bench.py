@@ -217,6 +217,8 @@ class HotPath:
         self.cfg, self.device, self.rank, self.world, self.B = cfg, device, rank, world, B
         utils.seed_everything(cfg.train.random_seed)
         model = utils.init_model(cfg).to(device)
+        if os.environ.get("HIAST_BENCH_RAW_INIT", "0") != "1":      # =1: the plain random init — NaN weights from step 3 on
+            self._spread_head(model, B)                             # (rounds 1-2 were measured like that: DESIGN §6)
         self.opt, _ = utils.init_optimizers(cfg, model)
         self.sched = utils.init_schedulers(cfg, self.opt)
         self.amp = autocast_dtype(cfg)
@@ -240,6 +242,41 @@ class HotPath:
         self.class_mean_probs = np.zeros(C)
         self._hist_host = self._hist_ready = None
         self.pipelined = os.environ.get("HIAST_BENCH_SERIAL", "0") != "1"
+
+    @staticmethod
+    def _spread_head(model, B):
+        """A random-init DeepLab predicts a near-uniform softmax (max-prob 0.06-0.1): the IAS thresholds then rise above
+        every pixel within two steps, the confident set is empty, the reference's losses are 0/0 = NaN, and from the third
+        step on the whole step would run on NaN weights — constant bit patterns on which the chip holds a higher clock
+        than on data (MI355X_MICROARCH.md, DVFS items 1 and 7).  Before the optimiser and the EMA copy exist, the random
+        init is therefore brought into the state a trained checkpoint is in: (i) the BatchNorm running statistics are set
+        to the batch statistics of the synthetic batch (one training-mode forward with momentum 1: the EMA teacher copies
+        these buffers from the student after every step and normalises with them), (ii) the classifier weights are scaled
+        so that the low-res logits have standard deviation 6 — max-probs spread over 0.2-1.0 as SURVEY.md §8(c) asks for
+        configs 2/3.  The step then keeps running on finite, varied data (tools/dbg/soak_bench_steps.py)."""
+        dev = next(model.parameters()).device
+        g = torch.Generator(device="cpu").manual_seed(1234)
+        x = torch.randn(min(B, 4), 3, H, W, generator=g).to(dev)
+        bns = [m for m in model.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+        mom = [m.momentum for m in bns]
+        was = model.training
+        with torch.no_grad():
+            for m in bns:
+                m.momentum = 1.0
+            model.train()
+            model(x, lowres=True)
+            for m, v in zip(bns, mom):
+                m.momentum = v
+            model.eval()
+            std = float(model(x, lowres=True)["logits_lowres"].float().std())
+            k = 6.0 / max(std, 1e-12)
+            head = model.seg_model.aspp
+            for m in head.conv2d_list:
+                m.weight.mul_(k)
+                if m.bias is not None:
+                    m.bias.mul_(k)
+            torch.autograd.graph.increment_version([p for p in head.parameters()])
+        model.train(was)
 
     def _allreduce(self, t):
         if self.world > 1:

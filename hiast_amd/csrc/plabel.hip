@@ -64,15 +64,22 @@ __global__ __launch_bounds__(256) void plabel_pass1_kernel(
             const unsigned bin = __half_as_ushort(__float2half_rn(prob));
             if (bin < HIAST_NBINS) key = (unsigned)am * HIAST_NBINS + bin;
         }
-        // wave-aggregated histogram update
+        // Histogram update.  Two wave-aggregated rounds take out the keys many lanes share (flat regions: one saturated
+        // bin per class — 64 same-address atomics would serialise in the L2), the lanes that are left add their own
+        // count: on realistic confidences nearly every lane of a wave holds a different (class, fp16 bin) key, and the
+        // fully aggregated loop then ran 64 ballot / shuffle rounds per wave row (1.85 ms per 8-image batch; the integer
+        // sums are the same in any order).
         unsigned long long todo = __ballot(key != 0xFFFFFFFFu);
-        while (todo) {
+#pragma unroll
+        for (int round = 0; round < 2; ++round) {
+            if (!todo) break;
             const int leader = __ffsll((long long)todo) - 1;
             const unsigned k = __shfl(key, leader, 64);
             const unsigned long long same = __ballot(key == k);
             if (lane_id() == leader) atomicAdd(&hist[k], (unsigned)__popcll(same));
             todo &= ~same;
         }
+        if ((todo >> lane_id()) & 1ull) atomicAdd(&hist[key], 1u);
     }
 }
 
