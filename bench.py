@@ -289,6 +289,15 @@ class HotPath:
     # device works through them while the host computes the thresholds, and the launch queue never runs dry behind
     # the read-back (it did: 0.8 ms of idle device per step + a host that stayed just-in-time for the rest of the step,
     # profiles/r01_s3_critical_before.txt).  No work is skipped or reordered across steps.
+    def _graphed(self, net, amp):
+        """the inference forward of `net` (no autograd; under autocast(amp) if given) as HF.GraphedEval"""
+        from hiast_amd import functional as HF
+        g = self.__dict__.setdefault("_graphs", {})
+        key = (id(net), amp)
+        if key not in g:
+            g[key] = HF.GraphedEval(net, amp)
+        return g[key]
+
     def plabel_begin(self):
         """eval forward (fp32-class) + pass 1 + asynchronous read-back of the histogram"""
         from hiast_amd import kernels as K
@@ -297,8 +306,9 @@ class HotPath:
         utils.set_mode(net, False)
         with torch.no_grad():
             from hiast_amd import functional as HF
-            logits = HF.eval_forward_split(net, self.weak, None if self.use_side else 1)["logits_lowres"]     # fp32, like the
-                                                                                                     # reference generator
+            # fp32 like the reference generator (HIAST_GRAPH_EVAL=1: replayed from a captured HIP graph, except on the steps
+            # that time every launch)
+            logits = self._graphed(net, None)(self.weak, parts=None if self.use_side else 1, eager=not self.use_side)
             mp, am, hist = K.plabel_pass1(logits.contiguous(), H, W)
             hist = self._allreduce(hist)
             if self._hist_host is None:
@@ -358,9 +368,8 @@ class HotPath:
             utils.set_mode(self.ema, False)
             side = self.side if (self.use_side and os.environ.get("HIAST_NO_SIDE_STREAM", "0") != "1") else main
             side.wait_stream(main)
-            with torch.cuda.stream(side), torch.no_grad(), torch.autocast("cuda", dtype=self.amp,
-                                                                          enabled=self.amp is not None):
-                teacher_lr = self.ema(self.weak, lowres=True)["logits_lowres"].float()
+            with torch.cuda.stream(side):
+                teacher_lr = self._graphed(self.ema, self.amp)(self.weak, parts=1, eager=not self.use_side)
         with torch.autocast("cuda", dtype=self.amp, enabled=self.amp is not None):
             out = self.model(self.strong, lowres=True)
         if self.teacher and side is not main:

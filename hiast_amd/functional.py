@@ -398,6 +398,25 @@ _eval_streams = {}
 _eval_trunks = {}
 
 
+def prepack_eval_trunks(model, x):
+    """bring the kernel-format weight copies of the model's trunk(s) up to date for an inference forward of x on the
+    current stream (one launch per trunk, only when a weight has changed) -> the (trunk, plan) pairs in use"""
+    trunks = _eval_trunks.get(id(model))
+    if trunks is None or trunks[0]() is not model:
+        import weakref
+        trunks = _eval_trunks[id(model)] = (weakref.ref(model), [m for m in model.modules()
+                                                                 if hasattr(m, "prepack") and hasattr(m, "fast_eval_planes")])
+    used = []
+    for m in trunks[1]:
+        PL = m.fast_eval_planes(x)
+        if PL:
+            m.prepack(PL)
+            ent = m.__dict__.get("_hiast_plans", {}).get((PL, False))
+            if ent is not None:
+                used.append(ent[0])
+    return used
+
+
 def eval_forward_split(model, x, parts=None):
     """low-resolution logits of an inference forward, computed as `parts` sub-batches on streams of their own (same
     values: an eval forward treats every image alone).  On the fp32-class pseudo-label forward of 8 images two
@@ -414,13 +433,7 @@ def eval_forward_split(model, x, parts=None):
     # kernel-format weight copies that are cached per module (ResNet.prepack) are brought up to date HERE, on the main
     # stream, before the sub-batches fork: the first forward to notice a stale copy re-packs it on ITS stream, and the
     # other streams would read the buffers while they are being written
-    trunks = _eval_trunks.get(id(model))
-    if trunks is None:
-        trunks = _eval_trunks[id(model)] = [m for m in model.modules() if hasattr(m, "prepack") and hasattr(m, "fast_eval_planes")]
-    for m in trunks:
-        PL = m.fast_eval_planes(x)
-        if PL:
-            m.prepack(PL)
+    prepack_eval_trunks(model, x)
     key = (x.device, parts)
     side = _eval_streams.get(key)
     if side is None:
@@ -438,6 +451,83 @@ def eval_forward_split(model, x, parts=None):
     out = dict(outs[0])
     out["logits_lowres"] = torch.cat([o["logits_lowres"] for o in outs], 0)
     return out
+
+
+class GraphedEval:
+    """`model(x, lowres=True)['logits_lowres']` of an inference forward (no autograd, eval mode), optionally replayed from a
+    captured HIP graph (HIAST_GRAPH_EVAL=1; default: eager calls).  The graph holds exactly the launches of the eager
+    forward (same kernels, same order, sub-batches on the same streams: bit-identical logits, tests/test_gpu_round2.py);
+    the kernel-format weight copies are refreshed OUTSIDE of it, before every replay, by the same `prepack` call the
+    eager forward makes (the teacher's weights change with every EMA step, the buffers they are packed into do not).
+    The first WARMUP calls per input signature run eagerly (library algorithm search, lazy allocations), the next one
+    captures; the returned tensor is then the graph's own output buffer, overwritten by the next call with the same
+    signature.  Off by default because it does not pay on this path: the ~330 launches of a forward cost the host 3 ms
+    (pseudo-label forward: 3.0 -> 0.56 ms of enqueue time) but the host runs 17-48 ms ahead of the device anyway — bench.py
+    61.4 (graphs) vs 60.2 ms/step (eager) on one box, the DataLoader-fed trainer 51.2 vs 50.7 ms/iteration with the device
+    never idle at the end of an iteration in either mode."""
+    WARMUP = 2
+
+    def __init__(self, model, amp_dtype=None, parts=1):
+        self.model, self.amp_dtype, self.parts = model, amp_dtype, parts
+        self.entries = {}
+        self.enabled = os.environ.get("HIAST_GRAPH_EVAL", "0") == "1"
+
+    def _autocast(self):
+        return torch.autocast("cuda", dtype=self.amp_dtype or torch.bfloat16, enabled=self.amp_dtype is not None,
+                              cache_enabled=False)
+
+    def _eager(self, x, parts):
+        with torch.no_grad(), self._autocast():
+            return eval_forward_split(self.model, x, parts)["logits_lowres"].float()
+
+    def _fingerprint(self):
+        ps = self.model.__dict__.get("_hiast_fp_params")
+        if ps is None:
+            allp = list(self.model.parameters()) + list(self.model.buffers())
+            ps = self.model.__dict__["_hiast_fp_params"] = [allp[0], allp[len(allp) // 2], allp[-1]]
+        return tuple(p.data_ptr() for p in ps)
+
+    def __call__(self, x, parts=None, eager=False):
+        """parts: sub-batches (eval_forward_split) for this call, default the constructor's; eager: no graph this time"""
+        parts = self.parts if parts is None else parts
+        if eager or not self.enabled or not x.is_cuda or self.model.training:
+            return self._eager(x, parts)
+        key = (tuple(x.shape), x.dtype, x.device, self.amp_dtype, parts)
+        e = self.entries.get(key)
+        if e is None:
+            e = self.entries[key] = {"calls": 0, "graph": None}
+        if e["graph"] is not None:
+            with torch.no_grad(), self._autocast():
+                plans = prepack_eval_trunks(self.model, x)
+            if self._fingerprint() == e["fp"] and len(plans) == len(e["plans"]) and all(a is b for a, b in zip(plans, e["plans"])):
+                e["x"].copy_(x)
+                e["graph"].replay()
+                return e["y"]
+            e["graph"], e["calls"] = None, 0            # the model's storage has moved: start over
+        e["calls"] += 1
+        if e["calls"] <= self.WARMUP or e.get("failed"):
+            return self._eager(x, parts)
+        try:
+            with torch.no_grad(), self._autocast():
+                plans = prepack_eval_trunks(self.model, x)      # nothing stale is left to be packed inside the graph
+            xs = torch.empty_like(x)
+            xs.copy_(x)
+            g = torch.cuda.CUDAGraph()
+            cur = torch.cuda.current_stream()
+            cap = torch.cuda.Stream(device=x.device)
+            cap.wait_stream(cur)
+            with torch.cuda.graph(g, stream=cap, capture_error_mode="thread_local"):
+                y = self._eager(xs, parts)
+            cur.wait_stream(cap)
+        except Exception as err:            # the eager forward is the same computation: say so and go on
+            import warnings
+            warnings.warn("hiast_amd: graph capture of the inference forward failed (%s: %s); running it eagerly"
+                          % (type(err).__name__, err))
+            e["failed"] = True
+            return self._eager(x, parts)
+        e.update(graph=g, x=xs, y=y, plans=plans, fp=self._fingerprint())
+        g.replay()
+        return y
 
 
 def enable_wgrad_overlap(on=True):

@@ -69,9 +69,12 @@ class HipPlabelEngine:
             from hiast_amd.sseg.datasets.utils import MEAN, STD
             imgs = K.normalize_u8(imgs, MEAN, STD)
         from hiast_amd import functional as HF
-        out = HF.eval_forward_split(self.model, imgs)
-        H, W = out["size"]
-        self._mp, self._am, hist = K.plabel_pass1(out["logits_lowres"].float().contiguous(), H, W)
+        if getattr(self, "_fwd", None) is None or self._fwd.model is not self.model:
+            # the fp32-class inference forward (two sub-batches on two streams for 8 or more images); HIAST_GRAPH_EVAL=1:
+            # replayed from a captured HIP graph once a batch shape has been seen twice
+            self._fwd = HF.GraphedEval(self.model, None)
+        H, W = imgs.shape[2:]
+        self._mp, self._am, hist = K.plabel_pass1(self._fwd(imgs).contiguous(), H, W)
         return hist
 
     @torch.no_grad()

@@ -8,6 +8,7 @@ import os
 import numpy as np
 import torch
 
+from hiast_amd import functional as HF
 from hiast_amd.sseg.datasets import utils as du
 from hiast_amd.sseg.datasets.preprocessor import CopyPaste
 from hiast_amd.utils import utils
@@ -66,9 +67,11 @@ class ConsistencySelfTrainingTrainer(BaseTrainer):
             self._side_stream = torch.cuda.Stream(device=t_weak_img.device)
         side = self._side_stream
         side.wait_stream(main)
-        with torch.cuda.stream(side), torch.no_grad(), torch.autocast("cuda", dtype=self.amp_dtype,
-                                                                      enabled=self.amp_dtype is not None):
-            teacher_lr = self.ema_model(t_weak_img, lowres=True)["logits_lowres"].float()
+        if getattr(self, "_teacher_fwd", None) is None or self._teacher_fwd.model is not self.ema_model:
+            # no-grad eval forward under autocast(amp_dtype) (HIAST_GRAPH_EVAL=1: replayed from a captured HIP graph)
+            self._teacher_fwd = HF.GraphedEval(self.ema_model, self.amp_dtype, parts=1)
+        with torch.cuda.stream(side):
+            teacher_lr = self._teacher_fwd(t_weak_img)
         utils.set_mode(self.model, True)
         with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
             out = self.model(t_strong_img, lowres=True)

@@ -219,3 +219,38 @@ def test_eval_forward_in_sub_batches(monkeypatch):
         ref2 = net(x, lowres=True)["logits_lowres"]
         torch.cuda.synchronize()
         assert close(out, ref2) and not close(ref2, ref)
+
+
+@pytest.mark.parametrize("amp", [None, torch.bfloat16])
+def test_graphed_inference_forward_replays_the_eager_launches(amp, monkeypatch):
+    """HF.GraphedEval: two eager calls, then the forward is captured into a HIP graph and replayed.  The graph holds the
+    launches of the eager forward, so its logits are the eager logits bit for bit — for a new input, after the weights
+    moved (the packed copies are refreshed outside of the graph, as after an EMA step), and for the two-sub-batch form;
+    without HIAST_GRAPH_EVAL=1 nothing is captured."""
+    from hiast_amd import functional as HF
+    monkeypatch.setenv("HIAST_GRAPH_EVAL", "1")
+    cfg, net = _model(782)
+    net.eval()
+    xs = [torch.from_numpy(synth.normal_f32(940 + i, (4, 3, 64, 128))).cuda() for i in range(5)]
+
+    for parts in (1, 2):
+        g = HF.GraphedEval(net, amp, parts=parts)
+        for i, x in enumerate(xs):
+            if i == 4:          # weights move: replay must see them
+                for p in net.parameters():
+                    p.data.mul_(1.01)
+                torch.autograd.graph.increment_version(list(net.parameters()))
+            out = g(x).clone()
+            ref = g(x, eager=True)
+            torch.cuda.synchronize()
+            assert out.dtype == torch.float32 and out.shape == ref.shape
+            assert torch.equal(out, ref), (parts, i, float((out - ref).abs().max()))
+        e = list(g.entries.values())
+        assert len(e) == 1 and e[0]["graph"] is not None and not e[0].get("failed"), "the forward was never captured"
+    assert not torch.equal(g(xs[0]).clone(), g(xs[1]))
+
+    monkeypatch.delenv("HIAST_GRAPH_EVAL")
+    g = HF.GraphedEval(net, amp)
+    for x in xs[:4]:
+        g(x)
+    assert not g.entries
