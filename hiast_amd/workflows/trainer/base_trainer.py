@@ -49,6 +49,30 @@ def _worker_init(_worker_id):
         pass
 
 
+class _EpochChain(torch.utils.data.Sampler):
+    """Batch sampler over a DistributedSampler that goes on into the next epoch instead of ending: the batches are those of
+    `set_epoch(e)` + a fresh DataLoader iterator per epoch (base_trainer.py:95-110 of the reference restarts its iterator on
+    StopIteration), without the restart — the prefetch queues of the persistent workers run dry at every epoch boundary and
+    the first batch of the new iterator takes a whole batch time of ONE worker (~0.25 s at 1024x512 with CopyPaste: 4.5 ms
+    per iteration on a 448-image set, 1.5 % at Cityscapes size).  HIAST_EPOCH_RESTART=1 keeps the restart."""
+
+    def __init__(self, sampler, batch_size, drop_last):
+        self.sampler, self.batch_size, self.drop_last = sampler, batch_size, drop_last
+
+    def __iter__(self):
+        while True:
+            n = 0
+            for b in torch.utils.data.BatchSampler(self.sampler, self.batch_size, self.drop_last):
+                n += 1
+                yield b
+            if n == 0:          # fewer samples than one batch: nothing to chain
+                return
+            self.sampler.set_epoch(self.sampler.epoch + 1)
+
+    def __len__(self):          # batches per epoch
+        return len(torch.utils.data.BatchSampler(self.sampler, self.batch_size, self.drop_last))
+
+
 class _Bare(torch.nn.Module):
     """`.module` indirection for a single process, so trainers can write model.module.* like under DDP"""
 
@@ -132,10 +156,12 @@ class BaseTrainer:
         # through the worker pipes and PCIe).  HIAST_HOST_TRANSFORM=1 keeps the reference's float32 / int64 batches.
         ds.device_transform = os.environ.get("HIAST_HOST_TRANSFORM", "0") != "1"
         sampler = DistributedSampler(ds, num_replicas=self.world, rank=self.gpu_index, shuffle=shuffle)
-        return sampler, DataLoader(ds, batch_size, sampler=sampler, num_workers=self.cfg.dataset.num_workers,
-                                   pin_memory=True, drop_last=drop_last,
-                                   persistent_workers=self.cfg.dataset.num_workers > 0,
-                                   worker_init_fn=_worker_init if self.cfg.dataset.num_workers > 0 else None)
+        nw = self.cfg.dataset.num_workers
+        kw = dict(num_workers=nw, pin_memory=True, persistent_workers=nw > 0, worker_init_fn=_worker_init if nw > 0 else None)
+        if shuffle and drop_last and os.environ.get("HIAST_EPOCH_RESTART", "0") != "1":
+            # training loaders: one endless iterator over the epochs (same batches, no restart at the boundaries)
+            return sampler, DataLoader(ds, batch_sampler=_EpochChain(sampler, batch_size, drop_last), **kw)
+        return sampler, DataLoader(ds, batch_size, sampler=sampler, drop_last=drop_last, **kw)
 
     def build_train_data_reader(self):
         s = self.cfg.dataset.source

@@ -404,3 +404,31 @@ def test_limit_cpu_threads_caps_and_respects_override(monkeypatch):
         assert torch.get_num_threads() == 2
     finally:
         torch.set_num_threads(before)
+
+
+def test_training_loader_chains_epochs_like_restarted_iterators():
+    """BaseTrainer's training DataLoader walks on into the next epoch without a new iterator (_EpochChain); the batches
+    are those of the reference's loop: iterator per epoch, set_epoch(epoch + 1) on StopIteration, incomplete batch dropped."""
+    import torch
+    from torch.utils.data import DataLoader, DistributedSampler
+    from hiast_amd.workflows.trainer.base_trainer import _EpochChain
+    ds = list(range(23))
+    ref_s = DistributedSampler(ds, num_replicas=2, rank=1, shuffle=True)
+    ref_l = DataLoader(ds, 4, sampler=ref_s, drop_last=True)
+    want, it = [], iter(ref_l)
+    while len(want) < 9:
+        try:
+            want.append(next(it).tolist())
+        except StopIteration:
+            ref_s.set_epoch(ref_s.epoch + 1)
+            it = iter(ref_l)
+    s = DistributedSampler(ds, num_replicas=2, rank=1, shuffle=True)
+    loader = DataLoader(ds, batch_sampler=_EpochChain(s, 4, True))
+    assert len(loader) == len(ref_l) == 3
+    it = iter(loader)
+    got = [next(it).tolist() for _ in range(9)]
+    assert got == want and s.epoch >= 2
+    assert want[0] != want[3]                       # the epochs are shuffled differently
+    # a dataset smaller than one batch ends instead of spinning
+    tiny = DistributedSampler(list(range(3)), num_replicas=1, rank=0, shuffle=True)
+    assert list(_EpochChain(tiny, 4, True)) == []

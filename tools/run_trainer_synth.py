@@ -133,6 +133,37 @@ try:
             tr.next_target_batch()
         dl = (time.time() - t0) / iters
         print("DataLoader alone, %s: %.1f ms/batch = %.1f images/s with %d workers" % (tag, dl * 1e3, bs / dl, nw), flush=True)
+        # the same trainer on ONE batch, workers idle: (a) host-resident batch (H2D + normalise + step every iteration),
+        # (b) device-resident batch (the step alone) — what the device needs for an iteration on this data
+        if os.environ.get("HIAST_E2E_FIXED", "1") == "1":
+            from hiast_amd.sseg.datasets import utils as du_
+            b = tr.next_target_batch()
+            time.sleep(3.0)                     # the workers fill their prefetch queues and go idle
+            tr.next_target_batch = lambda: b
+            for label, resident in (("host-resident", False), ("device-resident", True)):
+                orig = du_.to_device_batch
+                if resident:
+                    cache = {}
+
+                    def cached(imgs, lbl, dev, _o=orig, _c=cache):
+                        if "v" not in _c:
+                            _c["v"] = _o(imgs, lbl, dev)
+                        return _c["v"]
+                    du_.to_device_batch = cached
+                try:
+                    for it in range(3):
+                        tr.step(10 ** 5 + it)
+                    torch.cuda.synchronize()
+                    t0 = time.time()
+                    for it in range(iters):
+                        tr.step(10 ** 5 + 10 + it)
+                    th = (time.time() - t0) / iters
+                    torch.cuda.synchronize()
+                    dt = (time.time() - t0) / iters
+                finally:
+                    du_.to_device_batch = orig
+                print("  one %s batch, workers idle: %.1f ms/iter (host loop %.1f)" % (label, dt * 1e3, th * 1e3), flush=True)
+            del tr.next_target_batch
         tr.t_iter = tr.t_loader = None          # stop this trainer's worker processes before the next measurement
         del tr
         import gc
