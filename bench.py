@@ -310,13 +310,24 @@ class HotPath:
             # that time every launch)
             logits = self._graphed(net, None)(self.weak, parts=None if self.use_side else 1, eager=not self.use_side)
             mp, am, hist = K.plabel_pass1(logits.contiguous(), H, W)
-            hist = self._allreduce(hist)
-            if self._hist_host is None:
-                self._hist_host = torch.empty(hist.shape, dtype=hist.dtype, pin_memory=True)
-                self._hist_ready = torch.cuda.Event()
-            self._hist_host.copy_(hist, non_blocking=True)
-            self._hist_ready.record()
+            if self.world > 1 and getattr(self, "_pl_on_side", False):
+                # N > 1, pass on its own stream: the histogram all-reduce is ISSUED by plabel_finish(), after the student
+                # forward has issued its SyncBN all-reduces — a communicator executes its operations in issue order, and
+                # this one waits for the whole pseudo-label forward: issued here it would hold back every SyncBN
+                # all-reduce behind it, i.e. the student forward would no longer run beside this pass
+                self._hist_dev = hist
+            else:
+                self._hist_exchange(hist)
         return mp, am
+
+    def _hist_exchange(self, hist):
+        """all-reduce of the per-class confidence histogram + asynchronous read-back (on the current stream)"""
+        hist = self._allreduce(hist)
+        if self._hist_host is None:
+            self._hist_host = torch.empty(hist.shape, dtype=hist.dtype, pin_memory=True)
+            self._hist_ready = torch.cuda.Event()
+        self._hist_host.copy_(hist, non_blocking=True)
+        self._hist_ready.record()
 
     def plabel_begin_async(self):
         """plabel_begin() on a stream of its own, beside the two forwards of the training step (which do not depend on
@@ -329,8 +340,12 @@ class HotPath:
         if not hasattr(self, "_pl_stream"):
             self._pl_stream = torch.cuda.Stream(device=self.device)
         self._pl_stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self._pl_stream):
-            mp, am = self.plabel_begin()
+        self._pl_on_side = True
+        try:
+            with torch.cuda.stream(self._pl_stream):
+                mp, am = self.plabel_begin()
+        finally:
+            self._pl_on_side = False
         self._pl_join = True
         return mp, am
 
@@ -339,6 +354,10 @@ class HotPath:
         from hiast_amd import kernels as K
         from hiast_amd.workflows import ias_math
         with torch.no_grad():
+            if getattr(self, "_hist_dev", None) is not None:        # (N > 1: see plabel_begin)
+                with torch.cuda.stream(self._pl_stream):
+                    self._hist_exchange(self._hist_dev)
+                self._hist_dev = None
             if getattr(self, "_pl_join", False):
                 torch.cuda.current_stream().wait_stream(self._pl_stream)
                 mp.record_stream(torch.cuda.current_stream()); am.record_stream(torch.cuda.current_stream())
