@@ -461,16 +461,19 @@ class GraphedEval:
     eager forward makes (the teacher's weights change with every EMA step, the buffers they are packed into do not).
     The first WARMUP calls per input signature run eagerly (library algorithm search, lazy allocations), the next one
     captures; the returned tensor is then the graph's own output buffer, overwritten by the next call with the same
-    signature.  Off by default because it does not pay on this path: the ~330 launches of a forward cost the host 3 ms
-    (pseudo-label forward: 3.0 -> 0.56 ms of enqueue time) but the host runs 17-48 ms ahead of the device anyway — bench.py
-    61.4 (graphs) vs 60.2 ms/step (eager) on one box, the DataLoader-fed trainer 51.2 vs 50.7 ms/iteration with the device
-    never idle at the end of an iteration in either mode."""
+    signature.  Off by default in the trainers and bench.py, where it does not pay: the ~330 launches of a forward cost
+    the host 3 ms (pseudo-label forward: 3.0 -> 0.56 ms of enqueue time) but the host runs 17-48 ms ahead of the device anyway
+    — bench.py 61.4 (graphs) vs 60.2 ms/step (eager) on one box, the DataLoader-fed trainer unchanged.  The generator, whose
+    host used to start every batch without a lead over the device, gained 10 % from it (147.6 -> 163.0 images/s) until its
+    batches were pipelined (forward of batch t+1 enqueued before the histogram of batch t is awaited): 487 eager vs 473
+    replayed."""
     WARMUP = 2
 
-    def __init__(self, model, amp_dtype=None, parts=1):
+    def __init__(self, model, amp_dtype=None, parts=1, graph=False):
+        """graph: this caller's default; HIAST_GRAPH_EVAL=1 / 0 overrides it for every caller"""
         self.model, self.amp_dtype, self.parts = model, amp_dtype, parts
         self.entries = {}
-        self.enabled = os.environ.get("HIAST_GRAPH_EVAL", "0") == "1"
+        self.enabled = os.environ.get("HIAST_GRAPH_EVAL", "1" if graph else "0") == "1"
 
     def _autocast(self):
         return torch.autocast("cuda", dtype=self.amp_dtype or torch.bfloat16, enabled=self.amp_dtype is not None,

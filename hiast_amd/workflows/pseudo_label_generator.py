@@ -58,24 +58,72 @@ class HipPlabelEngine:
         self.model, self.device, self.C = model, device, num_classes
 
     @torch.no_grad()
-    def pass1(self, imgs):
+    def begin(self, imgs):
+        """forward + pass 1 of one batch, enqueued on the current stream; nothing waits.  -> state for hist_host() / finish().
+        The generators keep the device busy with the NEXT batch's begin() while the host turns this batch's histogram into
+        thresholds and its label maps into PNG files; everything that follows pass 1 of a batch (histogram exchange and
+        read-back, pass 2, read-back of the maps) runs on a second stream behind the state's event, so it does not queue up
+        behind the next forward."""
         from hiast_amd import kernels as K
         C = self.C
+        st = {"mp": None, "am": None}
         if imgs is None or imgs.shape[0] == 0:
-            self._mp = self._am = None
-            return torch.zeros((C, ias_math.NBINS), dtype=torch.int32, device=self.device)
-        imgs = imgs.to(self.device, non_blocking=True)
-        if imgs.dtype == torch.uint8:        # dataset.device_transform: ToTensor + Normalize here, on the device
-            from hiast_amd.sseg.datasets.utils import MEAN, STD
-            imgs = K.normalize_u8(imgs, MEAN, STD)
-        from hiast_amd import functional as HF
-        if getattr(self, "_fwd", None) is None or self._fwd.model is not self.model:
-            # the fp32-class inference forward (two sub-batches on two streams for 8 or more images); HIAST_GRAPH_EVAL=1:
-            # replayed from a captured HIP graph once a batch shape has been seen twice
-            self._fwd = HF.GraphedEval(self.model, None)
-        H, W = imgs.shape[2:]
-        self._mp, self._am, hist = K.plabel_pass1(self._fwd(imgs).contiguous(), H, W)
-        return hist
+            st["hist"] = torch.zeros((C, ias_math.NBINS), dtype=torch.int32, device=self.device)
+        else:
+            imgs = imgs.to(self.device, non_blocking=True)
+            if imgs.dtype == torch.uint8:        # dataset.device_transform: ToTensor + Normalize here, on the device
+                from hiast_amd.sseg.datasets.utils import MEAN, STD
+                imgs = K.normalize_u8(imgs, MEAN, STD)
+            from hiast_amd import functional as HF
+            if getattr(self, "_fwd", None) is None or self._fwd.model is not self.model:
+                # the fp32-class inference forward (two sub-batches on two streams for 8 or more images); HIAST_GRAPH_EVAL=1:
+                # replayed from a captured HIP graph once a batch shape has been seen twice (no gain once the batches are
+                # pipelined: 473 vs 487 images/s)
+                self._fwd = HF.GraphedEval(self.model, None)
+            H, W = imgs.shape[2:]
+            st["mp"], st["am"], st["hist"] = K.plabel_pass1(self._fwd(imgs).contiguous(), H, W)
+        if self.device.type == "cuda":
+            st["ev"] = torch.cuda.Event()
+            st["ev"].record()
+        return st
+
+    def post_stream(self):
+        """the stream of everything behind pass 1 (context manager target); None on a CPU device"""
+        if self.device.type != "cuda":
+            return None
+        if getattr(self, "_post", None) is None:
+            self._post = torch.cuda.Stream(device=self.device)
+        return self._post
+
+    @torch.no_grad()
+    def hist_host(self, st, allreduce=None):
+        """the (all-reduced) histogram of a begin() state on the host: uint32 view [C, NBINS]"""
+        post = self.post_stream()
+        with torch.cuda.stream(post):
+            post.wait_event(st["ev"])
+            h = st["hist"] if allreduce is None else allreduce(st["hist"])
+            return h.cpu().numpy().view(np.uint32)      # the copy runs on (and synchronises) the post stream
+
+    @torch.no_grad()
+    def finish(self, st, thr64):
+        """pass 2 of a begin() state on the post stream -> (plbl uint8 device tensor or None, count, sumprob_fx); the
+        caller reads them back inside `with torch.cuda.stream(engine.post_stream())`"""
+        from hiast_amd import kernels as K
+        post = self.post_stream()
+        with torch.cuda.stream(post):
+            post.wait_event(st["ev"])
+            if st["mp"] is None:
+                z = torch.zeros((self.C,), dtype=torch.int64, device=self.device)
+                return None, torch.zeros((0, self.C), dtype=torch.int64, device=self.device), z
+            thr_up = None if thr64 is None else K.h2d_async(ias_math.roundup_f32(thr64), self.device)
+            return K.plabel_pass2(st["mp"], st["am"], thr_up, self.C)
+
+    @torch.no_grad()
+    def pass1(self, imgs):
+        """one batch at a time (the constant-threshold policies): begin() with the state kept for pass2() / strided_hist()"""
+        st = self.begin(imgs)
+        self._mp, self._am = st["mp"], st["am"]
+        return st["hist"]
 
     @torch.no_grad()
     def strided_hist(self, interval, rank_offset=None):
@@ -121,14 +169,14 @@ class BasePseudoGenerator:
     # -- setup -------------------------------------------------------------------------------
     def initialize(self, engine=None, dataset=None):
         pp = self.cfg.pseudo_policy
-        if engine is None:
-            if not torch.cuda.is_available():
-                raise RuntimeError("pseudo-label generation runs on the HIP device; no GPU is visible "
-                                   "and there is no CPU fallback")
-            device = utils.get_device()
-            model = utils.load_model(self.cfg, resume_from=pp.resume_from).to(device).eval()
-            engine = HipPlabelEngine(model, device, self.cfg.dataset.num_classes)
-        self.engine = engine
+        if engine is None and not torch.cuda.is_available():
+            raise RuntimeError("pseudo-label generation runs on the HIP device; no GPU is visible "
+                               "and there is no CPU fallback")
+        # The DataLoader (and its worker processes) come FIRST, the model goes to the device afterwards: workers forked
+        # from a process that already holds device memory and queues stall its first device work by ~1.8 s on MI355X
+        # (measured, tools/dbg/generator_batch_times.py: every copy-on-write fault of a starting worker on memory the
+        # driver has registered evicts and restores the parent's queues) — and this way the workers decode the first
+        # batches while the checkpoint is read and copied to the device.
         if dataset is None:
             aug_type = ["PRS-{}-{}".format(pp.resize_size[0], pp.resize_size[1])]
             tgt = self.cfg.dataset.target
@@ -136,12 +184,19 @@ class BasePseudoGenerator:
                                         num_classes=self.cfg.dataset.num_classes)
         self.t_dataset = dataset
         # workers hand over uint8 images; normalisation runs on the device (same bits, 4x less host traffic)
-        dataset.device_transform = (isinstance(self.engine, HipPlabelEngine)
+        dataset.device_transform = ((engine is None or isinstance(engine, HipPlabelEngine))
                                     and os.environ.get("HIAST_HOST_TRANSFORM", "0") != "1")
         sampler = ShardedBatchSampler(len(dataset), pp.batch_size, self.rank, self.world, shuffle=True,
                                       seed=self.cfg.train.random_seed)
-        self.t_loader = DataLoader(dataset, batch_sampler=sampler, num_workers=self.cfg.dataset.num_workers,
-                                   pin_memory=torch.cuda.is_available(), collate_fn=_collate)
+        nw = self.cfg.dataset.num_workers
+        self.t_loader = DataLoader(dataset, batch_sampler=sampler, num_workers=nw, pin_memory=torch.cuda.is_available(),
+                                   collate_fn=_collate, persistent_workers=nw > 0)      # (CBST walks the set twice)
+        self._first_iter = iter(self.t_loader) if (engine is None and nw > 0) else None
+        if engine is None:
+            device = utils.get_device()
+            model = utils.load_model(self.cfg, resume_from=pp.resume_from).to(device).eval()
+            engine = HipPlabelEngine(model, device, self.cfg.dataset.num_classes)
+        self.engine = engine
         self.pseudo_label_save_dir = pp.save_dir
         assert self.pseudo_label_save_dir is not None and (
             not os.path.exists(self.pseudo_label_save_dir) or len(os.listdir(self.pseudo_label_save_dir)) == 0
@@ -192,13 +247,23 @@ class BasePseudoGenerator:
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return t
 
-    def select_and_save_confident_label(self, img_paths):
-        """pass 2 + statistics of select_and_save_confident_label (pseudo_label_generator.py:67-105)."""
-        plbl, count, sfx = self.engine.pass2(self.class_threshold)
-        count_c = self._allreduce(count.sum(0) if count.shape[0] else torch.zeros_like(sfx))
-        sfx = self._allreduce(sfx)
-        count_h = count.cpu().numpy()
-        plbl_h = plbl.cpu().numpy() if plbl is not None else None
+    def select_and_save_confident_label(self, img_paths, state=None):
+        """pass 2 + statistics of select_and_save_confident_label (pseudo_label_generator.py:67-105).
+        state: a HipPlabelEngine.begin() state (pipelined generators) instead of the engine's last pass1() batch"""
+        import contextlib
+        if state is None:
+            plbl, count, sfx = self.engine.pass2(self.class_threshold)
+            ctx = contextlib.nullcontext()
+        else:
+            plbl, count, sfx = self.engine.finish(state, self.class_threshold)
+            ctx = torch.cuda.stream(self.engine.post_stream())     # exchanges and read-backs on the stream that produced them
+        with ctx:
+            count_c = self._allreduce(count.sum(0) if count.shape[0] else torch.zeros_like(sfx))
+            sfx = self._allreduce(sfx)
+            count_h = count.cpu().numpy()
+            plbl_h = plbl.cpu().numpy() if plbl is not None else None
+            count_c = count_c.cpu().numpy()
+            sfx_h = sfx.cpu().numpy()
         C = self.cfg.dataset.num_classes
         for b, path in enumerate(img_paths):
             stats = {}
@@ -210,14 +275,13 @@ class BasePseudoGenerator:
             stats["file"] = path
             self.sample_stats.append(stats)
             self.save_pseudo_label(plbl_h[b], path)
-        count_c = count_c.cpu().numpy()
         self.statics_class += count_c
-        ias_math.update_class_mean_probs(self.class_mean_probs, count_c, sfx.cpu().numpy(),
-                                         self.cfg.preprocessor.copy_paste.gamma)
+        ias_math.update_class_mean_probs(self.class_mean_probs, count_c, sfx_h, self.cfg.preprocessor.copy_paste.gamma)
         return plbl_h
 
     def _batches(self):
-        for data in self.t_loader:
+        first, self._first_iter = self._first_iter, None        # the iterator initialize() has started, once
+        for data in (first if first is not None else self.t_loader):
             if data is None:
                 yield None, []
             else:
@@ -303,9 +367,27 @@ class IASPseudoGenerator(BasePseudoGenerator):
             return
         ias = self.cfg.pseudo_policy.ias
         self.class_threshold = 0.9 * np.ones(self.cfg.dataset.num_classes)     # :185
-        for imgs, paths in self._batches():
-            hist = self._allreduce(self.engine.pass1(imgs))
-            _, self.class_threshold = ias_math.ias_update(hist.cpu().numpy().view(np.uint32), self.class_threshold,
-                                                          ias.alpha, ias.beta, ias.gamma)
-            self.select_and_save_confident_label(paths)
+        if not hasattr(self.engine, "begin"):           # engines with the two-call interface only (test doubles)
+            for imgs, paths in self._batches():
+                hist = self._allreduce(self.engine.pass1(imgs))
+                _, self.class_threshold = ias_math.ias_update(hist.cpu().numpy().view(np.uint32), self.class_threshold,
+                                                              ias.alpha, ias.beta, ias.gamma)
+                self.select_and_save_confident_label(paths)
+            self.save_data()
+            return
+        # Software pipeline over the batches: forward + pass 1 of batch t+1 are enqueued BEFORE the host waits for the
+        # histogram of batch t.  The threshold recursion (thr_t from thr_{t-1} and hist_t, :185-205) is untouched — pass 1
+        # does not depend on the thresholds, only pass 2 does — so every artefact is what the one-batch-at-a-time loop
+        # writes; the device no longer idles while the host computes thresholds, reads the label maps back and hands them
+        # to the PNG writers, and the host no longer waits through a forward it could have enqueued earlier.
+        batches = iter(self._batches())
+        cur = next(batches, None)
+        st = self.engine.begin(cur[0]) if cur is not None else None
+        while cur is not None:
+            nxt = next(batches, None)
+            st_next = self.engine.begin(nxt[0]) if nxt is not None else None
+            hist = self.engine.hist_host(st, self._allreduce if self.world > 1 else None)
+            _, self.class_threshold = ias_math.ias_update(hist, self.class_threshold, ias.alpha, ias.beta, ias.gamma)
+            self.select_and_save_confident_label(cur[1], st)
+            cur, st = nxt, st_next
         self.save_data()

@@ -21,12 +21,11 @@ bs = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 nw = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 root = tempfile.mkdtemp(prefix="hiast_gen_")
 try:
-    cfg = synth_data.synthetic_cfg(root, n_train=N, n_val=1, h=512, w=1024)
+    cfg = synth_data.synthetic_cfg(root, n_train=N, n_val=1, h=512, w=1024, procs=max(nw, 1))
     cfg.pseudo_policy.batch_size = bs
     cfg.dataset.num_workers = nw
     gen = PSEUDO_POLICY["IAS"](cfg)
-    b0 = next(iter(gen.t_loader))
-    gen.engine.pass1(b0["images"]); gen.engine.pass2(None); torch.cuda.synchronize()
+    gen.engine.pass1(torch.zeros((bs, 512, 1024, 3), dtype=torch.uint8)); gen.engine.pass2(None); torch.cuda.synchronize()
     pr = cProfile.Profile()
     t0 = time.time()
     pr.enable()
