@@ -287,6 +287,18 @@ class BasePseudoGenerator:
             else:
                 yield data["images"], list(data["image_paths"])
 
+    def _pipelined_states(self):
+        """(image paths, HipPlabelEngine.begin() state) per batch, with forward + pass 1 of the NEXT batch already enqueued
+        when a batch is handed out: the device works on batch t+1 while the host finishes batch t"""
+        batches = iter(self._batches())
+        cur = next(batches, None)
+        st = self.engine.begin(cur[0]) if cur is not None else None
+        while cur is not None:
+            nxt = next(batches, None)
+            st_next = self.engine.begin(nxt[0]) if nxt is not None else None
+            yield cur[1], st
+            cur, st = nxt, st_next
+
     def _exists(self):
         """rank 0 looks at the directory; every rank takes ITS decision (a rank that went on alone into the
         collectives of run() would wait for the others forever)"""
@@ -320,9 +332,13 @@ class ConstantThresholdPseudoGenerator(BasePseudoGenerator):
         if self._exists():
             return
         self.class_threshold = self.get_constant_threshold()
-        for imgs, paths in self._batches():
-            self.engine.pass1(imgs)
-            self.select_and_save_confident_label(paths)
+        if hasattr(self.engine, "begin"):       # (test doubles have the two-call interface only)
+            for paths, st in self._pipelined_states():
+                self.select_and_save_confident_label(paths, st)
+        else:
+            for imgs, paths in self._batches():
+                self.engine.pass1(imgs)
+                self.select_and_save_confident_label(paths)
         self.save_data()
 
 
@@ -380,14 +396,8 @@ class IASPseudoGenerator(BasePseudoGenerator):
         # does not depend on the thresholds, only pass 2 does — so every artefact is what the one-batch-at-a-time loop
         # writes; the device no longer idles while the host computes thresholds, reads the label maps back and hands them
         # to the PNG writers, and the host no longer waits through a forward it could have enqueued earlier.
-        batches = iter(self._batches())
-        cur = next(batches, None)
-        st = self.engine.begin(cur[0]) if cur is not None else None
-        while cur is not None:
-            nxt = next(batches, None)
-            st_next = self.engine.begin(nxt[0]) if nxt is not None else None
+        for paths, st in self._pipelined_states():
             hist = self.engine.hist_host(st, self._allreduce if self.world > 1 else None)
             _, self.class_threshold = ias_math.ias_update(hist, self.class_threshold, ias.alpha, ias.beta, ias.gamma)
-            self.select_and_save_confident_label(cur[1], st)
-            cur, st = nxt, st_next
+            self.select_and_save_confident_label(paths, st)
         self.save_data()
