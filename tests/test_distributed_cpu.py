@@ -22,7 +22,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _gen_worker(rank, world, port, root, out, policy="IAS"):
+def _gen_worker(rank, world, port, root, out, policy="IAS", pipelined=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -32,7 +32,9 @@ def _gen_worker(rank, world, port, root, out, policy="IAS"):
     from hiast_amd.utils.registry import register  # noqa: F401
     from hiast_amd.utils.registry.registries import PSEUDO_POLICY
     from hiast_amd.tools import synth_data
-    from test_host_cpu import OracleEngine
+    from test_host_cpu import OracleEngine, PipelinedOracleEngine
+    if pipelined:       # the begin / hist_host / finish interface: the generators run their software-pipelined loop
+        OracleEngine = PipelinedOracleEngine
     h, w, C = 32, 64, 19
     c = synth_data.synthetic_cfg(root, n_train=7, n_val=1, h=h, w=w) if rank == 0 else None
     dist.barrier()
@@ -58,7 +60,8 @@ def _gen_worker(rank, world, port, root, out, policy="IAS"):
     dist.destroy_process_group()
 
 
-def test_sharded_generator_equals_single_process(tmp_path):
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_sharded_generator_equals_single_process(tmp_path, pipelined):
     from hiast_amd.utils.registry import register  # noqa: F401
     from hiast_amd.utils.registry.registries import PSEUDO_POLICY
     from hiast_amd.utils.default_config import CfgNode
@@ -67,7 +70,7 @@ def test_sharded_generator_equals_single_process(tmp_path):
     from PIL import Image
     root = str(tmp_path)
     out = os.path.join(root, "thr_w2.npy")
-    mp.spawn(_gen_worker, args=(2, _free_port(), root, out), nprocs=2, join=True)
+    mp.spawn(_gen_worker, args=(2, _free_port(), root, out, "IAS", pipelined), nprocs=2, join=True)
     # single process, batch 4 (= world 2 x local 2), same seeded order
     h, w, C = 32, 64, 19
     c = synth_data.synthetic_cfg(root + "/again", n_train=7, n_val=1, h=h, w=w)

@@ -236,6 +236,57 @@ class OracleEngine:
         return torch.from_numpy(plbl), torch.from_numpy(count), torch.from_numpy(sfx.view(np.int64))
 
 
+class PipelinedOracleEngine(OracleEngine):
+    """the same double with the HIP engine's begin() / hist_host() / finish() interface: the generators then run their
+    software-pipelined loop (forward + pass 1 of batch t+1 before the histogram of batch t is used)"""
+
+    def begin(self, imgs):
+        hist = self.pass1(imgs)
+        st = {"hist": hist, "mp": self.mp, "am": None if self.mp is None else self.am}
+        self.mp = self.am = "consumed"          # a state must carry everything pass 2 needs
+        return st
+
+    def post_stream(self):
+        return None
+
+    def hist_host(self, st, allreduce=None):
+        h = st["hist"] if allreduce is None else allreduce(st["hist"])
+        return h.numpy().view(np.uint32)
+
+    def finish(self, st, thr):
+        self.mp, self.am = st["mp"], st["am"]
+        try:
+            return self.pass2(thr)
+        finally:
+            self.mp = self.am = "consumed"
+
+
+@pytest.mark.parametrize("policy", ["IAS", "CT", "CBST"])
+def test_pipelined_generator_loop_writes_the_same_artefacts(tmp_path, policy):
+    """the software-pipelined batch loop (begin / hist_host / finish engines) against the one-batch-at-a-time loop"""
+    from PIL import Image
+    from hiast_amd.utils.registry import register  # noqa: F401
+    from hiast_amd.utils.registry.registries import PSEUDO_POLICY
+    from hiast_amd.tools import synth_data
+    h, w, C = 32, 64, 19
+    c = synth_data.synthetic_cfg(str(tmp_path), n_train=7, n_val=1, h=h, w=w)
+    c.pseudo_policy.batch_size = 2
+    c.pseudo_policy.cbst.sample_interval = 3
+    out = {}
+    for name, eng in (("serial", OracleEngine(C, h, w)), ("pipelined", PipelinedOracleEngine(C, h, w))):
+        c.pseudo_policy.save_dir = os.path.join(str(tmp_path), name, "pseudo_labels")
+        gen = PSEUDO_POLICY[policy](c, engine=eng)
+        gen.run()
+        d = c.pseudo_policy.save_dir
+        out[name] = ({f: np.load(os.path.join(d, "..", f)) for f in ("statics_class.npy", "class_mean_probabilities.npy")},
+                     {n: np.array(Image.open(os.path.join(d, n))) for n in sorted(os.listdir(d))},
+                     None if gen.class_threshold is None else np.asarray(gen.class_threshold).view(np.uint64).copy())
+    a, b = out["serial"], out["pipelined"]
+    assert len(a[1]) == 7 and a[1].keys() == b[1].keys()
+    assert all(np.array_equal(a[0][f], b[0][f]) for f in a[0]) and all(np.array_equal(a[1][n], b[1][n]) for n in a[1])
+    assert (a[2] is None and b[2] is None) or np.array_equal(a[2], b[2])
+
+
 def test_generator_host_logic_and_artefacts(tmp_path):
     """IAS generator end to end on CPU with the oracle engine: artefact files, formats, and equality
     with the oracle's list/quantile formulation driven in the same image order."""
