@@ -469,8 +469,9 @@ class GraphedEval:
     replayed."""
     WARMUP = 2
 
-    def __init__(self, model, amp_dtype=None, parts=1, graph=False):
-        """graph: this caller's default; HIAST_GRAPH_EVAL=1 / 0 overrides it for every caller"""
+    def __init__(self, model, amp_dtype=None, parts=None, graph=False):
+        """parts: as eval_forward_split takes them (None = its default: two sub-batches for 8 or more images, 1 = one
+        launch sequence); graph: this caller's default; HIAST_GRAPH_EVAL=1 / 0 overrides it for every caller"""
         self.model, self.amp_dtype, self.parts = model, amp_dtype, parts
         self.entries = {}
         self.enabled = os.environ.get("HIAST_GRAPH_EVAL", "1" if graph else "0") == "1"
@@ -490,9 +491,10 @@ class GraphedEval:
             ps = self.model.__dict__["_hiast_fp_params"] = [allp[0], allp[len(allp) // 2], allp[-1]]
         return tuple(p.data_ptr() for p in ps)
 
-    def __call__(self, x, parts=None, eager=False):
-        """parts: sub-batches (eval_forward_split) for this call, default the constructor's; eager: no graph this time"""
-        parts = self.parts if parts is None else parts
+    def __call__(self, x, parts="ctor", eager=False):
+        """parts: sub-batches for this call as eval_forward_split takes them (None = its default: 2 for 8 or more images),
+        "ctor" = the constructor's; eager: no graph this time"""
+        parts = self.parts if isinstance(parts, str) else parts
         if eager or not self.enabled or not x.is_cuda or self.model.training:
             return self._eager(x, parts)
         key = (tuple(x.shape), x.dtype, x.device, self.amp_dtype, parts)

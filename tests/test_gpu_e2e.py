@@ -344,39 +344,42 @@ def test_bench_steps_run_on_finite_data():
         assert bool(torch.isfinite(p).all())
 
 
-def _sharded_gen_worker(rank, world_size, port, cfg_dict, save_dir):
+def _sharded_gen_worker(rank, world_size, port, cfg_dict, save_dir, batch):
     import sys
     import torch.distributed as dist
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     sys.path.insert(0, os.path.join(root, "tests"))
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    if world_size > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    else:
+        os.environ["HIAST_EVAL_SPLIT"] = "2"        # batches of 4 forwarded as two sub-batches of 2, like the two ranks
     torch.cuda.set_device(0)
     from hiast_amd.utils.registry import register  # noqa: F401
     from hiast_amd.utils.registry.registries import PSEUDO_POLICY
     from hiast_amd.utils.default_config import CfgNode
     c = CfgNode(cfg_dict)
-    c.pseudo_policy.batch_size = 2
+    c.pseudo_policy.batch_size = batch
     c.pseudo_policy.save_dir = save_dir
     gen = PSEUDO_POLICY["IAS"](c)
     gen.run()
-    dist.barrier()
-    dist.destroy_process_group()
+    if world_size > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
-def test_sharded_generation_on_hip_equals_single_process(world, tmp_path, monkeypatch):
+def test_sharded_generation_on_hip_equals_single_process(world, tmp_path):
     """configs[1] sharded over 2 ranks (gloo, both on cuda:0) with the HIP engine — the pipelined loop with its histogram /
     class-sum exchanges on the second stream — writes what ONE process writes at batch = 2 x the local batch: thresholds
-    (float64 bit patterns), statistics, label maps.  (8 images, and the single process forwards its batches of 4 as two
-    sub-batches of 2: the library's stem convolution may pick its algorithm by batch size, everything else is per image.)"""
+    (float64 bit patterns), statistics, label maps.  (8 images; the single process forwards its batches of 4 as two
+    sub-batches of 2 and runs in a fresh process like the ranks: the library's stem convolution picks its algorithm by
+    batch size and by what the process has run before, everything else is per image.)"""
     import socket
     import torch.multiprocessing as mp
     from PIL import Image
     from hiast_amd.tools import synth_data
-    from hiast_amd.utils.registry.registries import PSEUDO_POLICY
-    from hiast_amd.utils.default_config import CfgNode
     cfg0, sd, _ = world
     root = str(tmp_path)
     cfg = synth_data.synthetic_cfg(root, n_train=8, n_val=1, h=H, w=W)
@@ -385,13 +388,9 @@ def test_sharded_generation_on_hip_equals_single_process(world, tmp_path, monkey
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     d2 = os.path.join(root, "pseudo_shard2", "pseudo_labels")
-    mp.spawn(_sharded_gen_worker, args=(2, port, cfg.to_dict(), d2), nprocs=2, join=True)
-    monkeypatch.setenv("HIAST_EVAL_SPLIT", "2")
-    c1 = CfgNode(cfg.to_dict())
-    c1.pseudo_policy.batch_size = 4
+    mp.spawn(_sharded_gen_worker, args=(2, port, cfg.to_dict(), d2, 2), nprocs=2, join=True)
     d1 = os.path.join(root, "pseudo_shard1", "pseudo_labels")
-    c1.pseudo_policy.save_dir = d1
-    PSEUDO_POLICY["IAS"](c1).run()
+    mp.spawn(_sharded_gen_worker, args=(1, port, cfg.to_dict(), d1, 4), nprocs=1, join=True)
     for f in ("class_threshold.npy", "statics_class.npy", "class_mean_probabilities.npy"):
         a, b = np.load(os.path.join(d1, "..", f)), np.load(os.path.join(d2, "..", f))
         assert np.array_equal(a.view(np.uint64) if a.dtype == np.float64 else a,
