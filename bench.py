@@ -617,9 +617,12 @@ def main():
 
     from hiast_amd import functional as HF
     for it in range(args.warmup):
-        # the first warm-up step runs in the configuration of the first timed step (everything in order on the main stream,
-        # whole-batch launches): the library's one-time algorithm search for those shapes stays out of the timed region
-        serial = it == 0
+        # the LAST warm-up step runs in the configuration of the first timed step (everything in order on the main stream,
+        # whole-batch launches): the library's one-time algorithm search for those shapes stays out of the timed region,
+        # and the caching allocator holds the whole-batch blocks that step asks for (with the serial step first and the
+        # overlapped steps — half-batch blocks — after it, a timed run was seen to pay four fresh 537 MB device allocations,
+        # 5 ms each, inside the first timed step)
+        serial = it == args.warmup - 1
         hp.use_side = not serial
         HF.enable_wgrad_overlap(not serial)
         hp.step()
