@@ -622,7 +622,7 @@ def main():
         # and the caching allocator holds the whole-batch blocks that step asks for (with the serial step first and the
         # overlapped steps — half-batch blocks — after it, a timed run was seen to pay four fresh 537 MB device allocations,
         # 5 ms each, inside the first timed step)
-        serial = it == args.warmup - 1
+        serial = it == args.warmup - 1 and args.warmup >= 2      # (a single warm-up step: the configuration of most timed steps)
         hp.use_side = not serial
         HF.enable_wgrad_overlap(not serial)
         hp.step()
