@@ -297,20 +297,30 @@ __global__ __launch_bounds__(256) void aspp2_wgrad_unpack_kernel(const float* __
     }
 }
 
-// db[co] = Σ_b Σ_p dY[b][co][p]  (one block per output channel, fixed order)
-__global__ __launch_bounds__(256) void aspp2_db_kernel(const float* __restrict__ dy, float* __restrict__ db, int B,
-                                                       int Cout, int hw)
+// db[co] = Σ_b Σ_p dY[b][co][p]  (one block of 1024 threads per output channel, fixed order, double accumulation;
+// 16-byte loads, four independent partial sums per thread: the first form — 256 threads, one float per dependent double
+// add — took 102 us for the 5 MB of an 8-image batch)
+__global__ __launch_bounds__(1024) void aspp2_db_kernel(const float* __restrict__ dy, float* __restrict__ db, int B,
+                                                        int Cout, int hw)
 {
-    __shared__ double s[256];
+    __shared__ double s[1024];
     const int co = blockIdx.x;
-    double acc = 0.0;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    const bool vec = (hw & 3) == 0 && (((uintptr_t)dy) & 15) == 0;
     for (int n = 0; n < B; ++n) {
         const float* p = dy + ((size_t)n * Cout + co) * hw;
-        for (int i = threadIdx.x; i < hw; i += 256) acc += (double)p[i];
+        if (vec) {
+            for (int i = threadIdx.x * 4; i < hw; i += 4096) {
+                const float4 v = *reinterpret_cast<const float4*>(p + i);
+                a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
+            }
+        } else {
+            for (int i = threadIdx.x; i < hw; i += 1024) a0 += (double)p[i];
+        }
     }
-    s[threadIdx.x] = acc;
+    s[threadIdx.x] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
+    for (int o = 512; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
         __syncthreads();
     }
@@ -434,7 +444,7 @@ extern "C" int hiast_aspp2_bwd(const void* x_nhwc, const float* dy, const void* 
         hipLaunchKernelGGL(hiast::aspp2_wgrad_unpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, P,
                            dw0, dw1, dw2, dw3, Cin, Cout, NP, nsplit);
         HIAST_CHECK_LAUNCH();
-        hipLaunchKernelGGL(hiast::aspp2_db_kernel, dim3(Cout), dim3(256), 0, st, dy, db, B, Cout, h * w);
+        hipLaunchKernelGGL(hiast::aspp2_db_kernel, dim3(Cout), dim3(1024), 0, st, dy, db, B, Cout, h * w);
         HIAST_CHECK_LAUNCH();
     }
     return 0;

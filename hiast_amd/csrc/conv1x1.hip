@@ -304,7 +304,54 @@ __global__ __launch_bounds__(256) void conv1x1_bn_act_kernel(
 }
 
 // NHWC BatchNorm(eval) (+ReLU) for the activations that come out of the library 3x3 / 7x7 convolutions:
-// y[m][c] = act(x[m][c]*scale_c + shift_c), 4 channels per thread (float4), C % 4 == 0.
+// y[m][c] = act(x[m][c]*scale_c + shift_c), VEC channels per thread (one 16-byte word), C % VEC == 0.
+// A thread's channels do not change along its grid-stride walk when the stride is a multiple of C (the launcher picks the
+// grid that way whenever C divides 256 * VEC * k): scale / shift are then derived ONCE per thread, and four words are
+// requested before the first is used.  (The first form derived 1/sqrt(var + eps) per element and kept one word in flight:
+// the 268 MB stem activation of the pseudo-label forward moved at 2.0 TB/s, the bf16 one of the teacher at 1.1.)
+template <int VEC>
+__device__ __forceinline__ void bna_params(const float* gamma, const float* beta, const float* mean, const float* var,
+                                           float eps, int c, float (&sc)[VEC], float (&sh)[VEC])
+{
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        const float invstd = 1.0f / sqrtf(var[c + k] + eps);
+        sc[k] = (gamma ? gamma[c + k] : 1.0f) * invstd;
+        sh[k] = fmaf(-mean[c + k], sc[k], beta ? beta[c + k] : 0.0f);
+    }
+}
+
+template <bool RELU>
+__device__ __forceinline__ float4 bna_apply4(const float4 v, const float (&sc)[4], const float (&sh)[4])
+{
+    float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float t = fmaf(o[k], sc[k], sh[k]);
+        o[k] = RELU ? (t > 0.f ? t : 0.f) : t;
+    }
+    return make_float4(o[0], o[1], o[2], o[3]);
+}
+
+template <bool RELU>
+__device__ __forceinline__ uint4 bna_apply8(const uint4 v, const float (&sc)[8], const float (&sh)[8])
+{
+    const unsigned wds[4] = {v.x, v.y, v.z, v.w};
+    unsigned pk[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float o[2] = {__uint_as_float(wds[q] << 16), __uint_as_float(wds[q] & 0xFFFF0000u)};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float t = fmaf(o[k], sc[2 * q + k], sh[2 * q + k]);
+            o[k] = RELU ? (t > 0.f ? t : 0.f) : t;
+        }
+        pk[q] = (unsigned)__bfloat16_as_ushort(__float2bfloat16(o[0])) |
+                ((unsigned)__bfloat16_as_ushort(__float2bfloat16(o[1])) << 16);
+    }
+    return make_uint4(pk[0], pk[1], pk[2], pk[3]);
+}
+
 template <bool RELU>
 __global__ __launch_bounds__(256) void bn_act_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                           const float* __restrict__ gamma,
@@ -313,19 +360,25 @@ __global__ __launch_bounds__(256) void bn_act_nhwc_kernel(const float* __restric
                                                           const float* __restrict__ var, float eps,
                                                           long long total4, int C)
 {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
-        const int c = (int)((i * 4) % C);
-        const float4 v = reinterpret_cast<const float4*>(x)[i];
-        float o[4] = {v.x, v.y, v.z, v.w};
+    const long long stride = (long long)gridDim.x * 256;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    float sc[4], sh[4];
+    if ((stride * 4) % C == 0) {            // block-uniform: this thread's channels are fixed
+        if (i < total4) bna_params<4>(gamma, beta, mean, var, eps, (int)((i * 4) % C), sc, sh);
+        for (; i + 3 * stride < total4; i += 4 * stride) {
+            float4 v[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float invstd = 1.0f / sqrtf(var[c + k] + eps);
-            const float sc = (gamma ? gamma[c + k] : 1.0f) * invstd;
-            const float sh = fmaf(-mean[c + k], sc, beta ? beta[c + k] : 0.0f);
-            float t = fmaf(o[k], sc, sh);
-            o[k] = RELU ? (t > 0.f ? t : 0.f) : t;
+            for (int u = 0; u < 4; ++u) v[u] = reinterpret_cast<const float4*>(x)[i + u * stride];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) reinterpret_cast<float4*>(y)[i + u * stride] = bna_apply4<RELU>(v[u], sc, sh);
         }
-        reinterpret_cast<float4*>(y)[i] = make_float4(o[0], o[1], o[2], o[3]);
+        for (; i < total4; i += stride)
+            reinterpret_cast<float4*>(y)[i] = bna_apply4<RELU>(reinterpret_cast<const float4*>(x)[i], sc, sh);
+        return;
+    }
+    for (; i < total4; i += stride) {
+        bna_params<4>(gamma, beta, mean, var, eps, (int)((i * 4) % C), sc, sh);
+        reinterpret_cast<float4*>(y)[i] = bna_apply4<RELU>(reinterpret_cast<const float4*>(x)[i], sc, sh);
     }
 }
 
@@ -339,27 +392,25 @@ __global__ __launch_bounds__(256) void bn_act_nhwc_bf16_kernel(const unsigned sh
                                                                const float* __restrict__ var, float eps,
                                                                long long total8, int C)
 {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long long)gridDim.x * 256) {
-        const int c = (int)((i * 8) % C);
-        const uint4 v = reinterpret_cast<const uint4*>(x)[i];
-        const unsigned wds[4] = {v.x, v.y, v.z, v.w};
-        unsigned pk[4];
+    const long long stride = (long long)gridDim.x * 256;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    float sc[8], sh[8];
+    if ((stride * 8) % C == 0) {
+        if (i < total8) bna_params<8>(gamma, beta, mean, var, eps, (int)((i * 8) % C), sc, sh);
+        for (; i + 3 * stride < total8; i += 4 * stride) {
+            uint4 v[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float o[2] = {__uint_as_float(wds[q] << 16), __uint_as_float(wds[q] & 0xFFFF0000u)};
+            for (int u = 0; u < 4; ++u) v[u] = reinterpret_cast<const uint4*>(x)[i + u * stride];
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int cc = c + 2 * q + k;
-                const float invstd = 1.0f / sqrtf(var[cc] + eps);
-                const float sc = (gamma ? gamma[cc] : 1.0f) * invstd;
-                const float sh = fmaf(-mean[cc], sc, beta ? beta[cc] : 0.0f);
-                const float t = fmaf(o[k], sc, sh);
-                o[k] = RELU ? (t > 0.f ? t : 0.f) : t;
-            }
-            pk[q] = (unsigned)__bfloat16_as_ushort(__float2bfloat16(o[0])) |
-                    ((unsigned)__bfloat16_as_ushort(__float2bfloat16(o[1])) << 16);
+            for (int u = 0; u < 4; ++u) reinterpret_cast<uint4*>(y)[i + u * stride] = bna_apply8<RELU>(v[u], sc, sh);
         }
-        reinterpret_cast<uint4*>(y)[i] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        for (; i < total8; i += stride)
+            reinterpret_cast<uint4*>(y)[i] = bna_apply8<RELU>(reinterpret_cast<const uint4*>(x)[i], sc, sh);
+        return;
+    }
+    for (; i < total8; i += stride) {
+        bna_params<8>(gamma, beta, mean, var, eps, (int)((i * 8) % C), sc, sh);
+        reinterpret_cast<uint4*>(y)[i] = bna_apply8<RELU>(reinterpret_cast<const uint4*>(x)[i], sc, sh);
     }
 }
 
@@ -446,7 +497,15 @@ extern "C" int hiast_bn_act_nhwc_infer(const void* x, void* y, const float* gamm
     if ((dtype != 0 && dtype != 1) || C % vec != 0 || ((((uintptr_t)x) | ((uintptr_t)y)) & 15)) return HIAST_E_RANGE;
     const long long totalv = (long long)M * C / vec;
     long long nb = (totalv + 256 * 4 - 1) / (256 * 4);
-    const int grid = (int)(nb < 1 ? 1 : (nb > 4096 ? 4096 : nb));
+    int grid = (int)(nb < 1 ? 1 : (nb > 8192 ? 8192 : nb));
+    // a grid-stride that is a multiple of C keeps a thread's channels fixed (parameters derived once per thread): round the
+    // grid down to a multiple of C / gcd(C, 256 * vec) when that leaves at least one block
+    {
+        long long a = 256LL * vec, g = C;
+        while (a) { const long long t = g % a; g = a; a = t; }          // g = gcd(C, 256 * vec)
+        const int need = (int)(C / g);
+        if (grid >= need) grid -= grid % need;
+    }
     hipStream_t st = (hipStream_t)stream;
     if (dtype == 0) {
         if (relu)
