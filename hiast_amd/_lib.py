@@ -70,6 +70,7 @@ SIGNATURES = {
     "hiast_bn_nhwc_bwd_apply": (c_int, [c_vp] * 8 + [ctypes.c_double, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp]),
     "hiast_pack_conv_weight_multi": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
     "hiast_split_planes": (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
+    "hiast_stem_tail": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "hiast_ema_update": (c_int, [c_vp, c_vp, c_vp, c_int, c_f32, c_f32, c_vp]),
     "hiast_normalize_u8": (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_vp, c_vp]),
     "hiast_copy_paste_u8": (c_int, [c_vp] * 6 + [c_int, c_i64, c_vp]),

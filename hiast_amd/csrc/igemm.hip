@@ -1006,6 +1006,122 @@ extern "C" int hiast_pack_conv_weight(const float* w, int N, int K, int taps, in
     return 0;
 }
 
+namespace hiast {
+
+// K9f: BN(eval) + ReLU + MaxPool2d(3, stride 2, padding 1) of the library stem's output, written in the operand format of
+// the trunk kernels — one pass instead of three (BN + ReLU, torch's pooling kernel, split / cast).  Thread = 8 channels of an
+// output pixel (its nine inputs: the 8 lanes of a pixel read one contiguous run); scale / shift are derived once per thread
+// (the channel group of a thread is fixed along its grid-stride walk: the stride is a multiple of C / 8).
+template <bool IN_BF16, int PL>
+__global__ __launch_bounds__(256) void stem_tail_kernel(const void* __restrict__ xv, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ mean,
+                                                        const float* __restrict__ var, float eps,
+                                                        unsigned short* __restrict__ out, int B, int H, int W, int C, int Ho,
+                                                        int Wo)
+{
+    const int G = C >> 3;
+    const long long total = (long long)B * Ho * Wo * G;
+    const long long stride = (long long)gridDim.x * 256;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int cg = (int)(i % G);
+    float sc[8], sh[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = cg * 8 + k;
+        const float invstd = 1.0f / sqrtf(var[c] + eps);
+        sc[k] = (gamma ? gamma[c] : 1.0f) * invstd;
+        sh[k] = fmaf(-mean[c], sc[k], beta ? beta[c] : 0.0f);
+    }
+    for (; i < total; i += stride) {
+        const long long pix = i / G;
+        const int xo = (int)(pix % Wo);
+        const int yo = (int)((pix / Wo) % Ho);
+        const int b = (int)(pix / ((long long)Wo * Ho));
+        float m[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m[k] = -INFINITY;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int yy = 2 * yo - 1 + dy;
+            if (yy < 0 || yy >= H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int xx = 2 * xo - 1 + dx;
+                if (xx < 0 || xx >= W) continue;
+                const size_t off = (((size_t)b * H + yy) * W + xx) * C + cg * 8;
+                float v[8];
+                if (IN_BF16) {
+                    const uint4 r = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(xv) + off);
+                    const unsigned w4[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        v[2 * q] = __uint_as_float(w4[q] << 16);
+                        v[2 * q + 1] = __uint_as_float(w4[q] & 0xFFFF0000u);
+                    }
+                } else {
+                    const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(xv) + off);
+                    const float4 c4 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(xv) + off + 4);
+                    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c4.x; v[5] = c4.y; v[6] = c4.z; v[7] = c4.w;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    float t = fmaf(v[k], sc[k], sh[k]);
+                    t = t > 0.f ? t : 0.f;
+                    if (IN_BF16) t = __bfloat162float(__float2bfloat16(t));     // the bf16 activation the pooling kernel saw
+                    m[k] = t > m[k] ? t : m[k];
+                }
+            }
+        }
+        unsigned ph[4], pl_[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned short h0, l0, h1, l1;
+            ig_split(m[2 * q], h0, l0);
+            ig_split(m[2 * q + 1], h1, l1);
+            ph[q] = (unsigned)h0 | ((unsigned)h1 << 16);
+            pl_[q] = (unsigned)l0 | ((unsigned)l1 << 16);
+        }
+        unsigned short* dst = out + ig_elem<PL>((size_t)pix, cg * 8, C);
+        *reinterpret_cast<uint4*>(dst) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+        if (PL == 2) *reinterpret_cast<uint4*>(dst + 32) = make_uint4(pl_[0], pl_[1], pl_[2], pl_[3]);
+    }
+}
+
+}  // namespace hiast
+
+extern "C" int hiast_stem_tail(const void* x, int dtype, const float* gamma, const float* beta, const float* mean,
+                               const float* var, float eps, void* out, int planes, int B, int H, int W, int C,
+                               hiast_stream_t stream)
+{
+    if (!x || !mean || !var || !out) return HIAST_E_ARG;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return HIAST_E_ARG;
+    if ((dtype != 0 && dtype != 1) || (planes != 1 && planes != 2) || C % 8 != 0 || (planes == 2 && C % 32 != 0) ||
+        ((((uintptr_t)x) | ((uintptr_t)out)) & 15))
+        return HIAST_E_RANGE;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1, G = C / 8;
+    const long long total = (long long)B * Ho * Wo * G;
+    if ((long long)B * H * W * C >= (1ll << 40)) return HIAST_E_RANGE;
+    long long nb = (total + 255) / 256;
+    int grid = (int)(nb > 16384 ? 16384 : nb);
+    {   // grid-stride = multiple of G, so that a thread keeps its channel group
+        long long a = 256, g = G;
+        while (a) { const long long t = g % a; g = a; a = t; }
+        const int need = (int)(G / g);
+        if (grid >= need) grid -= grid % need;
+        else return HIAST_E_RANGE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+#define L(BF, PL)                                                                                                  \
+    hipLaunchKernelGGL((hiast::stem_tail_kernel<BF, PL>), dim3(grid), dim3(256), 0, st, x, gamma, beta, mean, var, eps, \
+                       (unsigned short*)out, B, H, W, C, Ho, Wo)
+    if (dtype == 1) { if (planes == 2) L(true, 2); else L(true, 1); }
+    else { if (planes == 2) L(false, 2); else L(false, 1); }
+#undef L
+    HIAST_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int hiast_split_planes(float* x, void* planes, int64_t M, int C, int inverse, hiast_stream_t stream)
 {
     if (!x || !planes) return HIAST_E_ARG;

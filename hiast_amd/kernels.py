@@ -698,6 +698,20 @@ def bn_act_nhwc_infer(x2d, bn, relu=True):
     return y
 
 
+def stem_tail(x, bn, planes):
+    """K9f: bn (eval) -> ReLU -> MaxPool2d(3, 2, 1) of the stem convolution's output in one pass.
+    x: logical [B,C,H,W] with channels-last memory, fp32 or bf16 -> bf16 [B,Ho,Wo,planes*C] (planes = 2: split planes)"""
+    dt = _act_dtype(x)
+    B, C, H, W = x.shape
+    assert x.permute(0, 2, 3, 1).is_contiguous(), "stem_tail: x must be channels-last"
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = torch.empty((B, Ho, Wo, int(planes) * C), dtype=torch.bfloat16, device=x.device)
+    g, b, mu, var, eps = _bn_params(bn)
+    check(_lib.load().hiast_stem_tail(_ptr(x), dt, g, b, mu, var, eps, _ptr(out), int(planes), B, H, W, C, _stream()),
+          "hiast_stem_tail")
+    return out
+
+
 # ------------------------------------------------------------------------------- K9c LDS-DMA implicit GEMM on split planes
 # A "split-plane" activation is an opaque bf16 tensor [B,H,W,2*C] holding hi = bf16(v) and lo = bf16(v - hi) of an
 # fp32-class value (layout inside the last axis: include/hiast_hip.h, K9c); plain bf16 activations are [B,H,W,C].

@@ -189,6 +189,16 @@ class ResNet(nn.Module):
         x = x.contiguous(memory_format=torch.channels_last)
         o = self.conv1(x)                 # library 7x7 stem (bf16 output under autocast)
         o = o.contiguous(memory_format=torch.channels_last)
+        mp = self.maxpool
+        if ((mp.kernel_size, mp.stride, mp.padding, mp.dilation, mp.ceil_mode) == (3, 2, 1, 1, False)
+                and o.shape[1] % 32 == 0 and o.dtype in (torch.float32, torch.bfloat16)
+                and os.environ.get("HIAST_NO_STEM_TAIL", "0") != "1"):
+            # bn1 -> ReLU -> maxpool -> operand format of the trunk kernels in one pass over the stem's output (K9f)
+            o = K.stem_tail(o, self.bn1, PL)
+            for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
+                for blk in stage:
+                    o = blk.forward_eval_planes(o, PL)
+            return o
         B, _, H, W = o.shape
         o = _from2d(K.bn_act_nhwc_infer(_nhwc2d(o), self.bn1, True), B, H, W)
         o = self.maxpool(o)

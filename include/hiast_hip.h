@@ -279,6 +279,13 @@ int hiast_igemm_dgrad_bn_stats_rows(int64_t M);
 int hiast_pack_conv_weight(const float* w, int N, int K, int taps, int planes, int transpose, void* wp, void* wpt,
                            hiast_stream_t stream);
 int hiast_split_planes(float* x, void* planes, int64_t M, int C, int inverse, hiast_stream_t stream);
+/* K9f hiast_stem_tail: bn1 (eval) -> ReLU -> MaxPool2d(3, stride 2, padding 1) of the stem convolution's output
+ * (ResNet.forward, sseg/models/modules/resnet.py:180-184: x = conv1(x); bn1; relu; maxpool) in ONE pass, written in the
+ * operand format of the trunk kernels.  x: channels-last [B,H,W,C] fp32 (dtype 0) or bf16 (dtype 1; the ReLU output is
+ * rounded to bf16 before the maximum, as a bf16 module path does); out: planes = 2: split planes [B,Ho,Wo,2*C] (C % 32 == 0),
+ * planes = 1: bf16 [B,Ho,Wo,C]; Ho = (H-1)/2+1, Wo = (W-1)/2+1; C % 8 == 0; gamma / beta may be NULL (1 / 0). */
+int hiast_stem_tail(const void* x, int dtype, const float* gamma, const float* beta, const float* mean, const float* var,
+                    float eps, void* out, int planes, int B, int H, int W, int C, hiast_stream_t stream);
 /* hiast_pack_conv_weight for a list of weights in ONE launch (a trunk's 104 convolutions after every optimiser / EMA
  * update).  table: device array of records (mode = the `transpose` argument above; N, K multiples of 64, taps <= 9);
  * one block per 64 x 64 (n, k) tile of one weight: chunk_tensor[b] = record index, chunk_start[b] = index of the tile

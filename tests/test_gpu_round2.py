@@ -254,3 +254,44 @@ def test_graphed_inference_forward_replays_the_eager_launches(amp, monkeypatch):
     for x in xs[:4]:
         g(x)
     assert not g.entries
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 37, 53), (1, 64, 64, 128), (3, 32, 8, 9)])
+def test_stem_tail_equals_the_three_passes(shape):
+    """K9f hiast_stem_tail (bn1 eval + ReLU + 3x3/2 max pooling + operand format in one pass) against the passes it replaces
+    — hiast_bn_act_nhwc_infer, torch's MaxPool2d(3, 2, 1), hiast_split_planes / the bf16 cast — bit for bit, odd sizes
+    included; and the whole inference forward with and without it"""
+    from hiast_amd import kernels as K
+    B, C, H, W = shape
+    dev = torch.device("cuda")
+    bn = torch.nn.BatchNorm2d(C).to(dev).eval()
+    with torch.no_grad():
+        bn.weight.copy_(torch.from_numpy(synth.normal_f32(961, (C,), 0.5)) + 1.0)
+        bn.bias.copy_(torch.from_numpy(synth.normal_f32(962, (C,), 0.3)))
+        bn.running_mean.copy_(torch.from_numpy(synth.normal_f32(963, (C,), 0.4)))
+        bn.running_var.copy_(torch.from_numpy(synth.normal_f32(964, (C,), 0.2)).abs() + 0.5)
+    x = torch.from_numpy(synth.normal_f32(960, shape, 1.5)).to(dev).contiguous(memory_format=torch.channels_last)
+    pool = torch.nn.MaxPool2d(3, 2, 1)
+    for xin, PL in ((x, 2), (x.bfloat16(), 1), (x, 1)):
+        x2d = xin.permute(0, 2, 3, 1).reshape(B * H * W, C)
+        a = K.bn_act_nhwc_infer(x2d, bn, True).view(B, H, W, C).permute(0, 3, 1, 2)
+        p = pool(a).contiguous(memory_format=torch.channels_last)
+        Ho, Wo = p.shape[2:]
+        p2d = p.permute(0, 2, 3, 1).reshape(B * Ho * Wo, C)
+        ref = K.split_planes(p2d.float()) if PL == 2 else p2d.to(torch.bfloat16)
+        got = K.stem_tail(xin, bn, PL)
+        assert got.shape == (B, Ho, Wo, PL * C)
+        assert torch.equal(got.view(B * Ho * Wo, PL * C).view(torch.int16), ref.view(torch.int16)), (shape, PL, xin.dtype)
+
+
+def test_inference_forward_with_and_without_the_fused_stem_tail(monkeypatch):
+    cfg, net = _model(783)
+    net.eval()
+    x = torch.from_numpy(synth.normal_f32(965, (2, 3, 65, 97))).cuda()
+    for amp in (False, True):
+        outs = []
+        for off in ("0", "1"):
+            monkeypatch.setenv("HIAST_NO_STEM_TAIL", off)
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+                outs.append(net(x, lowres=True)["logits_lowres"].float().clone())
+        assert torch.equal(outs[0], outs[1]), amp
