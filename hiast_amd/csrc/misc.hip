@@ -1,4 +1,6 @@
 // Version / error strings, K11 (EMA teacher update) and K12 (IoU area histograms).
+#include <hip/hip_bf16.h>
+
 #include "common.h"
 
 namespace hiast {
@@ -258,6 +260,143 @@ extern "C" int hiast_multi_copy(const hiast_copy_rec* table, int n_tensors, hias
     if (!table) return HIAST_E_ARG;
     if (n_tensors <= 0) return HIAST_E_ARG;
     hipLaunchKernelGGL(hiast::multi_copy_kernel, dim3(n_tensors), dim3(256), 0, (hipStream_t)stream, table);
+    HIAST_CHECK_LAUNCH();
+    return 0;
+}
+
+namespace hiast {
+
+// K18: MaxPool2d(3, stride 2, padding 1) on channels-last bf16 activations (the stem of the mixed-precision training
+// forward), forward with a one-byte window position per element instead of the library's 8-byte flat index, and its
+// backward as a gather over the <= 4 windows that cover an input pixel.  Ties go to the first element in row-major
+// window order and a NaN takes the maximum, as in ATen's kernel; the backward adds in fp32 and rounds once.
+__global__ __launch_bounds__(256) void maxpool_cl_fwd_kernel(const unsigned short* __restrict__ x,
+                                                             unsigned short* __restrict__ y, unsigned char* __restrict__ idx,
+                                                             int B, int H, int W, int C, int Ho, int Wo)
+{
+    const int G = C >> 3;
+    const long long total = (long long)B * Ho * Wo * G;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int cg = (int)(i % G);
+        const long long pix = i / G;
+        const int xo = (int)(pix % Wo), yo = (int)((pix / Wo) % Ho), b = (int)(pix / ((long long)Wo * Ho));
+        float m[8];
+        unsigned code[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { m[k] = -INFINITY; code[k] = 255u; }
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int yy = 2 * yo - 1 + dy;
+            if (yy < 0 || yy >= H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int xx = 2 * xo - 1 + dx;
+                if (xx < 0 || xx >= W) continue;
+                const uint4 r = *reinterpret_cast<const uint4*>(x + (((size_t)b * H + yy) * W + xx) * C + cg * 8);
+                const unsigned w4[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float v0 = __uint_as_float(w4[q] << 16), v1 = __uint_as_float(w4[q] & 0xFFFF0000u);
+                    // ATen: maxidx starts at the first element of the window, then (val > maxval || isnan(val)) takes over
+                    if (code[2 * q] == 255u) code[2 * q] = dy * 3 + dx;
+                    if (v0 > m[2 * q] || v0 != v0) { m[2 * q] = v0; code[2 * q] = dy * 3 + dx; }
+                    if (code[2 * q + 1] == 255u) code[2 * q + 1] = dy * 3 + dx;
+                    if (v1 > m[2 * q + 1] || v1 != v1) { m[2 * q + 1] = v1; code[2 * q + 1] = dy * 3 + dx; }
+                }
+            }
+        }
+        unsigned pk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            pk[q] = (__float_as_uint(m[2 * q]) >> 16) | (__float_as_uint(m[2 * q + 1]) & 0xFFFF0000u);     // exact: inputs are bf16
+        *reinterpret_cast<uint4*>(y + (size_t)pix * C + cg * 8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        *reinterpret_cast<uint2*>(idx + (size_t)pix * C + cg * 8) =
+            make_uint2(code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24),
+                       code[4] | (code[5] << 8) | (code[6] << 16) | (code[7] << 24));
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_cl_bwd_kernel(const unsigned short* __restrict__ dy,
+                                                             const unsigned char* __restrict__ idx,
+                                                             unsigned short* __restrict__ dx, int B, int H, int W, int C,
+                                                             int Ho, int Wo)
+{
+    const int G = C >> 3;
+    const long long total = (long long)B * H * W * G;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int cg = (int)(i % G);
+        const long long pix = i / G;
+        const int xi = (int)(pix % W), yi = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+        // windows (yo, xo) with 2*yo - 1 <= yi <= 2*yo + 1: yo = yi / 2 and, for odd yi, also (yi + 1) / 2 (ascending order)
+        const int y0 = yi >> 1, ny = (yi & 1) ? 2 : 1, x0 = xi >> 1, nx = (xi & 1) ? 2 : 1;
+        for (int a = 0; a < ny; ++a) {
+            const int yo = y0 + a;
+            if (yo >= Ho) continue;
+            const unsigned pdy = (unsigned)(yi - (2 * yo - 1));
+            for (int c = 0; c < nx; ++c) {
+                const int xo = x0 + c;
+                if (xo >= Wo) continue;
+                const unsigned pos = pdy * 3u + (unsigned)(xi - (2 * xo - 1));
+                const size_t o = (((size_t)b * Ho + yo) * Wo + xo) * C + cg * 8;
+                const uint2 cd = *reinterpret_cast<const uint2*>(idx + o);
+                const uint4 g = *reinterpret_cast<const uint4*>(dy + o);
+                const unsigned gw[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const unsigned code = ((k < 4 ? cd.x : cd.y) >> (8 * (k & 3))) & 255u;
+                    const float gv = (k & 1) ? __uint_as_float(gw[k >> 1] & 0xFFFF0000u) : __uint_as_float(gw[k >> 1] << 16);
+                    if (code == pos) acc[k] += gv;
+                }
+            }
+        }
+        unsigned pk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            pk[q] = (unsigned)__bfloat16_as_ushort(__float2bfloat16(acc[2 * q])) |
+                    ((unsigned)__bfloat16_as_ushort(__float2bfloat16(acc[2 * q + 1])) << 16);
+        *reinterpret_cast<uint4*>(dx + (size_t)pix * C + cg * 8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    }
+}
+
+}  // namespace hiast
+
+static int maxpool_cl_check(const void* a, const void* b, const void* c, int B, int H, int W, int C)
+{
+    if (!a || !b || !c) return HIAST_E_ARG;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return HIAST_E_ARG;
+    if (C % 8 != 0 || ((((uintptr_t)a) | ((uintptr_t)b)) & 15) || (((uintptr_t)c) & 7) ||
+        (long long)B * H * W * C >= (1ll << 40))
+        return HIAST_E_RANGE;
+    return 0;
+}
+
+extern "C" int hiast_maxpool3x3s2_nhwc_fwd(const void* x, void* y, uint8_t* idx, int B, int H, int W, int C,
+                                           hiast_stream_t stream)
+{
+    int e = maxpool_cl_check(x, y, idx, B, H, W, C);
+    if (e) return e;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    long long nb = ((long long)B * Ho * Wo * (C / 8) + 255) / 256;
+    nb = nb > 16384 ? 16384 : nb;
+    hipLaunchKernelGGL(hiast::maxpool_cl_fwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)x, (unsigned short*)y, idx, B, H, W, C, Ho, Wo);
+    HIAST_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int hiast_maxpool3x3s2_nhwc_bwd(const void* dy, const uint8_t* idx, void* dx, int B, int H, int W, int C,
+                                           hiast_stream_t stream)
+{
+    int e = maxpool_cl_check(dy, dx, idx, B, H, W, C);
+    if (e) return e;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    long long nb = ((long long)B * H * W * (C / 8) + 255) / 256;
+    nb = nb > 32768 ? 32768 : nb;
+    hipLaunchKernelGGL(hiast::maxpool_cl_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)dy, idx, (unsigned short*)dx, B, H, W, C, Ho, Wo);
     HIAST_CHECK_LAUNCH();
     return 0;
 }

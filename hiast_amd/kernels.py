@@ -698,6 +698,31 @@ def bn_act_nhwc_infer(x2d, bn, relu=True):
     return y
 
 
+def maxpool3x3s2_cl_fwd(x):
+    """K18: x logical [B,C,H,W] bf16 with channels-last memory -> (y like x at [B,C,Ho,Wo], idx uint8 [B,Ho,Wo,C])"""
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.permute(0, 2, 3, 1).is_contiguous()):
+        raise ValueError("maxpool3x3s2_cl: x must be a channels-last bfloat16 HIP tensor [B,C,H,W]")
+    B, C, H, W = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty((B, C, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    idx = torch.empty((B, Ho, Wo, C), dtype=torch.uint8, device=x.device)
+    check(_lib.load().hiast_maxpool3x3s2_nhwc_fwd(_ptr(x), _ptr(y), _ptr(idx), B, H, W, C, _stream()),
+          "hiast_maxpool3x3s2_nhwc_fwd")
+    return y, idx
+
+
+def maxpool3x3s2_cl_bwd(dy, idx, H, W):
+    """dy logical [B,C,Ho,Wo] bf16 channels-last, idx from the forward -> dx [B,C,H,W] bf16 channels-last"""
+    if not (dy.is_cuda and dy.dtype == torch.bfloat16 and dy.dim() == 4 and dy.permute(0, 2, 3, 1).is_contiguous()):
+        raise ValueError("maxpool3x3s2_cl: dy must be a channels-last bfloat16 HIP tensor [B,C,Ho,Wo]")
+    B, C, Ho, Wo = dy.shape
+    assert tuple(idx.shape) == (B, Ho, Wo, C) and idx.dtype == torch.uint8
+    dx = torch.empty((B, C, H, W), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
+    check(_lib.load().hiast_maxpool3x3s2_nhwc_bwd(_ptr(dy), _ptr(idx), _ptr(dx), B, H, W, C, _stream()),
+          "hiast_maxpool3x3s2_nhwc_bwd")
+    return dx
+
+
 def stem_tail(x, bn, planes):
     """K9f: bn (eval) -> ReLU -> MaxPool2d(3, 2, 1) of the stem convolution's output in one pass.
     x: logical [B,C,H,W] with channels-last memory, fp32 or bf16 -> bf16 [B,Ho,Wo,planes*C] (planes = 2: split planes)"""

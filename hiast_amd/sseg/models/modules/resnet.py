@@ -251,7 +251,7 @@ class ResNet(nn.Module):
         prev = HF._nbt_batched[0]
         HF._nbt_batched[0] = batched or prev
         try:
-            x = self.maxpool(bn_act(self.bn1, x))
+            x = HF.maxpool(bn_act(self.bn1, x), self.maxpool)
             low = self.layer1(x)
             x = self.layer4(self.layer3(self.layer2(low)))
         finally:

@@ -345,6 +345,16 @@ int hiast_ema_update(const hiast_ema_rec* table, const int32_t* chunk_tensor,
                      const int64_t* chunk_start, int n_chunks, float gamma,
                      float one_minus_gamma, hiast_stream_t stream);
 
+/* ---- K18: MaxPool2d(3, stride 2, padding 1) on channels-last bf16 activations ------------------------------------
+ * ResNet.forward, sseg/models/modules/resnet.py:184 (x = self.maxpool(x)) in the mixed-precision training forward, and
+ * its autograd.  x, y, dy, dx: bf16 [B,H,W,C] / [B,Ho,Wo,C] (Ho = (H-1)/2+1, Wo = (W-1)/2+1), C % 8 == 0;
+ * idx: one byte per output element, the position 3*dy + dx of the maximum inside its window (ATen keeps an int64 flat
+ * index: 8x the bytes); first maximum in row-major window order, a NaN takes over, as ATen.  The backward gathers, for
+ * every input pixel, the gradients of the <= 4 windows whose maximum it is (fp32 sum, one rounding). */
+int hiast_maxpool3x3s2_nhwc_fwd(const void* x, void* y, uint8_t* idx, int B, int H, int W, int C, hiast_stream_t stream);
+int hiast_maxpool3x3s2_nhwc_bwd(const void* dy, const uint8_t* idx, void* dx, int B, int H, int W, int C,
+                                hiast_stream_t stream);
+
 /* ---- K14: ToTensor + Normalize on the device ------------------------------------------------------
  * transform (sseg/datasets/utils.py:37-55: torchvision ToTensor + Normalize in the DataLoader workers): img uint8
  * [B][H*W][3] (HWC as decoded) -> out float32 [B][3][H*W]; v = float(u8)/255, out = (v - mean[c])/std[c], torch's

@@ -295,3 +295,37 @@ def test_inference_forward_with_and_without_the_fused_stem_tail(monkeypatch):
             with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
                 outs.append(net(x, lowres=True)["logits_lowres"].float().clone())
         assert torch.equal(outs[0], outs[1]), amp
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 37, 53), (1, 64, 64, 128), (2, 16, 5, 4)])
+def test_stem_max_pooling_kernels_equal_the_library(shape):
+    """K18 (hiast_maxpool3x3s2_nhwc_fwd / _bwd through HF.maxpool): values and input gradient of nn.MaxPool2d(3, 2, 1) on
+    channels-last bf16, bit for bit — with ties (coarsely quantised values: the first maximum of a window takes the
+    gradient), odd sizes, and a few -inf / NaN entries"""
+    from hiast_amd import functional as HF
+    B, C, H, W = shape
+    dev = torch.device("cuda")
+    pool = torch.nn.MaxPool2d(3, 2, 1)
+    for case in ("smooth", "ties", "special"):
+        v = torch.from_numpy(synth.normal_f32(970, shape, 1.0)).to(dev)
+        if case == "ties":
+            v = torch.round(v * 2) / 2
+        if case == "special":
+            v.view(-1)[::97] = float("-inf")
+            v.view(-1)[5::389] = float("nan")
+        x = v.bfloat16().contiguous(memory_format=torch.channels_last)
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        ya = HF.maxpool(xa, pool)
+        yb = pool(xb)
+        assert ya.dtype == torch.bfloat16 and ya.shape == yb.shape and ya.permute(0, 2, 3, 1).is_contiguous()
+        assert torch.equal(ya.detach().view(torch.int16), yb.detach().contiguous(memory_format=torch.channels_last).view(torch.int16)), case
+        g = torch.from_numpy(synth.normal_f32(971, tuple(yb.shape), 1.0)).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+        ya.backward(g)
+        yb.backward(g)
+        ga, gb = xa.grad, xb.grad.contiguous(memory_format=torch.channels_last)
+        if case == "special":       # where the window holds a NaN the library's pick is what we copy; compare the finite rest
+            ok = ~(torch.isnan(ga.float()) | torch.isnan(gb.float()))
+            assert torch.equal(torch.isnan(ga.float()), torch.isnan(gb.float()))
+            assert torch.equal(ga.float()[ok], gb.float()[ok]), case
+        else:
+            assert torch.equal(ga.view(torch.int16), gb.view(torch.int16)), case
