@@ -279,8 +279,9 @@ class HotPath:
         model.train(was)
 
     def _allreduce(self, t):
-        if self.world > 1:
-            dist.all_reduce(t)
+        if self.world > 1:      # histogram / class sums of the pseudo-label pass: auxiliary communicator (utils/comm.py)
+            from hiast_amd.utils import comm
+            dist.all_reduce(t, group=comm.aux_group())
         return t
 
     # One step = the pseudo-label pass and the training step on the same batch.  Both are split at the point where the
@@ -572,7 +573,8 @@ def spawn_ranks(n):
         port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    from hiast_amd.utils import comm
+    env.setdefault("OMP_NUM_THREADS", str(max(1, comm.usable_cpus() // n)))     # the cgroup's CPU share, not the 256 visible
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
@@ -595,10 +597,11 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
-        if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=device)
-        else:
-            dist.init_process_group(backend=args.backend)
+        # (no device_id: communicators are then created lazily by ncclCommInitRank at the first collective of each group —
+        # the oldest and most exercised path of torch's RCCL backend — instead of eagerly + ncclCommSplit for new groups)
+        dist.init_process_group(backend=args.backend)
+        from hiast_amd.utils import comm
+        comm.setup()        # SyncBN sums and the histogram exchange get communicators of their own, beside DDP's
     torch.backends.cudnn.benchmark = bool(int(os.environ.get("HIAST_MIOPEN_FIND", "0")))
 
     cfg = make_cfg(world, args.trainer)
@@ -612,7 +615,7 @@ def main():
 
     def sync():
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[local]) if args.backend == "nccl" else dist.barrier()
         torch.cuda.synchronize()
 
     from hiast_amd import functional as HF
@@ -651,7 +654,7 @@ def main():
                                                 # sequence per forward), so the per-launch durations are not stretched by
                                                 # co-running work
         e = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
-        hp.step(e)
+        last_losses, _ = hp.step(e)
         marks.append(e)
         if not timer.on:
             host_parts.append([1e3 * (hp.host_marks[i + 1] - hp.host_marks[i]) for i in range(4)])
@@ -672,6 +675,21 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    # after the timed region: the last step's losses (mean over ranks) and, at N > 1, whether the replicas still agree —
+    # IAS thresholds as float64 bit patterns and a checksum over every parameter must be identical on all ranks (a rank
+    # that missed an all-reduce, or reduced on the wrong communicator, drifts within one step)
+    names = list(last_losses.keys())
+    lv = torch.stack([torch.mean(last_losses[k]).double() for k in names])
+    ranks_agree = None
+    if world > 1:
+        dist.all_reduce(lv)
+        lv /= world
+        chk = torch.cat([torch.from_numpy(hp.thr.view(np.int64).copy()).to(device),
+                         torch.stack([p.detach().double().sum() for p in hp.model.parameters()]).view(torch.int64)])
+        both = torch.stack([chk, -chk])
+        dist.all_reduce(both, op=dist.ReduceOp.MAX)         # max(x) == -max(-x) on every element <=> all ranks equal
+        ranks_agree = bool(torch.equal(both[0], -both[1]))
+    final_losses = dict(zip(names, [float(v) for v in lv.cpu()]))
 
     if rank == 0:
         imgs = world * args.batch * args.steps
@@ -693,6 +711,7 @@ def main():
                                   "events); the other steps overlap the parts on four streams"},
             # host time spent ENQUEUING each part (steps without per-launch events; the third entry includes the wait
             # for the histogram): the sum must stay below ms_per_step or the step is launch-bound
+            "final_losses": final_losses, "ranks_agree": ranks_agree,
             "host_enqueue_ms": dict(zip(["plabel_fwd_pass1", "train_forwards", "hist_wait_thresholds_pass2",
                                          "loss_bwd_adam_ema"] if hp.pipelined else
                                         ["plabel_fwd_pass1", "hist_wait_thresholds_pass2", "-", "train_step"],
@@ -717,7 +736,7 @@ def main():
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out))
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[local]) if args.backend == "nccl" else dist.barrier()
         dist.destroy_process_group()
 
 

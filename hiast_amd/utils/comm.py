@@ -1,0 +1,82 @@
+"""Communicators of the N>1 path (one process per GPU, torch.distributed; backend 'nccl' = RCCL over xGMI).
+
+The reference has ONE exchange path (apex DDP + apex SyncBN on the default group, code/train.py:52-59,82,
+workflows/trainer/base_trainer.py:43-56, utils/utils.py:103-105).  Here three kinds of traffic share a step:
+
+  * DDP's gradient buckets (175 MB per step in 32 MB all-reduces, overlapped with backward)   -> default group
+  * the SyncBN sums: 208 all-reduces of [C,2] doubles per step, each between two kernels of the
+    main stream, i.e. latency-critical                                                          -> stat_group()
+  * the pseudo-label exchange (19 x 15361 u32 histogram, [C] class sums), validation I/U areas  -> aux_group()
+
+A communicator executes its operations in issue order: on the default group a [C,2] reduce issued during backward
+queues behind whatever 32 MB bucket DDP's reducer has issued before it, and the histogram all-reduce (which waits for
+the whole pseudo-label forward) holds back every SyncBN reduce issued after it.  Separate process groups have separate
+RCCL communicators and streams, so the three kinds only meet on the links.
+
+Every rank must create the groups at the same point of its program: `setup()` is called right after
+init_process_group by the trainers / generator / bench.py; the getters create lazily otherwise (first use is at the
+same program point on every rank as well).  HIAST_COMM_GROUPS=0 routes everything through the default group.
+"""
+import os
+
+import torch.distributed as dist
+
+_groups = {}
+
+
+def _enabled():
+    return (os.environ.get("HIAST_COMM_GROUPS", "1") != "0" and dist.is_available() and dist.is_initialized()
+            and dist.get_world_size() > 1)
+
+
+def _get(name):
+    if not _enabled():
+        return None                          # dist.all_reduce(..., group=None) = the default group
+    ent = _groups.get(name)
+    if ent is None or ent[0] is not dist.distributed_c10d._get_default_group():
+        # (a re-initialised default group — tests start several process groups in one interpreter — invalidates ours)
+        ent = _groups[name] = (dist.distributed_c10d._get_default_group(), dist.new_group())
+    return ent[1]
+
+
+def setup():
+    """create both groups now (collective: every rank, same order).  No-op for a single process."""
+    stat_group()
+    aux_group()
+
+
+def stat_group():
+    """group of the SyncBN statistics all-reduces (hiast_amd/functional.py)"""
+    return _get("stat")
+
+
+def aux_group():
+    """group of the pseudo-label histogram / class-sum exchange and of the validation areas"""
+    return _get("aux")
+
+
+def reset():
+    """forget the groups (after destroy_process_group)"""
+    _groups.clear()
+
+
+def usable_cpus():
+    """CPUs this process may actually use: affinity mask capped by the cgroup quota (an MI355X box shows 256 logical
+    CPUs and grants 16; thread pools sized by os.cpu_count() run 10x slower there than pools sized by the quota)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], txt[1]
+            else:
+                quota, period = txt[0], open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()
+            if quota not in ("max", "-1") and int(period) > 0:
+                n = max(1, min(n, int(int(quota) / int(period))))
+                break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n

@@ -23,7 +23,7 @@ import torch.distributed as dist
 from PIL import Image
 from torch.utils.data import DataLoader, Sampler
 
-from hiast_amd.utils import utils
+from hiast_amd.utils import comm, utils
 from hiast_amd.utils.registry.registries import DATASET, PSEUDO_POLICY
 from hiast_amd.workflows import ias_math
 
@@ -164,6 +164,7 @@ class BasePseudoGenerator:
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self._io = ThreadPoolExecutor(max_workers=max(2, cfg.dataset.num_workers))
         self._pending = []
+        comm.setup()
         self.initialize(engine, dataset)
 
     # -- setup -------------------------------------------------------------------------------
@@ -243,8 +244,8 @@ class BasePseudoGenerator:
 
     # -- one batch ---------------------------------------------------------------------------
     def _allreduce(self, t):
-        if self.world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        if self.world > 1:      # histogram / class sums: on the auxiliary communicator (utils/comm.py)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=comm.aux_group())
         return t
 
     def select_and_save_confident_label(self, img_paths, state=None):
@@ -368,7 +369,7 @@ class CBSTPseudoGenerator(ConstantThresholdPseudoGenerator):
             if self.world > 1:          # class-c pixels of this global batch held by the lower ranks
                 mine = full.long().sum(1)
                 parts = [torch.zeros_like(mine) for _ in range(self.world)]
-                dist.all_gather(parts, mine)
+                dist.all_gather(parts, mine, group=comm.aux_group())
                 offset = torch.stack(parts[:self.rank]).sum(0) if self.rank else torch.zeros_like(mine)
             total += (full if interval == 1 and offset is None else self.engine.strided_hist(interval, offset)).long()
         total = self._allreduce(total)

@@ -14,7 +14,7 @@ from torch.nn.parallel import DistributedDataParallel as DDP
 from torch.utils.data import DataLoader, DistributedSampler
 
 from hiast_amd.sseg.datasets import utils as du
-from hiast_amd.utils import metrics, utils
+from hiast_amd.utils import comm, metrics, utils
 from hiast_amd.utils.registry.registries import DATASET
 from hiast_amd.utils.result_recorder import ResultRecorder
 
@@ -126,6 +126,8 @@ class BaseTrainer:
                 dist.init_process_group(backend="nccl" if use_cuda else "gloo",
                                         init_method="tcp://127.0.0.1:{}".format(self.cfg.train.port),
                                         world_size=self.world, rank=self.gpu_index)
+        if self.world > 1:
+            comm.setup()        # communicators of the SyncBN sums and of the small exchanges, beside DDP's (utils/comm.py)
         if use_cuda:
             # HIAST_SAME_DEVICE=1 (functional tests of the N>1 path on a one-GPU box): every rank uses cuda:0
             self.device_index = 0 if os.environ.get("HIAST_SAME_DEVICE", "0") == "1" else self.gpu_index
@@ -301,7 +303,7 @@ class BaseTrainer:
             acc[1] += union
         model.train(was_training)    # the reference calls model.train() at the top of every iteration
         if self.world > 1:
-            dist.all_reduce(acc)       # one 38-element all-reduce instead of two
+            dist.all_reduce(acc, group=comm.aux_group())       # one 38-element all-reduce instead of two
         acc = acc.cpu().numpy().astype(np.float64)
         iou = acc[0] / (acc[1] + 1e-10)
         return iou, float(np.mean(iou))

@@ -15,8 +15,13 @@ LAYERS = (3, 4, 23, 3)
 PLANES = (64, 128, 256, 512)
 
 
-def _bn(x, sd, pre, train, eps=1e-5):
+def _bn(x, sd, pre, train, eps=1e-5, stats_out=None):
     if train:   # frozen-affine BN still normalises with batch statistics in model.train()
+        if stats_out is not None:      # ... and moves its running statistics (momentum 0.1, unbiased variance)
+            rm, rv = sd[pre + ".running_mean"].detach().clone(), sd[pre + ".running_var"].detach().clone()
+            y = F.batch_norm(x, rm, rv, sd[pre + ".weight"], sd[pre + ".bias"], True, 0.1, eps)
+            stats_out[pre + ".running_mean"], stats_out[pre + ".running_var"] = rm, rv
+            return y
         return F.batch_norm(x, None, None, sd[pre + ".weight"], sd[pre + ".bias"], True, 0.1, eps)
     return F.batch_norm(x, sd[pre + ".running_mean"], sd[pre + ".running_var"], sd[pre + ".weight"],
                         sd[pre + ".bias"], False, 0.1, eps)
@@ -33,7 +38,12 @@ def conv_geometry(layer, block):
     return 1, (full // 2 if block == 0 else full)
 
 
-def backbone(x, sd, pre="backbone.", train=False):
+def backbone(x, sd, pre="backbone.", train=False, stats_out=None):
+    """stats_out: dict that receives the running statistics every BatchNorm holds AFTER this train-mode forward"""
+    g_bn = globals()["_bn"]
+
+    def _bn(x, sd, name, train):
+        return g_bn(x, sd, name, train, stats_out=stats_out)
     x = F.conv2d(x, sd[pre + "conv1.weight"], None, 2, 3)
     x = F.relu(_bn(x, sd, pre + "bn1", train))
     x = F.max_pool2d(x, 3, 2, 1)
@@ -61,10 +71,10 @@ def aspp(feat, sd, pre="aspp.conv2d_list.", dil=(6, 12, 18, 24)):
     return out
 
 
-def deeplab_v2(x, sd, train=False):
+def deeplab_v2(x, sd, train=False, stats_out=None):
     """-> (prediction [B,C,H/8,W/8], feature [B,2048,H/8,W/8]); `representation` is computed and
     dropped by the reference (deeplab_v2.py:63), so it is skipped here."""
-    feat = backbone(x, sd, train=train)
+    feat = backbone(x, sd, train=train, stats_out=stats_out)
     return aspp(feat, sd), feat
 
 

@@ -203,3 +203,60 @@ def test_manual_gradient_allreduce_averages_over_ranks(tmp_path):
     for i, g in enumerate(grads[:-1]):
         want = torch.full_like(g, 1.5 * (i + 1)) + torch.arange(g.numel()).view(g.shape)
         assert torch.equal(g, want)
+
+
+def _comm_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hiast_amd import functional as HF
+    from hiast_amd.utils import comm
+    comm.setup()
+    sg, ag = comm.stat_group(), comm.aux_group()
+    default = dist.distributed_c10d._get_default_group()
+    ok = sg is not None and ag is not None and sg is not ag and sg is not default and ag is not default
+    ok = ok and comm.stat_group() is sg and comm.aux_group() is ag           # created once
+    # the three communicators carry independent sequences: each rank issues them in a different interleaving per group
+    # kind, as DDP buckets / SyncBN sums / the histogram do in a step, and every sum must still be the global one
+    g = torch.full((1 << 16,), float(rank + 1), dtype=torch.float32)        # a "gradient bucket" on the default group
+    s = torch.tensor([[1.0 + rank, 2.0 * rank]] * 7, dtype=torch.float64)   # SyncBN [C,2] double sums
+    h = torch.arange(19 * 11, dtype=torch.int32).view(19, 11) * (rank + 1)  # histogram
+    w_g = dist.all_reduce(g, async_op=True)
+    HF._stat_all_reduce(s)
+    w_h = dist.all_reduce(h, group=ag, async_op=True)
+    s2 = s.clone()
+    HF._stat_all_reduce(s2)
+    w_g.wait()
+    w_h.wait()
+    tri = world * (world + 1) // 2
+    ok = ok and bool((g == tri).all())
+    ok = ok and bool(torch.equal(s[:, 0], torch.full((7,), float(tri), dtype=torch.float64)))
+    ok = ok and bool(torch.equal(s2, s * world))
+    ok = ok and bool(torch.equal(h, torch.arange(19 * 11, dtype=torch.int32).view(19, 11) * tri))
+    # HIAST_COMM_GROUPS=0: everything on the default group (group=None)
+    os.environ["HIAST_COMM_GROUPS"] = "0"
+    ok = ok and comm.stat_group() is None and comm.aux_group() is None
+    t = torch.ones(3, dtype=torch.float64)
+    HF._stat_all_reduce(t)
+    ok = ok and bool((t == world).all())
+    os.environ["HIAST_COMM_GROUPS"] = "1"
+    if rank == 0:
+        np.save(out, np.array([ok]))
+    dist.barrier()
+    dist.destroy_process_group()
+    comm.reset()
+
+
+def test_stat_and_aux_groups_are_separate_communicators(tmp_path):
+    """utils/comm.py: the SyncBN sums and the pseudo-label exchange run on process groups of their own (not DDP's
+    default communicator); same sums whatever the interleaving; HIAST_COMM_GROUPS=0 falls back to the default group"""
+    out = str(tmp_path / "ok.npy")
+    mp.spawn(_comm_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert bool(np.load(out)[0])
+
+
+def test_usable_cpus_respects_affinity():
+    from hiast_amd.utils import comm
+    n = comm.usable_cpus()
+    assert 1 <= n <= len(os.sched_getaffinity(0))

@@ -95,14 +95,18 @@ def _step(tr, weak, strong, plbl):
     return out
 
 
-def _worker(rank, world, port, root, apex_opt, out):
+def _worker(rank, world, port, root, apex_opt, out, backend="gloo"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    os.environ["HIAST_SAME_DEVICE"] = "1"
+    # gloo: both ranks on cuda:0 (a one-GPU box); nccl (= RCCL): one rank per device, as in production
+    os.environ["HIAST_SAME_DEVICE"] = "1" if backend == "gloo" else "0"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import warnings
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        torch.cuda.set_device(rank)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     with warnings.catch_warnings(record=True) as wlist:
         warnings.simplefilter("always")
         tr = _make_trainer(root, world, rank, apex_opt)
@@ -138,10 +142,19 @@ def _cos(a, b):
     return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300))
 
 
+def _backend_or_skip(backend):
+    """'nccl' needs one device per rank: collected everywhere, run wherever >= 2 MI355X are visible (device_count() does
+    not initialise the GPU in this image, so the spawned ranks are still the first to touch it)"""
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("RCCL needs one device per rank; %d visible" % torch.cuda.device_count())
+
+
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
 @pytest.mark.parametrize("apex_opt", ["O0", "O1"])
-def test_two_rank_step_equals_single_process(root, apex_opt):
-    out = os.path.join(root, "r%d_" + apex_opt + ".npz")
-    mp.spawn(_worker, args=(2, _port(), root, apex_opt, out), nprocs=2, join=True)
+def test_two_rank_step_equals_single_process(root, apex_opt, backend):
+    _backend_or_skip(backend)
+    out = os.path.join(root, "r%d_" + apex_opt + "_" + backend + ".npz")
+    mp.spawn(_worker, args=(2, _port(), root, apex_opt, out, backend), nprocs=2, join=True)
     parts = [dict(np.load(out % k)) for k in range(2)]
     tr = _make_trainer(root, 1, 0, apex_opt)
     one = _step(tr, *_inputs())

@@ -344,7 +344,7 @@ def test_bench_steps_run_on_finite_data():
         assert bool(torch.isfinite(p).all())
 
 
-def _sharded_gen_worker(rank, world_size, port, cfg_dict, save_dir, batch):
+def _sharded_gen_worker(rank, world_size, port, cfg_dict, save_dir, batch, backend="gloo"):
     import sys
     import torch.distributed as dist
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -353,10 +353,14 @@ def _sharded_gen_worker(rank, world_size, port, cfg_dict, save_dir, batch):
     if world_size > 1:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
-        dist.init_process_group("gloo", rank=rank, world_size=world_size)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend == "nccl":                        # RCCL: one rank per device
+            torch.cuda.set_device(rank)
+        dist.init_process_group(backend, rank=rank, world_size=world_size)
     else:
         os.environ["HIAST_EVAL_SPLIT"] = "2"        # batches of 4 forwarded as two sub-batches of 2, like the two ranks
-    torch.cuda.set_device(0)
+    if not (world_size > 1 and backend == "nccl"):
+        torch.cuda.set_device(0)
     from hiast_amd.utils.registry import register  # noqa: F401
     from hiast_amd.utils.registry.registries import PSEUDO_POLICY
     from hiast_amd.utils.default_config import CfgNode
@@ -370,7 +374,8 @@ def _sharded_gen_worker(rank, world_size, port, cfg_dict, save_dir, batch):
         dist.destroy_process_group()
 
 
-def test_sharded_generation_on_hip_equals_single_process(world, tmp_path):
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_sharded_generation_on_hip_equals_single_process(world, tmp_path, backend):
     """configs[1] sharded over 2 ranks (gloo, both on cuda:0) with the HIP engine — the pipelined loop with its histogram /
     class-sum exchanges on the second stream — writes what ONE process writes at batch = 2 x the local batch: thresholds
     (float64 bit patterns), statistics, label maps.  (8 images; the single process forwards its batches of 4 as two
@@ -380,6 +385,8 @@ def test_sharded_generation_on_hip_equals_single_process(world, tmp_path):
     import torch.multiprocessing as mp
     from PIL import Image
     from hiast_amd.tools import synth_data
+    if backend == "nccl" and torch.cuda.device_count() < 2:      # collected everywhere, runs once >= 2 devices are visible
+        pytest.skip("RCCL needs one device per rank; %d visible" % torch.cuda.device_count())
     cfg0, sd, _ = world
     root = str(tmp_path)
     cfg = synth_data.synthetic_cfg(root, n_train=8, n_val=1, h=H, w=W)
@@ -388,7 +395,7 @@ def test_sharded_generation_on_hip_equals_single_process(world, tmp_path):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     d2 = os.path.join(root, "pseudo_shard2", "pseudo_labels")
-    mp.spawn(_sharded_gen_worker, args=(2, port, cfg.to_dict(), d2, 2), nprocs=2, join=True)
+    mp.spawn(_sharded_gen_worker, args=(2, port, cfg.to_dict(), d2, 2, backend), nprocs=2, join=True)
     d1 = os.path.join(root, "pseudo_shard1", "pseudo_labels")
     mp.spawn(_sharded_gen_worker, args=(1, port, cfg.to_dict(), d1, 4), nprocs=1, join=True)
     for f in ("class_threshold.npy", "statics_class.npy", "class_mean_probabilities.npy"):

@@ -1,0 +1,58 @@
+"""The N>1 launch path exactly as the driver issues it: `python bench.py --gpus N ...` with no launcher -> spawn_ranks ->
+ONE torch.distributed.run child -> N ranks -> DDP (bucket views) + SyncBN sums on their own communicator + histogram /
+class-sum exchange of the pseudo-label pass -> ONE JSON line from rank 0 (reference: code/train.py:52-59,82,
+workflows/trainer/base_trainer.py:43-56, utils/utils.py:103-105).
+
+On a one-GPU box both ranks share cuda:0 over gloo (--same-device --backend gloo); with >= 2 devices visible the same
+command runs over RCCL, one rank per device (collected everywhere, skipped on one device)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_bench(extra, timeout=900):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline"] + extra
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert p.returncode == 0, "bench.py rc %d\n--- stdout\n%s\n--- stderr (tail)\n%s" % (p.returncode, p.stdout[-2000:],
+                                                                                            p.stderr[-6000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, "bench.py must print ONE line on stdout, got %d:\n%s" % (len(lines), p.stdout[-2000:])
+    return json.loads(lines[0]), p.stderr
+
+
+def _check(out, batch):
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2"
+    assert out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["images_per_gpu_per_step"] == batch
+    assert out["value"] > 0 and abs(out["value"] - 2 * batch * 2 / (out["ms_per_step"] * 2e-3)) <= 1e-6 * out["value"]
+    fin = out["final_losses"]
+    assert set(fin) == {"target_seg_loss", "kld_confident_loss", "ent_ignored_loss", "cst_loss"}
+    assert all(v == v and abs(v) < 1e4 for v in fin.values()), fin         # finite on every rank (all-reduced mean)
+    assert out["ranks_agree"] is True           # thresholds (float64 bits) and a parameter checksum equal on both ranks
+    assert "cpu_baseline" not in out
+
+
+def test_bench_two_ranks_through_spawn_ranks_gloo_same_device():
+    out, err = _run_bench(["--same-device", "--backend", "gloo", "--batch", "2"])
+    _check(out, 2)
+    assert "grad strides do not match bucket view" not in err
+
+
+def test_bench_two_ranks_through_spawn_ranks_rccl():
+    if torch.cuda.device_count() < 2:
+        pytest.skip("RCCL needs one device per rank; %d visible" % torch.cuda.device_count())
+    out, err = _run_bench(["--batch", "2"])
+    _check(out, 2)
+    assert "grad strides do not match bucket view" not in err
