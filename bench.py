@@ -584,6 +584,12 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
+    # stdout carries exactly ONE line (rank 0's JSON).  Native libraries write there too ([Gloo] connection notes, RCCL's
+    # NCCL_DEBUG / "NCCL WARN" lines, MIOpen): file descriptor 1 is pointed at stderr for the life of the process and the
+    # JSON line goes to a duplicate of the original descriptor.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -734,7 +740,8 @@ def main():
                     out["cpu_baseline"] = cpu_baseline(cfg, tuple(args.cpu_size), args.cpu_threads, reps=args.cpu_reps)
             except Exception as e:      # the baseline must never take the measurement down
                 out["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(out))
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     if world > 1:
         dist.barrier(device_ids=[local]) if args.backend == "nccl" else dist.barrier()
         dist.destroy_process_group()

@@ -968,6 +968,9 @@ extern "C" int hiast_igemm_debug_stamps(unsigned* dst_device)
 }
 #endif
 
+// rows of the partial-sum buffer of a want_stats launch.  Such a launch is always the PLAIN convolution: igemm_launch_mode
+// rejects stats together with a BatchNorm, a residual or a ReLU (HIAST_E_RANGE), so the kernel choice below (xconv for the
+// expanding 1x1 shapes, the tile kernel otherwise) is the one the launch makes.
 extern "C" int hiast_igemm_stats_rows(int64_t M, int Cin, int Cout, int taps, int planes)
 {
     if (M <= 0 || Cin <= 0 || Cout <= 0) return 0;

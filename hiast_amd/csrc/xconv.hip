@@ -325,7 +325,7 @@ int hiast_xconv_ok(int64_t M, int K, int N, int planes, int taps, int out_f32, i
     if (K != 256 || N % hiast::XC_COLS != 0 || N > 2048) return 0;
     if (has_gate && (!gate_mask || !has_res || relu)) return 0;
     if (has_bn && has_res && !relu) return 0;        // (no caller in the trunk; that variant would need scratch)
-    if (has_stats && (has_res || relu)) return 0;
+    if (has_stats && (has_res || relu || has_bn)) return 0;      // the statistics variant is the plain GEMM only
     if (M < 4096) return 0;                          // small maps: the tile kernel's grid fills the chip better
     return 1;
 }

@@ -146,6 +146,15 @@ def plabel_strided_hist(maxprob, argmax, C, interval, hist=None, rank_offset=Non
     return (hist, tot) if want_totals else hist
 
 
+TTA_FUSED_CLASSES = (19, 16, 9, 2)       # class counts hiast_tta_fused is instantiated for (plabel2.hip)
+TTA_FUSED_MAX_SCALES = 8                 # HIAST_TTA_MAX_SCALES of include/hiast_hip.h
+
+
+def tta_fused_supported(C, n_scales):
+    """whether hiast_tta_fused covers this class count / number of scales (it returns HIAST_E_RANGE otherwise)"""
+    return int(C) in TTA_FUSED_CLASSES and 1 <= int(n_scales) <= TTA_FUSED_MAX_SCALES
+
+
 def tta_fused(zs, zfs, sizes, H, W, want_probs=False, want_label=True):
     """Validator.get_multi_scale_and_flip_logits (+ argmax) from the low-res head outputs of every (scale, flip)
     forward: zs / zfs lists of fp32 [B,C,hs,ws] (zfs None = no flip), sizes list of (Hs, Ws) the image was resized to

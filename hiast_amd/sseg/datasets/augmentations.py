@@ -182,7 +182,11 @@ class RandomContrast(_Aug):
         self.p = p
 
     def params(self, image):
-        return {"alpha": 1.0 + random.uniform(self.limit[0], self.limit[1])}
+        # albumentations 1.0.3: a RandomBrightnessContrast subclass with brightness_limit = (0, 0) — get_params draws
+        # alpha, then beta; the degenerate uniform(0, 0) still consumes one random.random()
+        alpha = 1.0 + random.uniform(self.limit[0], self.limit[1])
+        random.uniform(0.0, 0.0)
+        return {"alpha": alpha}
 
     def apply(self, image, masks, alpha):
         return _lut(image, _brightness_contrast_lut(alpha, 0.0)), masks
@@ -196,6 +200,8 @@ class RandomBrightness(_Aug):
         self.p = p
 
     def params(self, image):
+        # RandomBrightnessContrast with contrast_limit = (0, 0): the (degenerate) alpha draw comes first, then beta
+        random.uniform(0.0, 0.0)
         return {"beta": 0.0 + random.uniform(self.limit[0], self.limit[1])}
 
     def apply(self, image, masks, beta):
@@ -424,9 +430,12 @@ class FDA(_Aug):
         self.read_fn = read_fn or (lambda path: np.asarray(Image.open(path).convert("RGB"), dtype=np.uint8))
 
     def params(self, image):
+        # draw order of albumentations 1.0.3: get_params() (beta) runs before get_params_dependent_on_targets() (the
+        # reference image)
+        beta = random.uniform(self.beta[0], self.beta[1])
         target = self.read_fn(random.choice(self.refs))
         target = _resize_img(target, image.shape[0], image.shape[1])
-        return {"target": target, "beta": random.uniform(self.beta[0], self.beta[1])}
+        return {"target": target, "beta": beta}
 
     def apply(self, image, masks, target, beta):
         return fourier_domain_adaptation(image, target, beta), masks

@@ -110,8 +110,10 @@ def cbst_threshold(hist, p, arithmetic=None):
         like the IAS quantile above;
       * arithmetic="float16": numpy >= 2.0 keeps the SAMPLE's dtype — q, the virtual index (n-1)q and the lerp are
         all rounded to float16 (the index of a sample of more than 2048 values is no longer exact, and beyond
-        65504/q it overflows to inf -> the class maximum is returned).  This is what the reference computes under
-        the numpy of this image, reproduced operation by operation; tests/golden/policies.npz holds such values.
+        65504/q it overflows to inf: both neighbours become the class maximum and the lerp weight inf, so the result
+        is 0 * inf = NaN — numpy 2.2 returns exactly that, checked on 200k samples; a warning names such classes).
+        This is what the reference computes under the numpy of this image, reproduced operation by operation;
+        tests/golden/policies.npz holds such values.  Only usable for small pools: real target sets need "float64".
     HIAST_CBST_QUANTILE=float16|float64 selects it when `arithmetic` is None."""
     import os
     if arithmetic is None:
@@ -155,6 +157,11 @@ def cbst_threshold(hist, p, arithmetic=None):
             if gamma >= 0.5:
                 r = np.subtract(b, diff * (1 - gamma)).astype(np.float16)
         out[c] = float(r)
+        if np.isnan(out[c]):
+            import warnings
+            warnings.warn("cbst_threshold(arithmetic='float16'): class %d has %d pooled confidences, its float16 virtual "
+                          "index overflows and numpy >= 2.0 yields NaN (no pixel of the class will be kept); use "
+                          "arithmetic='float64' (numpy 1.19.2, the reference's pin)" % (c, n))
     return out
 
 

@@ -55,6 +55,8 @@ class HipPlabelEngine:
     """Device side of one generator step (the HIP kernels); no CPU path."""
 
     def __init__(self, model, device, num_classes):
+        if torch.device(device).type != "cuda":
+            raise RuntimeError("HipPlabelEngine runs on the HIP device only (no CPU path); got %r" % (device,))
         self.model, self.device, self.C = model, device, num_classes
 
     @torch.no_grad()
@@ -82,15 +84,12 @@ class HipPlabelEngine:
                 self._fwd = HF.GraphedEval(self.model, None)
             H, W = imgs.shape[2:]
             st["mp"], st["am"], st["hist"] = K.plabel_pass1(self._fwd(imgs).contiguous(), H, W)
-        if self.device.type == "cuda":
-            st["ev"] = torch.cuda.Event()
-            st["ev"].record()
+        st["ev"] = torch.cuda.Event()
+        st["ev"].record()
         return st
 
     def post_stream(self):
-        """the stream of everything behind pass 1 (context manager target); None on a CPU device"""
-        if self.device.type != "cuda":
-            return None
+        """the stream of everything behind pass 1 (context manager target)"""
         if getattr(self, "_post", None) is None:
             self._post = torch.cuda.Stream(device=self.device)
         return self._post

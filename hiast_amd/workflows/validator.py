@@ -67,10 +67,16 @@ class Validator:
         H, W = imgs.shape[2:]
         return K.tta_fused(zs, zfs if self.cfg.validate.is_flip else None, sizes, H, W, want_probs, want_label)
 
+    def _fused_tta_ok(self):
+        """hiast_tta_fused is instantiated for C in {19, 16, 9, 2} and up to 8 scales; any other class count / scale list
+        takes the general composition below (own resampling kernel + torch softmax), as the reference handles any"""
+        from hiast_amd import kernels as K
+        return K.tta_fused_supported(self.cfg.dataset.num_classes, len(self.cfg.validate.resize_sizes))
+
     def get_multi_scale_and_flip_logits(self, imgs, is_softmax=True):
         """validator.py:34-55: Σ over scales of softmax(model(resized)) (+ flipped), each resampled
         back to the native size"""
-        if imgs.is_cuda and is_softmax:
+        if imgs.is_cuda and is_softmax and self._fused_tta_ok():
             return self._tta_device(imgs, True, False)[0]
 
         def pred(x):
@@ -113,7 +119,7 @@ class Validator:
         for data in tqdm.tqdm(self.v_loader, desc="Validation", ncols=100):
             imgs = data["images"].to(self.device)
             lbls = data["labels"].to(self.device)
-            if imgs.is_cuda:     # fused tail: label map straight from the low-res head outputs
+            if imgs.is_cuda and self._fused_tta_ok():     # fused tail: label map straight from the low-res head outputs
                 pred = self._tta_device(imgs, False, True)[1].long()
             else:
                 pred = self.get_multi_scale_and_flip_logits(imgs).argmax(dim=1)

@@ -157,3 +157,50 @@ def test_serial_multi_view_and_index_seeding():
     b = A.aug(views, img, lbl, index=7)
     assert np.array_equal(a[0][1], b[0][1]) and a[0][0].shape == (20, 32, 3)
     assert np.array_equal(a[1][0], a[1][1])           # colour transforms leave the label alone
+
+
+def test_random_draws_per_transform_follow_albumentations_1_0_3():
+    """number and ORDER of the random.random() calls behind each transform's parameters (albumentations 1.0.3):
+    RandomContrast / RandomBrightness are RandomBrightnessContrast subclasses whose get_params draws alpha THEN beta, the
+    degenerate uniform(0, 0) included (2 draws each); FDA draws beta (get_params) BEFORE the reference image
+    (get_params_dependent_on_targets).  A transform that drew one value less would shift the stream every later
+    transform of a 'CCA' SomeOf sees."""
+    img = _img(21)
+
+    class Counting(random.Random):
+        def __init__(self, seed):
+            super().__init__(seed)
+            self.n = 0
+
+        def random(self):
+            self.n += 1
+            return super().random()
+
+    def draws(fn, seed=31):
+        """-> (result of fn, number of random.random() calls, the values drawn) with the module RNG replaced"""
+        rng = Counting(seed)
+        saved = {k: getattr(random, k) for k in ("random", "uniform", "randint", "choice")}
+        random.random, random.uniform, random.randint, random.choice = rng.random, rng.uniform, rng.randint, rng.choice
+        try:
+            out = fn()
+        finally:
+            for k, v in saved.items():
+                setattr(random, k, v)
+        ref = random.Random(seed)
+        return out, rng.n, [ref.random() for _ in range(rng.n)]
+
+    p, n, u = draws(lambda: A.RandomContrast(limit=(0, 3)).params(img))
+    assert n == 2 and p == {"alpha": 1.0 + (0 + 3 * u[0])}
+    p, n, u = draws(lambda: A.RandomBrightness(limit=0.5).params(img))
+    assert n == 2 and p == {"beta": 0.0 + (-0.5 + 1.0 * u[1])}          # the SECOND draw: alpha's dummy draw comes first
+    refs = ["a", "b", "c", "d", "e"]
+    seen = []
+
+    def read(path):
+        seen.append(path)
+        return _img(22)
+    p, n, u = draws(lambda: A.FDA(refs, beta_limit=0.1, read_fn=read).params(img))
+    assert abs(p["beta"] - 0.1 * u[0]) < 1e-15                           # beta first ...
+    again = Counting(31)             # (a Random subclass that overrides random() draws choice() through random() too)
+    again.random()
+    assert seen == [again.choice(refs)]                                  # ... then the reference image

@@ -10,11 +10,19 @@ weights and inputs: the four loss values, EVERY gradient tensor (104 trunk convo
 head; BatchNorm affine is frozen, utils/utils.py:60-65) and the BatchNorm running statistics the train-mode forward
 leaves behind.
 
-Modes: O0 = fp32 (library convolutions + own fp32 BN / ASPP / loss kernels): tight bounds.
-       O1/bf16, O1/fp16 = the mixed-precision step on the hand-written channels-last kernels: the head and the loss
-       must still agree closely; deep in the trunk a 16-bit forward on random-init weights with batch-statistics BN
-       cannot reproduce fp32 gradients element by element (two fp32 implementations already differ there), so the
-       per-tensor cosines are RECORDED (gpurun_out/r03_trainstep_oracle_<mode>.txt -> profiles/) and bounded loosely.
+The truth is the oracle in FLOAT64; the oracle in float32 is the yardstick.  Why a yardstick: a gradient through ReLUs
+answers a forward perturbation of relative size e with an error of ~sqrt(e) — a fraction ~e of the pre-activations
+changes sign, and each flipped mask bit changes its element of the backward signal by 100 % (L2: sqrt of the flipped
+fraction), layer after layer.  Measured on this state (CPU, float32 vs float64, tools-free: this file's _oracle_step):
+the logits agree to 5e-4 of their maximum, the trunk gradients to cos 0.99996 (1 % in L2) — and the same float32 oracle
+run with 1 instead of 8 threads already sits at cos 0.9995-0.99999 of itself on the plain seeded state.  So:
+  O0 (fp32: library convolutions + own fp32 BN / ASPP / loss kernels): every gradient tensor must be as close to the
+      float64 truth as the float32 oracle is (1 - cos within 4x), head and losses tight, running statistics 1e-3.
+  O1/bf16, O1/fp16 (the mixed-precision step on the hand-written channels-last kernels): e is 4e-3 / 5e-4 per stored
+      activation, so over 33 blocks the masks decorrelate and no 16-bit arithmetic reproduces float64's trunk gradients
+      tensor by tensor (neither does the reference's apex O1).  Losses and head are bounded on the full trunk and the
+      per-tensor cosines are RECORDED (gpurun_out/r03_trainstep_oracle_<depth>_<mode>.txt -> profiles/); the same step
+      on a two-blocks-per-stage trunk ('r26': every block kind, 28 convolutions) is bounded tensor by tensor.
 """
 import os
 
@@ -28,11 +36,31 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 H, W, C, B = 128, 256, 19, 2
 WEIGHTS = dict(w_t=1.0, w_k=0.1, w_e=1.0, w_c=0.5)
+# depth variants: the real trunk, and the same architecture with two blocks per stage (every kind of block is there:
+# stage entries with their downsample branch, the strided 3x3, identity blocks, dilations 1 / 2 / 4) — shallow enough that a
+# 16-bit forward stays close to the fp32 one, so the 16-bit GRADIENTS can be bounded tensor by tensor (see the docstring)
+DEPTHS = {"r101": (3, 4, 23, 3), "r26": (2, 2, 2, 2)}
+BN3_GAMMA = {"r101": 0.25, "r26": 1.0}
 
 
-def _state(seed=9500):
-    """seeded weights whose BatchNorm running statistics are those of the data (the teacher normalises with them) and
-    whose head is scaled to logits of a few units, so that all four loss terms and their gradients are healthy"""
+def _patch_depth(monkeypatch, depth):
+    """SEG_MODEL['DeepLab_V2'] and the oracle both build the trunk with DEPTHS[depth] blocks per stage"""
+    from hiast_amd.sseg.models.modules import resnet
+    from hiast_amd.sseg.models.modules.seg_models import deeplab_v2
+    from oracle import deeplab_ref
+    layers = DEPTHS[depth]
+    monkeypatch.setattr(deeplab_v2, "build_resnet101", lambda pretrained=False, output_stride=8: resnet.ResNet(
+        layers=layers, strides=(1, 2, 1, 1), dilations=((1, 1), (1, 1), (1, 2), (2, 4))))
+    monkeypatch.setattr(deeplab_ref, "LAYERS", layers)
+
+
+def _state(depth, seed=9500):
+    """seeded weights in the state of a TRAINED checkpoint as far as conditioning goes: BatchNorm running statistics are
+    those of the data (the teacher normalises with them), the head is scaled to logits of a few units (all four loss
+    terms and their gradients are healthy), and for the full-depth trunk the last BatchNorm of every block has
+    gamma x 0.25 (residual branches are corrections to the identity path, as after training / zero-init-residual; with
+    gamma = 1 on all 33 blocks a random-init ResNet-101 in batch-statistics mode amplifies a 1e-7 rounding of its input to
+    5e-4 at the logits — chaos of the test state, not of the code under test)"""
     from hiast_amd.utils.registry import register  # noqa: F401
     from hiast_amd.utils.registry.registries import MODEL
     from hiast_amd.utils.default_config import get_default_cfg
@@ -40,13 +68,15 @@ def _state(seed=9500):
     from oracle import deeplab_ref
     m = MODEL["SelfTrainingSegmentor"](get_default_cfg())
     sd = seeded_state_dict(m.seg_model, seed)
+    for k in sd:
+        if k.endswith("bn3.weight"):
+            sd[k] = sd[k] * BN3_GAMMA[depth]
     x = torch.from_numpy(synth.normal_f32(seed + 1, (B, 3, H, W)))
     with torch.no_grad():
-        for _ in range(1):          # running statistics := batch statistics of the synthetic data (CPU oracle)
-            so = {}
-            deeplab_ref.deeplab_v2(x, sd, train=True, stats_out=so)
-            for k, v in so.items():
-                sd[k] = sd[k] + (v - sd[k]) / 0.1
+        so = {}          # running statistics := batch statistics of the synthetic data (CPU oracle)
+        deeplab_ref.deeplab_v2(x, sd, train=True, stats_out=so)
+        for k, v in so.items():
+            sd[k] = sd[k] + (v - sd[k]) / 0.1
         s = 4.0 / float(deeplab_ref.deeplab_v2(x, sd)[0].std())
     for i in range(4):
         sd["aspp.conv2d_list.%d.weight" % i] = sd["aspp.conv2d_list.%d.weight" % i] * s
@@ -61,27 +91,38 @@ def _inputs():
     return weak, strong, plbl
 
 
-@pytest.fixture(scope="module")
-def oracle_step(tmp_path_factory):
-    """one CPU-autograd step of the oracle -> losses, gradients, post-forward running statistics; + the checkpoint file"""
+def _oracle_step(sd, dtype):
+    """one CPU-autograd step of the oracle in `dtype` -> (losses, gradients as float64 arrays, running statistics)"""
     from oracle import deeplab_ref, losses_ref
-    root = str(tmp_path_factory.mktemp("trainstep"))
-    sd = _state()
-    torch.save(sd, os.path.join(root, "init.pth"))
     weak, strong, plbl = _inputs()
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
-    sub = {k[len("seg_model."):]: v for k, v in sd.items()}
+    sub = {k[len("seg_model."):]: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
     with torch.no_grad():
-        zt = deeplab_ref.deeplab_v2(torch.from_numpy(weak), sub, train=False)[0]       # EMA teacher == student at step 1
+        zt = deeplab_ref.deeplab_v2(torch.from_numpy(weak).to(dtype), sub, train=False)[0]   # EMA teacher == student at step 1
     params = {k: v.detach().clone().requires_grad_(v.dim() == 4 or "aspp" in k) for k, v in sub.items()}
     so = {}
-    zs = deeplab_ref.deeplab_v2(torch.from_numpy(strong), params, train=True, stats_out=so)[0]
-    L = losses_ref.st_losses(zs, zt, torch.from_numpy(plbl.astype(np.int64)), (H, W), "ignored", dtype=torch.float32,
-                             **WEIGHTS)
+    zs = deeplab_ref.deeplab_v2(torch.from_numpy(strong).to(dtype), params, train=True, stats_out=so)[0]
+    L = losses_ref.st_losses(zs, zt.float() if dtype == torch.float32 else zt, torch.from_numpy(plbl.astype(np.int64)),
+                             (H, W), "ignored", dtype=dtype, **WEIGHTS)
     sum(L.values()).backward()
-    grads = {"seg_model." + k: p.grad.numpy() for k, p in params.items() if p.grad is not None}
-    return {"root": root, "losses": {k: float(v) for k, v in L.items()}, "grads": grads,
-            "stats": {"seg_model." + k: v.numpy() for k, v in so.items()}, "zs": zs.detach().numpy()}
+    grads = {"seg_model." + k: p.grad.double().numpy() for k, p in params.items() if p.grad is not None}
+    return ({k: float(v.detach()) for k, v in L.items()}, grads,
+            {"seg_model." + k: v.double().numpy() for k, v in so.items()})
+
+
+_ORACLE = {}
+
+
+def _oracle(depth, tmp_path_factory, monkeypatch):
+    """the oracle's step in float64 (the truth) and in float32 (the yardstick: what an independent, correct fp32
+    implementation is away from the truth on this state), once per depth"""
+    _patch_depth(monkeypatch, depth)
+    if depth not in _ORACLE:
+        root = str(tmp_path_factory.mktemp("trainstep_" + depth))
+        sd = _state(depth)
+        torch.save(sd, os.path.join(root, "init.pth"))
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        _ORACLE[depth] = {"root": root, "f64": _oracle_step(sd, torch.float64), "f32": _oracle_step(sd, torch.float32)}
+    return _ORACLE[depth]
 
 
 def _trainer(root, apex_opt, amp_dtype):
@@ -141,11 +182,11 @@ def _device_step(tr):
             HF.enable_wgrad_overlap(False)
         HF.wgrad_stream_join()
         torch.cuda.synchronize()
-        grads = {k: p.grad.detach().float().cpu().numpy() / scale for k, p in net.named_parameters() if p.grad is not None}
+        grads = {k: p.grad.detach().double().cpu().numpy() / scale for k, p in net.named_parameters() if p.grad is not None}
         if tr.scaler is None or all(np.isfinite(g).all() for g in grads.values()) or scale <= 1.0:
             break
         scale *= 0.5
-    stats = {k: v.detach().float().cpu().numpy() for k, v in net.state_dict().items()
+    stats = {k: v.detach().double().cpu().numpy() for k, v in net.state_dict().items()
              if k.endswith(("running_mean", "running_var"))}
     return {k: float(v) for k, v in losses.items()}, grads, stats, scale
 
@@ -153,52 +194,61 @@ def _device_step(tr):
 MODES = {"O0": ("O0", "bf16"), "O1_bf16": ("O1", "bf16"), "O1_fp16": ("O1", "fp16")}
 
 
+@pytest.mark.parametrize("depth", list(DEPTHS))
 @pytest.mark.parametrize("mode", list(MODES))
-def test_training_step_vs_cpu_autograd_oracle(oracle_step, mode):
-    tr = _trainer(oracle_step["root"], *MODES[mode])
+def test_training_step_vs_cpu_autograd_oracle(tmp_path_factory, monkeypatch, mode, depth):
+    orc = _oracle(depth, tmp_path_factory, monkeypatch)
+    tr = _trainer(orc["root"], *MODES[mode])
     losses, grads, stats, scale = _device_step(tr)
     fp32 = mode == "O0"
-    want = oracle_step["losses"]
-    lines = ["training step vs CPU-autograd oracle, mode %s, B=%d 3x%dx%d, loss scale %g" % (mode, B, H, W, scale)]
+    want, og, ostats = orc["f64"]
+    _, yg, _ = orc["f32"]
+    lines = ["training step vs CPU-autograd oracle (float64), mode %s, trunk %s %s, B=%d 3x%dx%d, loss scale %g"
+             % (mode, depth, DEPTHS[depth], B, H, W, scale),
+             "columns: cos(device, oracle64) | max-rel(device, oracle64) | cos(oracle32, oracle64) = the yardstick"]
     for k, v in want.items():
         rel = abs(losses[k] - v) / max(1.0, abs(v))
         lines.append("loss %-22s device %.7f oracle %.7f rel %.2e" % (k, losses[k], v, rel))
         assert rel <= (2e-4 if fp32 else 3e-2), (k, losses[k], v)
-    og = oracle_step["grads"]
-    assert set(grads) == set(og) and len(og) == 112, (len(grads), len(og))
-    rel, cos = {}, {}
+    n_convs = 3 * sum(DEPTHS[depth]) + 4 + 1
+    assert set(grads) == set(og) and len(og) == n_convs + 8, (len(grads), len(og))     # (r101: 104 + 8 = 112)
+    rel, cos, ycos = {}, {}, {}
     for k in og:
-        cos[k] = _cos(grads[k], og[k])
+        cos[k], ycos[k] = _cos(grads[k], og[k]), _cos(yg[k], og[k])
         rel[k] = float(np.abs(grads[k] - og[k]).max() / (np.abs(og[k]).max() + 1e-30))
     order = [k for k in tr.model.module.state_dict() if k in og]
     for k in order:
-        lines.append("grad %-52s cos %.6f  max-rel %.2e  |g|max %.3e" % (k[len("seg_model."):], cos[k], rel[k],
-                                                                       float(np.abs(og[k]).max())))
+        lines.append("grad %-52s cos %.8f  max-rel %.2e  | yardstick cos %.8f" % (k[len("seg_model."):], cos[k], rel[k], ycos[k]))
     head = [k for k in og if "aspp" in k]
     trunk = [k for k in og if "aspp" not in k]
-    lines.append("summary: head cos min %.6f, trunk cos min %.6f mean %.6f; max-rel head %.2e trunk max %.2e median %.2e"
+    lines.append("summary: head cos min %.8f; trunk cos min %.8f mean %.8f (yardstick: min %.8f mean %.8f); max-rel head %.2e "
+                 "trunk max %.2e median %.2e"
                  % (min(cos[k] for k in head), min(cos[k] for k in trunk), float(np.mean([cos[k] for k in trunk])),
+                    min(ycos[k] for k in trunk), float(np.mean([ycos[k] for k in trunk])),
                     max(rel[k] for k in head), max(rel[k] for k in trunk), float(np.median([rel[k] for k in trunk]))))
-    # running statistics after the train-mode forward (momentum 0.1, unbiased variance; the student's 104 layers)
-    srel = {}
-    for k, v in oracle_step["stats"].items():
-        srel[k] = float(np.abs(stats[k] - v).max() / (np.abs(v).max() + 1e-30))
+    # running statistics after the train-mode forward (momentum 0.1, unbiased variance; every BatchNorm of the student)
+    srel = {k: float(np.abs(stats[k] - v).max() / (np.abs(v).max() + 1e-30)) for k, v in ostats.items()}
     lines.append("running statistics: max rel deviation %.2e (%s)" % (max(srel.values()), max(srel, key=srel.get)))
     out_dir = os.path.join(ROOT, "gpurun_out")
     try:
         os.makedirs(out_dir, exist_ok=True)
-        with open(os.path.join(out_dir, "r03_trainstep_oracle_%s.txt" % mode), "w") as f:
+        with open(os.path.join(out_dir, "r03_trainstep_oracle_%s_%s.txt" % (depth, mode)), "w") as f:
             f.write("\n".join(lines) + "\n")
     except OSError:
         pass
     print("\n".join(lines[:6] + lines[-2:]))
     if fp32:
-        assert min(cos.values()) >= 0.999, min(cos.items(), key=lambda kv: kv[1])
+        # every tensor: as close to the float64 truth as an independent fp32 implementation (the oracle in float32) is —
+        # 1 - cos within 4x of the yardstick's (+ 1e-7: where the yardstick itself is at rounding level)
+        for k in og:
+            assert 1.0 - cos[k] <= 4.0 * (1.0 - ycos[k]) + 1e-7, (k, cos[k], ycos[k])
+        assert min(cos.values()) >= 0.9998, min(cos.items(), key=lambda kv: kv[1])
         assert max(rel[k] for k in head) <= 1e-3, max(((k, rel[k]) for k in head), key=lambda kv: kv[1])
-        assert max(rel.values()) <= 1e-2, max(rel.items(), key=lambda kv: kv[1])
         assert max(srel.values()) <= 1e-3, max(srel.items(), key=lambda kv: kv[1])
     else:
         assert min(cos[k] for k in head) >= 0.995, min(((k, cos[k]) for k in head), key=lambda kv: kv[1])
-        assert cos["seg_model.backbone.layer4.2.conv3.weight"] >= 0.98
-        assert min(cos[k] for k in trunk if "layer4" in k) >= 0.9
         assert max(srel.values()) <= 5e-2, max(srel.items(), key=lambda kv: kv[1])
+        if depth == "r26":          # shallow trunk: every gradient tensor is bounded
+            assert min(cos[k] for k in trunk) >= 0.90, min(((k, cos[k]) for k in trunk), key=lambda kv: kv[1])
+        else:                       # full depth: the last block is bounded, the rest is recorded (docstring)
+            assert cos["seg_model.backbone.layer4.2.conv3.weight"] >= 0.9
