@@ -6,6 +6,7 @@
 // are reproducible against the CPU oracle.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 
@@ -20,6 +21,62 @@
     } while (0)
 
 namespace hiast {
+
+// ---- the two 16-bit storage types of the mixed-precision path (operand format HIAST_FMT_BF16 / HIAST_FMT_FP16) ----------
+// The reference trains under apex O1 = IEEE fp16 (code/utils/default_config.py:109, utils/utils.py:126-132); bf16 is
+// the type the round-1/2 kernels were written for.  Both feed the same matrix cores at the same rate
+// (v_mfma_f32_16x16x32_{bf16,f16}, v_mfma_f32_32x32x16_{bf16,f16}: fp32 accumulate) and the slab format / LDS images /
+// DMA patterns are type-agnostic, so every kernel of that path takes the type as a template parameter and touches
+// it only where a value is decoded, encoded (round to nearest even) or multiplied.
+typedef __attribute__((ext_vector_type(8))) __bf16 h_bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 h_f16x8;
+typedef __attribute__((ext_vector_type(4))) float h_f32x4;
+typedef __attribute__((ext_vector_type(16))) float h_f32x16;
+
+template <bool F16>
+struct H16;
+
+template <>
+struct H16<false> {                                   // bf16: the upper half of an fp32
+    static __device__ __forceinline__ float lo(unsigned w) { return __uint_as_float(w << 16); }           // low 16 bits of w
+    static __device__ __forceinline__ float hi(unsigned w) { return __uint_as_float(w & 0xFFFF0000u); }   // high 16 bits
+    static __device__ __forceinline__ float dec(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+    static __device__ __forceinline__ unsigned short enc(float v) { return __bfloat16_as_ushort(__float2bfloat16(v)); }
+    static __device__ __forceinline__ unsigned pack(float a, float b) { return (unsigned)enc(a) | ((unsigned)enc(b) << 16); }
+    template <class V>
+    static __device__ __forceinline__ h_f32x4 mfma16(const V& a, const V& b, h_f32x4 c)
+    {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(h_bf16x8, a), __builtin_bit_cast(h_bf16x8, b), c, 0, 0, 0);
+    }
+    template <class V>
+    static __device__ __forceinline__ h_f32x16 mfma32(const V& a, const V& b, h_f32x16 c)
+    {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(h_bf16x8, a), __builtin_bit_cast(h_bf16x8, b), c, 0, 0, 0);
+    }
+};
+
+template <>
+struct H16<true> {                                    // IEEE binary16 (v_cvt_f32_f16 / v_cvt_f16_f32, round to nearest even)
+    static __device__ __forceinline__ float dec(unsigned short h) { return __half2float(__ushort_as_half(h)); }
+    static __device__ __forceinline__ float lo(unsigned w) { return dec((unsigned short)(w & 0xFFFFu)); }
+    static __device__ __forceinline__ float hi(unsigned w) { return dec((unsigned short)(w >> 16)); }
+    static __device__ __forceinline__ unsigned short enc(float v) { return __half_as_ushort(__float2half_rn(v)); }
+    static __device__ __forceinline__ unsigned pack(float a, float b) { return (unsigned)enc(a) | ((unsigned)enc(b) << 16); }
+    template <class V>
+    static __device__ __forceinline__ h_f32x4 mfma16(const V& a, const V& b, h_f32x4 c)
+    {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h_f16x8, a), __builtin_bit_cast(h_f16x8, b), c, 0, 0, 0);
+    }
+    template <class V>
+    static __device__ __forceinline__ h_f32x16 mfma32(const V& a, const V& b, h_f32x16 c)
+    {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h_f16x8, a), __builtin_bit_cast(h_f16x8, b), c, 0, 0, 0);
+    }
+};
+
+// operand format argument of the C ABI -> (planes per value, fp16?)
+static inline int hiast_fmt_planes(int fmt) { return fmt == HIAST_FMT_SPLIT_BF16 ? 2 : 1; }
+static inline int hiast_fmt_ok(int fmt) { return fmt == HIAST_FMT_BF16 || fmt == HIAST_FMT_SPLIT_BF16 || fmt == HIAST_FMT_FP16; }
 
 // exp(x) for x <= 0: Cody-Waite reduction + degree-7 Taylor (Horner, fmaf); x < -87 -> 0.
 __device__ __forceinline__ float a_expf(float x)
