@@ -51,15 +51,19 @@ def parse():
     p.add_argument("--same-device", action="store_true", help="testing: every rank uses cuda:0")
     p.add_argument("--cpu-threads", type=int, default=64, help="upper bound; the usable CPUs of the box decide")
     p.add_argument("--cpu-reps", type=int, default=3)
+    p.add_argument("--amp-dtype", default=os.environ.get("HIAST_BENCH_AMP", "bf16"), choices=["bf16", "fp16"],
+                   help="16-bit type of the mixed-precision training step: fp16 = the reference's apex-O1 arithmetic (dynamic "
+                        "loss scaling, handled on the device), bf16 = no loss scaling; both run on the same hand-written kernels")
     p.add_argument("--trainer", default="ConsistencySelfTrainingTrainer",
                    choices=["ConsistencySelfTrainingTrainer", "SelfTrainingTrainer"])
     return p.parse_args()
 
 
-def make_cfg(world, trainer):
+def make_cfg(world, trainer, amp_dtype="bf16"):
     from hiast_amd.utils.default_config import get_default_cfg
     c = get_default_cfg()
     c.trainer = trainer
+    c.train.amp_dtype = amp_dtype
     c.model.type = "SelfTrainingSegmentor"
     c.model.predictor.kld_loss.weight = 0.1        # configs/sl_1.yaml
     c.model.predictor.ent_loss.weight = 1.0
@@ -213,7 +217,7 @@ class HotPath:
         from hiast_amd.utils import utils
         from hiast_amd.utils.registry import register  # noqa: F401
         from torch.nn.parallel import DistributedDataParallel as DDP
-        from hiast_amd.workflows.trainer.base_trainer import _Bare, autocast_dtype
+        from hiast_amd.workflows.trainer.base_trainer import _Bare, autocast_dtype, make_grad_scaler
         self.cfg, self.device, self.rank, self.world, self.B = cfg, device, rank, world, B
         utils.seed_everything(cfg.train.random_seed)
         model = utils.init_model(cfg).to(device)
@@ -222,6 +226,8 @@ class HotPath:
         self.opt, _ = utils.init_optimizers(cfg, model)
         self.sched = utils.init_schedulers(cfg, self.opt)
         self.amp = autocast_dtype(cfg)
+        self.scaler = make_grad_scaler(self.amp)        # fp16: apex's dynamic loss scaling (2^16, halved on overflow)
+        self.skipped = 0
         self.model = (DDP(model, device_ids=[device.index], gradient_as_bucket_view=True, bucket_cap_mb=32,
                           broadcast_buffers=False) if world > 1 else _Bare(model))
         self.teacher = cfg.cst_training.is_enabled
@@ -403,9 +409,13 @@ class HotPath:
         losses = self.model.module.compute_loss_lowres(out["logits_lowres"], plbl, out["size"], teacher_lr)
         g_loss = sum(torch.mean(v) for v in losses.values())
         self.opt.zero_grad(set_to_none=True)
-        g_loss.backward()
+        (self.scaler.scale(g_loss) if self.scaler else g_loss).backward()
         HF.wgrad_stream_join()      # weight gradients of the trunk run on a side stream in single-process runs
-        self.opt.step()
+        if self.scaler:             # FusedAdam unscales / skips on the device: no host read of found_inf
+            self.scaler.step(self.opt)
+            self.scaler.update()
+        else:
+            self.opt.step()
         if self.teacher:
             self.ema_updater(self.ema, self.model, self.cfg.cst_training.ema_model.gamma)
         for s in self.sched:
@@ -610,7 +620,7 @@ def main():
         comm.setup()        # SyncBN sums and the histogram exchange get communicators of their own, beside DDP's
     torch.backends.cudnn.benchmark = bool(int(os.environ.get("HIAST_MIOPEN_FIND", "0")))
 
-    cfg = make_cfg(world, args.trainer)
+    cfg = make_cfg(world, args.trainer, args.amp_dtype)
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):        # the package's progress prints ("%% freeze all BN layers" ...)
         from hiast_amd.utils import utils as _u
@@ -638,6 +648,19 @@ def main():
     hp.use_side = True
     HF.enable_wgrad_overlap(True)
     sync()
+    # fp16: the dynamic loss scale starts at 2^16 (apex) and is halved on every overflow; a step that overflows skips its
+    # optimiser update.  No such step may sit in the timed region: extra (untimed) steps until one has been APPLIED at the
+    # current scale, and the applied-step counter is compared again after the timed steps.
+    settle = 0
+    if hp.scaler is not None:
+        while settle < 24:
+            before = hp.opt.applied_steps()
+            hp.step()
+            settle += 1
+            if hp.opt.applied_steps() == before + 1:
+                break
+        sync()
+    applied_before = hp.opt.applied_steps() if hp.scaler is not None else None
 
     def marker():
         """a uniquely named tiny kernel (hiast::confusion_kernel) that brackets the timed region in a
@@ -696,6 +719,9 @@ def main():
         dist.all_reduce(both, op=dist.ReduceOp.MAX)         # max(x) == -max(-x) on every element <=> all ranks equal
         ranks_agree = bool(torch.equal(both[0], -both[1]))
     final_losses = dict(zip(names, [float(v) for v in lv.cpu()]))
+    skipped = None
+    if hp.scaler is not None:       # optimiser updates skipped inside the timed region (must be 0: see the warm-up above)
+        skipped = args.steps - (hp.opt.applied_steps() - applied_before)
 
     if rank == 0:
         imgs = world * args.batch * args.steps
@@ -703,10 +729,16 @@ def main():
             "metric": "self-training images/sec (fwd+bwd+pseudo-label) at 1024x512",
             "value": imgs / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
-            "dtype_detail": "bf16 MFMA with fp32 accumulate everywhere: plain bf16 in the training step (the reference "
-                            "trains under apex O1), split-bf16 planes (hi*hi+lo*hi+hi*lo, fp32-class) in the "
-                            "pseudo-label forward incl. its ASPP head; losses / softmax / thresholds fp32 + integer",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.amp_dtype,
+            "dtype_detail": "16-bit MFMA with fp32 accumulate everywhere: %s in the training step, split-bf16 planes "
+                            "(hi*hi+lo*hi+hi*lo, fp32-class) in the pseudo-label forward incl. its ASPP head; losses / "
+                            "softmax / thresholds fp32 + integer"
+                            % ("IEEE fp16 operands with apex-style dynamic loss scaling — the reference's own training "
+                               "arithmetic (apex O1)" if args.amp_dtype == "fp16" else
+                               "plain bf16 operands (no loss scaling; the reference trains under apex O1 = fp16: "
+                               "--amp-dtype fp16 runs that on the same kernels)"),
+            "loss_scale": ({"final": float(hp.scaler.get_scale()), "settle_steps_before_timing": settle,
+                            "optimizer_steps_skipped_in_timed_region": skipped} if hp.scaler is not None else None),
             "data": "synthetic",
             "config": {"workload": "configs[2] self-training round (%s, region-adaptive reg on) bs=%d/GPU @1024x512 "
                                    "+ configs[1] IAS pseudo-label pass on the same batch" % (args.trainer, args.batch),

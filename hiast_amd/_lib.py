@@ -41,7 +41,7 @@ SIGNATURES = {
     "hiast_aspp2_workspace_bytes": (c_sz, [c_int] * 6),
     "hiast_aspp2_pack_weights": (c_int, [c_vp] * 8 + [c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "hiast_aspp2_fwd": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp] + [c_int] * 5 + [c_vp, c_vp, c_sz, c_vp]),
-    "hiast_aspp2_bwd": (c_int, [c_vp] * 9 + [c_int] * 5 + [c_vp, c_vp, c_sz, c_vp]),
+    "hiast_aspp2_bwd": (c_int, [c_vp] * 9 + [c_int] * 5 + [c_vp, c_int, c_vp, c_sz, c_vp]),
     "hiast_bn_workspace_bytes": (c_sz, [c_int, c_int]),
     "hiast_bn_stats": (c_int, [c_vp, c_int, c_int, c_i64, c_int, c_vp, c_vp]),
     "hiast_bn_act_apply": (c_int, [c_vp] * 8 + [c_int, ctypes.c_double, c_f32, c_f32, c_int, c_vp, c_vp,
@@ -54,30 +54,32 @@ SIGNATURES = {
     "hiast_bn_act_nhwc_infer": (c_int, [c_vp] * 6 + [c_f32, c_int, c_i64, c_int, c_int, c_vp]),
     "hiast_igemm_bn_act": (c_int, [c_vp] * 6 + [c_f32, c_vp, c_int, c_vp] + [c_int] * 10 + [c_vp, c_vp, c_int, c_vp]),
     "hiast_igemm_stats_rows": (c_int, [c_i64, c_int, c_int, c_int, c_int]),
-    "hiast_igemm_dgrad_bn_stats": (c_int, [c_vp, c_vp, c_vp] + [c_int] * 7 + [c_vp] * 7),
+    "hiast_igemm_dgrad_bn_stats": (c_int, [c_vp, c_vp, c_vp] + [c_int] * 7 + [c_vp] * 6 + [c_int, c_vp]),
     "hiast_igemm_dgrad_bn_stats_rows": (c_int, [c_i64]),
     "hiast_bn_nhwc_stats_from_partial": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
     "hiast_conv_wgrad_workspace_bytes": (c_sz, [c_int] * 6),
-    "hiast_conv_wgrad_nhwc": (c_int, [c_vp, c_vp, c_vp] + [c_int] * 8 + [c_vp, c_sz, c_vp]),
+    "hiast_conv_wgrad_nhwc": (c_int, [c_vp, c_vp, c_vp] + [c_int] * 9 + [c_vp, c_sz, c_vp]),
     "hiast_pack_conv_weight": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "hiast_bn_nhwc_workspace_bytes": (c_sz, [c_int]),
-    "hiast_bn_nhwc_stats": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_sz, c_vp]),
+    "hiast_bn_nhwc_stats": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_sz, c_int, c_vp]),
     "hiast_bn_nhwc_apply": (c_int, [c_vp] * 8 + [ctypes.c_double, c_f32, c_f32, c_int, c_vp, c_vp, c_i64, c_int, c_vp,
-                                    c_vp]),
+                                    c_int, c_vp]),
     "hiast_bn_nhwc_apply_partial": (c_int, [c_vp] * 8 + [c_int, ctypes.c_double, c_f32, c_f32, c_int, c_vp, c_vp, c_i64,
-                                            c_int, c_vp, c_vp]),
-    "hiast_bn_nhwc_bwd_stats": (c_int, [c_vp] * 7 + [c_int, c_i64, c_int, c_vp, c_vp, c_sz, c_vp]),
-    "hiast_bn_nhwc_bwd_apply": (c_int, [c_vp] * 8 + [ctypes.c_double, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp]),
+                                            c_int, c_vp, c_int, c_vp]),
+    "hiast_bn_nhwc_bwd_stats": (c_int, [c_vp] * 7 + [c_int, c_i64, c_int, c_vp, c_vp, c_sz, c_int, c_vp]),
+    "hiast_bn_nhwc_bwd_apply": (c_int, [c_vp] * 8 + [ctypes.c_double, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int,
+                                        c_vp]),
     "hiast_pack_conv_weight_multi": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
     "hiast_split_planes": (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
     "hiast_stem_tail": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "hiast_ema_update": (c_int, [c_vp, c_vp, c_vp, c_int, c_f32, c_f32, c_vp]),
     "hiast_normalize_u8": (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_vp, c_vp]),
-    "hiast_maxpool3x3s2_nhwc_fwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
-    "hiast_maxpool3x3s2_nhwc_bwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "hiast_maxpool3x3s2_nhwc_fwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "hiast_maxpool3x3s2_nhwc_bwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "hiast_copy_paste_u8": (c_int, [c_vp] * 6 + [c_int, c_i64, c_vp]),
     "hiast_multi_copy": (c_int, [c_vp, c_int, c_vp]),
-    "hiast_adam_step": (c_int, [c_vp, c_vp, c_vp, c_int, ctypes.c_double, ctypes.c_double, c_f32, c_f32, c_vp]),
+    "hiast_adam_step": (c_int, [c_vp, c_vp, c_vp, c_int, ctypes.c_double, ctypes.c_double, c_f32, c_f32, c_vp, c_vp, c_vp,
+                                c_vp]),
     "hiast_confusion_hist": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp]),
 }
 
@@ -109,7 +111,7 @@ def load():
             raise HiastLibraryError("libhiast_hip.so does not export %s" % name) from e
         fn.restype = res
         fn.argtypes = args
-    if lib.hiast_version() != 1:
+    if lib.hiast_version() != 2:
         raise HiastLibraryError("libhiast_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -123,6 +123,7 @@ __global__ __launch_bounds__(256) void aspp2_shift_add_kernel(const float* __res
 
 // G[q][n = tap*Cout+co] = bf16(dY[b][co][q - off(tap)]) (0 outside the image and for n >= 33*Cout);
 // one thread = 8 consecutive n of one pixel (one 16-byte store).
+template <bool F16>
 __global__ __launch_bounds__(256) void aspp2_gather_kernel(const float* __restrict__ dy,
                                                            unsigned short* __restrict__ G, int B, int h, int w,
                                                            int Cout, int NP, Taps2 taps)
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256) void aspp2_gather_kernel(const float* __restri
                 const int yy = qy - taps.dy[t], xx = qx - taps.dx[t];
                 if (yy >= 0 && yy < h && xx >= 0 && xx < w) f = dyb[(size_t)co * hw + yy * w + xx];
             }
-            v[u] = __bfloat16_as_ushort(__float2bfloat16(f));
+            v[u] = H16<F16>::enc(f);
         }
         pk[j >> 1] = (unsigned)v[0] | ((unsigned)v[1] << 16);
     }
@@ -169,6 +170,7 @@ typedef short s16x8_t __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ int tn_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
 
+template <bool F16>
 __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const unsigned short* __restrict__ A,
                                                            const unsigned short* __restrict__ Bm,
                                                            float* __restrict__ P, int M, int I, int J,
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const unsigned short*
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = H16<F16>::mfma32(fa[a], fb[b], acc[a][b]);
         }
         if (kt + 1 < nk) lds_store(buf ^ 1);
         __syncthreads();
@@ -383,7 +385,7 @@ extern "C" int hiast_aspp2_fwd(const void* x_nhwc, int dtype, const void* wt, co
     if (!x_nhwc || !wt || !bias || !y || !dil || !workspace) return HIAST_E_ARG;
     int e = aspp2_check(B, Cin, h, w, Cout);
     if (e) return e;
-    if (dtype < 0 || dtype > 2) return HIAST_E_RANGE;
+    if (dtype < 0 || dtype > 3) return HIAST_E_RANGE;      // 0 fp32 rows | HIAST_FMT_BF16 | _SPLIT_BF16 | _FP16
     const int NP = aspp2_np(Cout);
     const long long M = (long long)B * h * w;
     if (workspace_bytes < (size_t)M * NP * sizeof(float)) return HIAST_E_WS;
@@ -392,7 +394,7 @@ extern "C" int hiast_aspp2_fwd(const void* x_nhwc, int dtype, const void* wt, co
     float* T = (float*)workspace;
     if (dtype == 0)      // fp32 rows, fp32 weights: the register-staged kernel splits on the fly
         e = hiast_gemm_nt_launch(x_nhwc, (const float*)wt, T, M, Cin, NP, 0, st);
-    else                 // bf16 rows (1) / split planes (2) with weights packed by hiast_pack_conv_weight: LDS-DMA kernel
+    else                 // bf16 rows (1) / split planes (2) / fp16 rows (3), weights packed by hiast_pack_conv_weight: LDS-DMA kernel
         e = hiast_igemm_launch(x_nhwc, wt, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, 0, T, M, Cin, NP, 1, 0, 0,
                                1, 1, dtype, 1, st, nullptr, nullptr, 0);
     if (e) return e;
@@ -405,8 +407,10 @@ extern "C" int hiast_aspp2_fwd(const void* x_nhwc, int dtype, const void* wt, co
 
 extern "C" int hiast_aspp2_bwd(const void* x_nhwc, const float* dy, const void* wd, void* dx_nhwc, float* dw0,
                                float* dw1, float* dw2, float* dw3, float* db, int B, int Cin, int h, int w, int Cout,
-                               const int* dil, void* workspace, size_t workspace_bytes, hiast_stream_t stream)
+                               const int* dil, int fmt, void* workspace, size_t workspace_bytes, hiast_stream_t stream)
 {
+    if (fmt != HIAST_FMT_BF16 && fmt != HIAST_FMT_FP16) return HIAST_E_RANGE;
+    const bool f16 = fmt == HIAST_FMT_FP16;
     if (!dy || !dil || !workspace) return HIAST_E_ARG;
     const bool want_w = dw0 || dw1 || dw2 || dw3 || db;
     if (want_w && (!x_nhwc || !dw0 || !dw1 || !dw2 || !dw3 || !db)) return HIAST_E_ARG;
@@ -423,13 +427,17 @@ extern "C" int hiast_aspp2_bwd(const void* x_nhwc, const float* dy, const void* 
     const size_t g_bytes = (((size_t)M * NP * 2 + 255) / 256) * 256;
     float* P = (float*)((unsigned char*)workspace + g_bytes);
     const long long gthreads = M * (NP / 8);
-    hipLaunchKernelGGL(hiast::aspp2_gather_kernel, dim3((unsigned)((gthreads + 255) / 256)), dim3(256), 0, st, dy, G, B,
-                       h, w, Cout, NP, taps);
+    if (f16)
+        hipLaunchKernelGGL(hiast::aspp2_gather_kernel<true>, dim3((unsigned)((gthreads + 255) / 256)), dim3(256), 0, st, dy, G,
+                           B, h, w, Cout, NP, taps);
+    else
+        hipLaunchKernelGGL(hiast::aspp2_gather_kernel<false>, dim3((unsigned)((gthreads + 255) / 256)), dim3(256), 0, st, dy, G,
+                           B, h, w, Cout, NP, taps);
     HIAST_CHECK_LAUNCH();
     if (dx_nhwc) {
         // dX[M][Cin] = G[M][NP] * wd[Cin][NP]^T, wd packed bf16 (hiast_pack_conv_weight, planes = 1)
         e = hiast_igemm_launch(G, wd, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, 0, dx_nhwc, M, NP, Cin, 1, 0, 0, 1,
-                               1, 1, 0, st, nullptr, nullptr, 0);
+                               1, fmt, 0, st, nullptr, nullptr, 0);
         if (e) return e;
     }
     if (want_w) {
@@ -437,8 +445,12 @@ extern "C" int hiast_aspp2_bwd(const void* x_nhwc, const float* dy, const void* 
         int mps = (int)((M + nsplit - 1) / nsplit);
         mps = ((mps + 31) / 32) * 32;
         dim3 grid(NP / 128, Cin / 128, nsplit);
-        hipLaunchKernelGGL(hiast::gemm_tn_bf16_kernel, grid, dim3(256), 0, st, G, (const unsigned short*)x_nhwc, P,
-                           (int)M, NP, Cin, mps);
+        if (f16)
+            hipLaunchKernelGGL(hiast::gemm_tn_bf16_kernel<true>, grid, dim3(256), 0, st, G, (const unsigned short*)x_nhwc, P,
+                               (int)M, NP, Cin, mps);
+        else
+            hipLaunchKernelGGL(hiast::gemm_tn_bf16_kernel<false>, grid, dim3(256), 0, st, G, (const unsigned short*)x_nhwc, P,
+                               (int)M, NP, Cin, mps);
         HIAST_CHECK_LAUNCH();
         const long long total = (long long)hiast::A2_NTAP * Cout * Cin;
         hipLaunchKernelGGL(hiast::aspp2_wgrad_unpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, P,

@@ -60,19 +60,23 @@ constexpr int BNH_MAXBLK = 512;
 #define BNH_UNR_BWD 4
 #endif
 
+// F16 (every kernel below): the activations are IEEE fp16 rows (HIAST_FMT_FP16) instead of bf16; statistics, scale / shift
+// and the arithmetic are fp32 either way
+template <bool F16>
 __device__ __forceinline__ void bnh_unpack8(const uint4 r, float (&v)[8])
 {
     const unsigned w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        v[2 * i] = __uint_as_float(w[i] << 16);
-        v[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
+        v[2 * i] = H16<F16>::lo(w[i]);
+        v[2 * i + 1] = H16<F16>::hi(w[i]);
     }
 }
 
+template <bool F16>
 __device__ __forceinline__ void bnh_load8(const unsigned short* p, float (&v)[8])
 {
-    bnh_unpack8(*reinterpret_cast<const uint4*>(p), v);
+    bnh_unpack8<F16>(*reinterpret_cast<const uint4*>(p), v);
 }
 
 // 8 consecutive per-channel floats as two 16-byte loads; p == nullptr -> the constant dflt (selected, not branched on)
@@ -85,13 +89,12 @@ __device__ __forceinline__ void bnh_param8(const float* p, const float* some_val
     v[4] = has ? b.x : dflt; v[5] = has ? b.y : dflt; v[6] = has ? b.z : dflt; v[7] = has ? b.w : dflt;
 }
 
+template <bool F16>
 __device__ __forceinline__ void bnh_store8(unsigned short* p, const float (&v)[8])
 {
     unsigned w[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-        w[i] = (unsigned)__bfloat16_as_ushort(__float2bfloat16(v[2 * i])) |
-               ((unsigned)__bfloat16_as_ushort(__float2bfloat16(v[2 * i + 1])) << 16);
+    for (int i = 0; i < 4; ++i) w[i] = H16<F16>::pack(v[2 * i], v[2 * i + 1]);
     *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
@@ -101,7 +104,7 @@ __device__ __forceinline__ void bnh_store8(unsigned short* p, const float (&v)[8
 // GATE (ReLU gate of the backward passes): 0 = none, 1 = y > 0 (y is read), 2 = recomputed from x as
 // x*scale + shift > 0 — valid when the forward had no residual input, and saves reading y in both backward passes,
 // 3 = the bit mask the forward wrote ([M][C/8] bytes, passed in place of y): 1/16 of y's bytes.
-template <bool BWD, int GATE>
+template <bool BWD, int GATE, bool F16 = false>
 __global__ __launch_bounds__(256) void bnh_partial_kernel(const unsigned short* __restrict__ a,    // x | dy
                                                           const unsigned short* __restrict__ y,
                                                           const unsigned short* __restrict__ x,
@@ -161,15 +164,15 @@ __global__ __launch_bounds__(256) void bnh_partial_kernel(const unsigned short* 
         for (int u = 0; u < UNR; ++u) {
             if (r0 + u * stride >= lim) break;
             float v[8];
-            bnh_unpack8(ra[u], v);
+            bnh_unpack8<F16>(ra[u], v);
             if (!BWD) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { s1[k] += v[k]; s2[k] = fmaf(v[k], v[k], s2[k]); }
             } else {
                 float yy[8], xx[8];
-                if (GATE == 1) bnh_unpack8(ry[u], yy);
+                if (GATE == 1) bnh_unpack8<F16>(ry[u], yy);
                 const unsigned bits = rbits[u];
-                bnh_unpack8(rx[u], xx);
+                bnh_unpack8<F16>(rx[u], xx);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const bool open = GATE == 0 || (GATE == 1 ? yy[k] > 0.f
@@ -306,7 +309,7 @@ __global__ __launch_bounds__(256) void bnh_finalize_prep_kernel(const float* __r
     }
 }
 
-template <bool RES, bool RELU>
+template <bool RES, bool RELU, bool F16 = false>
 __global__ __launch_bounds__(256) void bnh_apply_kernel(const unsigned short* __restrict__ x,
                                                         const unsigned short* __restrict__ res,
                                                         unsigned short* __restrict__ y, const float* __restrict__ gamma,
@@ -353,8 +356,8 @@ __global__ __launch_bounds__(256) void bnh_apply_kernel(const unsigned short* __
             if (r >= lim) break;
             const size_t off = (size_t)r * C + cg * 8;
             float v[8], rr[8];
-            bnh_unpack8(rx[u], v);
-            if (RES) bnh_unpack8(rres[u], rr);
+            bnh_unpack8<F16>(rx[u], v);
+            if (RES) bnh_unpack8<F16>(rres[u], rr);
             unsigned bits = 0;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(256) void bnh_apply_kernel(const unsigned short* __
                 bits |= (o > 0.f ? 1u : 0u) << k;
                 v[k] = o;
             }
-            bnh_store8(y + off, v);
+            bnh_store8<F16>(y + off, v);
             if (mask) mask[(size_t)r * G + cg] = (unsigned char)bits;
         }
         r0 += step;
@@ -372,7 +375,7 @@ __global__ __launch_bounds__(256) void bnh_apply_kernel(const unsigned short* __
     }
 }
 
-template <int GATE, bool DRES>
+template <int GATE, bool DRES, bool F16 = false>
 __global__ __launch_bounds__(256) void bnh_bwd_apply_kernel(
     const unsigned short* __restrict__ dy, const unsigned short* __restrict__ y, const unsigned short* __restrict__ x,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ save_mean,
@@ -430,10 +433,10 @@ __global__ __launch_bounds__(256) void bnh_bwd_apply_kernel(
             if (r >= lim) break;
             const size_t off = (size_t)r * C + cg * 8;
             float g[8], yy[8], xx[8];
-            bnh_unpack8(rg[u], g);
-            if (GATE == 1) bnh_unpack8(ry[u], yy);
+            bnh_unpack8<F16>(rg[u], g);
+            if (GATE == 1) bnh_unpack8<F16>(ry[u], yy);
             const unsigned bits = rbits[u];
-            bnh_unpack8(rx[u], xx);
+            bnh_unpack8<F16>(rx[u], xx);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const bool open = GATE == 0 || (GATE == 1 ? yy[k] > 0.f
@@ -442,8 +445,8 @@ __global__ __launch_bounds__(256) void bnh_bwd_apply_kernel(
                 g[k] = gg;
                 xx[k] = k0[k] * (gg - mg[k] - (xx[k] - mean[k]) * invstd[k] * mgx[k]);
             }
-            bnh_store8(dx + off, xx);
-            if (DRES) bnh_store8(dres + off, g);
+            bnh_store8<F16>(dx + off, xx);
+            if (DRES) bnh_store8<F16>(dres + off, g);
         }
         r0 += step;
         if (r0 < lim) load_rows(r0);
@@ -470,17 +473,26 @@ static int bnh_check(const void* x, long long M, int C)
 
 extern "C" size_t hiast_bn_nhwc_workspace_bytes(int C) { return (size_t)hiast::BNH_MAXBLK * C * 2 * sizeof(float); }
 
+#define BNH_FMT_CHECK()                                                             \
+    if (fmt != HIAST_FMT_BF16 && fmt != HIAST_FMT_FP16) return HIAST_E_RANGE;          \
+    const bool f16 = fmt == HIAST_FMT_FP16
+
 extern "C" int hiast_bn_nhwc_stats(const void* x, int64_t M, int C, double* sums, void* workspace,
-                                   size_t workspace_bytes, hiast_stream_t stream)
+                                   size_t workspace_bytes, int fmt, hiast_stream_t stream)
 {
+    BNH_FMT_CHECK();
     int e = bnh_check(x, M, C);
     if (e) return e;
     if (!sums || !workspace) return HIAST_E_ARG;
     const int nblk = hiast::bnh_nblk(M, C);
     if (workspace_bytes < (size_t)nblk * C * 2 * sizeof(float)) return HIAST_E_WS;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL((hiast::bnh_partial_kernel<false, 0>), dim3(nblk), dim3(256), 0, st, (const unsigned short*)x,
-                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (long long)M, C, (float*)workspace);
+    if (f16)
+        hipLaunchKernelGGL((hiast::bnh_partial_kernel<false, 0, true>), dim3(nblk), dim3(256), 0, st, (const unsigned short*)x,
+                           nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (long long)M, C, (float*)workspace);
+    else
+        hipLaunchKernelGGL((hiast::bnh_partial_kernel<false, 0>), dim3(nblk), dim3(256), 0, st, (const unsigned short*)x,
+                           nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (long long)M, C, (float*)workspace);
     HIAST_CHECK_LAUNCH();
     hipLaunchKernelGGL(hiast::bnh_finalize_kernel, dim3(C * 2 / 16), dim3(256), 0, st, (const float*)workspace, nblk, C,
                        sums);
@@ -504,8 +516,9 @@ extern "C" int hiast_bn_nhwc_stats_from_partial(const float* partial, int nblk, 
 extern "C" int hiast_bn_nhwc_apply(const void* x, const void* res, void* y, const float* gamma, const float* beta,
                                    float* running_mean, float* running_var, const double* sums, double count,
                                    float momentum, float eps, int relu, float* save_mean, float* save_invstd,
-                                   int64_t M, int C, void* mask, hiast_stream_t stream)
+                                   int64_t M, int C, void* mask, int fmt, hiast_stream_t stream)
 {
+    BNH_FMT_CHECK();
     int e = bnh_check(x, M, C);
     if (e) return e;
     if (!y || !sums || !save_mean || !save_invstd || count <= 0) return HIAST_E_ARG;
@@ -517,13 +530,15 @@ extern "C" int hiast_bn_nhwc_apply(const void* x, const void* res, void* y, cons
     hipLaunchKernelGGL(hiast::bnh_prep_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, count, momentum, eps,
                        running_mean, running_var, save_mean, save_invstd, C);
     HIAST_CHECK_LAUNCH();
-#define L(RES, RELU)                                                                                              \
-    hipLaunchKernelGGL((hiast::bnh_apply_kernel<RES, RELU>), dim3((unsigned)nb), dim3(256), 0, st,                 \
+#define L1(RES, RELU, F)                                                                                           \
+    hipLaunchKernelGGL((hiast::bnh_apply_kernel<RES, RELU, F>), dim3((unsigned)nb), dim3(256), 0, st,              \
                        (const unsigned short*)x, (const unsigned short*)res, (unsigned short*)y, gamma, beta,      \
                        save_mean, save_invstd, (long long)M, C, (unsigned char*)mask)
+#define L(RES, RELU) do { if (f16) L1(RES, RELU, true); else L1(RES, RELU, false); } while (0)
     if (res) { if (relu) L(true, true); else L(true, false); }
     else { if (relu) L(false, true); else L(false, false); }
 #undef L
+#undef L1
     HIAST_CHECK_LAUNCH();
     return 0;
 }
@@ -533,8 +548,10 @@ extern "C" int hiast_bn_nhwc_apply(const void* x, const void* res, void* y, cons
 extern "C" int hiast_bn_nhwc_apply_partial(const void* x, const void* res, void* y, const float* gamma, const float* beta,
                                            float* running_mean, float* running_var, const float* partial, int nblk,
                                            double count, float momentum, float eps, int relu, float* save_mean,
-                                           float* save_invstd, int64_t M, int C, void* mask, hiast_stream_t stream)
+                                           float* save_invstd, int64_t M, int C, void* mask, int fmt,
+                                           hiast_stream_t stream)
 {
+    BNH_FMT_CHECK();
     int e = bnh_check(x, M, C);
     if (e) return e;
     if (!y || !partial || !save_mean || !save_invstd || count <= 0 || nblk <= 0) return HIAST_E_ARG;
@@ -546,22 +563,25 @@ extern "C" int hiast_bn_nhwc_apply_partial(const void* x, const void* res, void*
     hipLaunchKernelGGL(hiast::bnh_finalize_prep_kernel, dim3(C / 2), dim3(256), 0, st, partial, nblk, C, count,
                        momentum, eps, running_mean, running_var, save_mean, save_invstd);
     HIAST_CHECK_LAUNCH();
-#define L(RES, RELU)                                                                                              \
-    hipLaunchKernelGGL((hiast::bnh_apply_kernel<RES, RELU>), dim3((unsigned)nb), dim3(256), 0, st,                 \
+#define L1(RES, RELU, F)                                                                                           \
+    hipLaunchKernelGGL((hiast::bnh_apply_kernel<RES, RELU, F>), dim3((unsigned)nb), dim3(256), 0, st,              \
                        (const unsigned short*)x, (const unsigned short*)res, (unsigned short*)y, gamma, beta,      \
                        save_mean, save_invstd, (long long)M, C, (unsigned char*)mask)
+#define L(RES, RELU) do { if (f16) L1(RES, RELU, true); else L1(RES, RELU, false); } while (0)
     if (res) { if (relu) L(true, true); else L(true, false); }
     else { if (relu) L(false, true); else L(false, false); }
 #undef L
+#undef L1
     HIAST_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int hiast_bn_nhwc_bwd_stats(const void* dy, const void* y, const void* x, const float* gamma,
                                        const float* beta, const float* save_mean, const float* save_invstd, int relu,
-                                       int64_t M, int C, double* sums, void* workspace, size_t workspace_bytes,
+                                       int64_t M, int C, double* sums, void* workspace, size_t workspace_bytes, int fmt,
                                        hiast_stream_t stream)
 {
+    BNH_FMT_CHECK();
     int e = bnh_check(x, M, C);
     if (e) return e;
     if (!dy || !save_mean || !save_invstd || !sums || !workspace || ((relu == 1 || relu == 3) && !y)) return HIAST_E_ARG;
@@ -569,12 +589,14 @@ extern "C" int hiast_bn_nhwc_bwd_stats(const void* dy, const void* y, const void
     const int nblk = hiast::bnh_nblk(M, C);
     if (workspace_bytes < (size_t)nblk * C * 2 * sizeof(float)) return HIAST_E_WS;
     hipStream_t st = (hipStream_t)stream;
-#define L(G)                                                                                                        \
-    hipLaunchKernelGGL((hiast::bnh_partial_kernel<true, G>), dim3(nblk), dim3(256), 0, st, (const unsigned short*)dy, \
+#define L1(G, F)                                                                                                    \
+    hipLaunchKernelGGL((hiast::bnh_partial_kernel<true, G, F>), dim3(nblk), dim3(256), 0, st, (const unsigned short*)dy, \
                        (const unsigned short*)y, (const unsigned short*)x, gamma, beta, save_mean, save_invstd,      \
                        (long long)M, C, (float*)workspace)
+#define L(G) do { if (f16) L1(G, true); else L1(G, false); } while (0)
     if (relu == 1) L(1); else if (relu == 2) L(2); else if (relu == 3) L(3); else L(0);
 #undef L
+#undef L1
     HIAST_CHECK_LAUNCH();
     hipLaunchKernelGGL(hiast::bnh_finalize_kernel, dim3(C * 2 / 16), dim3(256), 0, st, (const float*)workspace, nblk, C,
                        sums);
@@ -586,8 +608,9 @@ extern "C" int hiast_bn_nhwc_bwd_apply(const void* dy, const void* y, const void
                                        const float* beta, const float* save_mean, const float* save_invstd,
                                        const double* sums,
                                        double count, int relu, void* dx, void* dres, float* dgamma, float* dbeta,
-                                       int64_t M, int C, hiast_stream_t stream)
+                                       int64_t M, int C, int fmt, hiast_stream_t stream)
 {
+    BNH_FMT_CHECK();
     int e = bnh_check(x, M, C);
     if (e) return e;
     if (!dy || !save_mean || !save_invstd || !sums || !dx || ((relu == 1 || relu == 3) && !y) || count <= 0)
@@ -599,16 +622,18 @@ extern "C" int hiast_bn_nhwc_bwd_apply(const void* dy, const void* y, const void
     long long nb = (M + (long long)rpp * BNH_ROWS_PER_BLOCK_PASS - 1) / ((long long)rpp * BNH_ROWS_PER_BLOCK_PASS);
     nb = nb < 1 ? 1 : (nb > BNH_APPLY_MAXBLK ? BNH_APPLY_MAXBLK : nb);
     hipStream_t st = (hipStream_t)stream;
-#define L(G, DRES)                                                                                                 \
-    hipLaunchKernelGGL((hiast::bnh_bwd_apply_kernel<G, DRES>), dim3((unsigned)nb), dim3(256), 0, st,                \
+#define L1(G, DRES, F)                                                                                             \
+    hipLaunchKernelGGL((hiast::bnh_bwd_apply_kernel<G, DRES, F>), dim3((unsigned)nb), dim3(256), 0, st,             \
                        (const unsigned short*)dy, (const unsigned short*)y, (const unsigned short*)x, gamma, beta,  \
                        save_mean, save_invstd, sums, 1.0 / count, (unsigned short*)dx, (unsigned short*)dres, dgamma, \
                        dbeta, (long long)M, C)
+#define L(G, DRES) do { if (f16) L1(G, DRES, true); else L1(G, DRES, false); } while (0)
     if (relu == 1) { if (dres) L(1, true); else L(1, false); }
     else if (relu == 3) { if (dres) L(3, true); else L(3, false); }
     else if (relu == 2) { if (dres) L(2, true); else L(2, false); }
     else { if (dres) L(0, true); else L(0, false); }
 #undef L
+#undef L1
     HIAST_CHECK_LAUNCH();
     return 0;
 }

@@ -20,6 +20,10 @@
         if (e__ != hipSuccess) return (int)e__;      \
     } while (0)
 
+// operand format argument of the C ABI -> (planes per value, fp16?)
+static inline int hiast_fmt_planes(int fmt) { return fmt == HIAST_FMT_SPLIT_BF16 ? 2 : 1; }
+static inline int hiast_fmt_ok(int fmt) { return fmt == HIAST_FMT_BF16 || fmt == HIAST_FMT_SPLIT_BF16 || fmt == HIAST_FMT_FP16; }
+
 namespace hiast {
 
 // ---- the two 16-bit storage types of the mixed-precision path (operand format HIAST_FMT_BF16 / HIAST_FMT_FP16) ----------
@@ -73,10 +77,6 @@ struct H16<true> {                                    // IEEE binary16 (v_cvt_f3
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h_f16x8, a), __builtin_bit_cast(h_f16x8, b), c, 0, 0, 0);
     }
 };
-
-// operand format argument of the C ABI -> (planes per value, fp16?)
-static inline int hiast_fmt_planes(int fmt) { return fmt == HIAST_FMT_SPLIT_BF16 ? 2 : 1; }
-static inline int hiast_fmt_ok(int fmt) { return fmt == HIAST_FMT_BF16 || fmt == HIAST_FMT_SPLIT_BF16 || fmt == HIAST_FMT_FP16; }
 
 // exp(x) for x <= 0: Cody-Waite reduction + degree-7 Taylor (Horner, fmaf); x < -87 -> 0.
 __device__ __forceinline__ float a_expf(float x)

@@ -78,20 +78,47 @@ __global__ __launch_bounds__(256) void multi_copy_kernel(const hiast_copy_rec* _
 //   g' = g + wd*p;  m = m + (g' - m)*(1 - b1);  v = v*b2 + (1 - b2)*g'*g';
 //   p  = p - (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
 // 64Ki-element chunks like the EMA kernel; lr and the bias corrections travel per tensor in the record.
+// Mixed precision with dynamic loss scaling (apex O1 / torch GradScaler; base_trainer.py:129-131 of the reference):
+// the gradients arrive multiplied by the loss scale and a step whose gradients hold an inf / NaN must be skipped
+// ENTIRELY (no moment update, no step count).  Both decisions are taken on the device: adam_prepare_kernel turns the
+// scaler's device scalars (scale, found_inf) into a control block — skip flag, 1 / scale, the count of APPLIED steps and
+// the bias corrections that count implies — and adam_kernel reads it; the host never waits for found_inf (GradScaler's
+// own `if not found_inf.item(): optimizer.step()` drains the launch queue once per iteration).
+__global__ void adam_prepare_kernel(hiast_adam_ctl* __restrict__ ctl, const float* __restrict__ grad_scale,
+                                    const float* __restrict__ found_inf, double beta1, double beta2)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const bool skip = found_inf && *found_inf != 0.f;
+    float t = ctl->step;
+    if (!skip) t += 1.0f;
+    ctl->step = t;
+    ctl->skip = skip ? 1.0f : 0.0f;
+    ctl->inv_scale = grad_scale ? (float)(1.0 / (double)*grad_scale) : 1.0f;
+    ctl->bc1 = (float)(1.0 - pow(beta1, (double)t));             // torch: 1 - beta1 ** step, sqrt(1 - beta2 ** step), in double
+    ctl->bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)t));
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(const hiast_adam_rec* __restrict__ table,
                                                    const int32_t* __restrict__ chunk_tensor,
                                                    const int64_t* __restrict__ chunk_start, float beta1, float beta2,
-                                                   float omb1, float omb2, float eps, float wd)
+                                                   float omb1, float omb2, float eps, float wd,
+                                                   const hiast_adam_ctl* __restrict__ ctl)
 {
     const hiast_adam_rec r = table[chunk_tensor[blockIdx.x]];
     const int64_t s = chunk_start[blockIdx.x];
     const int64_t e = (s + 65536 < r.n) ? s + 65536 : r.n;
-    const float step_size = r.lr / r.bc1;     // omb1 / omb2 = float(1 - beta) formed in double on the host, as torch does
+    float bc1 = r.bc1, bc2_sqrt = r.bc2_sqrt, inv_scale = 1.0f;
+    if (ctl) {                                // device-side control block: skipped step / loss scale / applied-step count
+        if (ctl->skip != 0.f) return;
+        bc1 = ctl->bc1; bc2_sqrt = ctl->bc2_sqrt; inv_scale = ctl->inv_scale;
+    }
+    const float step_size = r.lr / bc1;       // omb1 / omb2 = float(1 - beta) formed in double on the host, as torch does
     auto upd = [&](float& p, float g, float& m, float& v) {
+        g = g * inv_scale;                    // (x 1.0f is exact: the unscaled path keeps its bits)
         if (wd != 0.f) g = g + wd * p;
         m = m + (g - m) * omb1;
         v = v * beta2 + omb2 * g * g;
-        const float denom = sqrtf(v) / r.bc2_sqrt + eps;
+        const float denom = sqrtf(v) / bc2_sqrt + eps;
         p = p - step_size * (m / denom);
     };
     const bool vec = ((((uintptr_t)r.p) | ((uintptr_t)r.g) | ((uintptr_t)r.m) | ((uintptr_t)r.v)) & 15) == 0;
@@ -187,13 +214,20 @@ extern "C" int hiast_confusion_hist(const int64_t* pred, const int64_t* target, 
 
 extern "C" int hiast_adam_step(const hiast_adam_rec* table, const int32_t* chunk_tensor, const int64_t* chunk_start,
                                int n_chunks, double beta1, double beta2, float eps, float weight_decay,
+                               hiast_adam_ctl* ctl, const float* grad_scale, const float* found_inf,
                                hiast_stream_t stream)
 {
     if (!table || !chunk_tensor || !chunk_start) return HIAST_E_ARG;
     if (n_chunks <= 0) return HIAST_E_ARG;
+    if (!ctl && (grad_scale || found_inf)) return HIAST_E_ARG;      // the device-side decisions need the control block
+    if (ctl) {
+        hipLaunchKernelGGL(hiast::adam_prepare_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ctl, grad_scale, found_inf,
+                           beta1, beta2);
+        HIAST_CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL(hiast::adam_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, table, chunk_tensor,
                        chunk_start, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), eps,
-                       weight_decay);
+                       weight_decay, (const hiast_adam_ctl*)ctl);
     HIAST_CHECK_LAUNCH();
     return 0;
 }
@@ -270,6 +304,8 @@ namespace hiast {
 // forward), forward with a one-byte window position per element instead of the library's 8-byte flat index, and its
 // backward as a gather over the <= 4 windows that cover an input pixel.  Ties go to the first element in row-major
 // window order and a NaN takes the maximum, as in ATen's kernel; the backward adds in fp32 and rounds once.
+// F16: fp16 rows (HIAST_FMT_FP16) instead of bf16
+template <bool F16>
 __global__ __launch_bounds__(256) void maxpool_cl_fwd_kernel(const unsigned short* __restrict__ x,
                                                              unsigned short* __restrict__ y, unsigned char* __restrict__ idx,
                                                              int B, int H, int W, int C, int Ho, int Wo)
@@ -296,7 +332,7 @@ __global__ __launch_bounds__(256) void maxpool_cl_fwd_kernel(const unsigned shor
                 const unsigned w4[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float v0 = __uint_as_float(w4[q] << 16), v1 = __uint_as_float(w4[q] & 0xFFFF0000u);
+                    const float v0 = H16<F16>::lo(w4[q]), v1 = H16<F16>::hi(w4[q]);
                     // ATen: maxidx starts at the first element of the window, then (val > maxval || isnan(val)) takes over
                     if (code[2 * q] == 255u) code[2 * q] = dy * 3 + dx;
                     if (v0 > m[2 * q] || v0 != v0) { m[2 * q] = v0; code[2 * q] = dy * 3 + dx; }
@@ -308,7 +344,7 @@ __global__ __launch_bounds__(256) void maxpool_cl_fwd_kernel(const unsigned shor
         unsigned pk[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            pk[q] = (__float_as_uint(m[2 * q]) >> 16) | (__float_as_uint(m[2 * q + 1]) & 0xFFFF0000u);     // exact: inputs are bf16
+            pk[q] = H16<F16>::pack(m[2 * q], m[2 * q + 1]);       // exact: the maximum is one of the 16-bit inputs
         *reinterpret_cast<uint4*>(y + (size_t)pix * C + cg * 8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
         *reinterpret_cast<uint2*>(idx + (size_t)pix * C + cg * 8) =
             make_uint2(code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24),
@@ -316,6 +352,7 @@ __global__ __launch_bounds__(256) void maxpool_cl_fwd_kernel(const unsigned shor
     }
 }
 
+template <bool F16>
 __global__ __launch_bounds__(256) void maxpool_cl_bwd_kernel(const unsigned short* __restrict__ dy,
                                                              const unsigned char* __restrict__ idx,
                                                              unsigned short* __restrict__ dx, int B, int H, int W, int C,
@@ -347,7 +384,7 @@ __global__ __launch_bounds__(256) void maxpool_cl_bwd_kernel(const unsigned shor
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const unsigned code = ((k < 4 ? cd.x : cd.y) >> (8 * (k & 3))) & 255u;
-                    const float gv = (k & 1) ? __uint_as_float(gw[k >> 1] & 0xFFFF0000u) : __uint_as_float(gw[k >> 1] << 16);
+                    const float gv = (k & 1) ? H16<F16>::hi(gw[k >> 1]) : H16<F16>::lo(gw[k >> 1]);
                     if (code == pos) acc[k] += gv;
                 }
             }
@@ -355,8 +392,7 @@ __global__ __launch_bounds__(256) void maxpool_cl_bwd_kernel(const unsigned shor
         unsigned pk[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            pk[q] = (unsigned)__bfloat16_as_ushort(__float2bfloat16(acc[2 * q])) |
-                    ((unsigned)__bfloat16_as_ushort(__float2bfloat16(acc[2 * q + 1])) << 16);
+            pk[q] = H16<F16>::pack(acc[2 * q], acc[2 * q + 1]);
         *reinterpret_cast<uint4*>(dx + (size_t)pix * C + cg * 8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
     }
 }
@@ -373,30 +409,40 @@ static int maxpool_cl_check(const void* a, const void* b, const void* c, int B, 
     return 0;
 }
 
-extern "C" int hiast_maxpool3x3s2_nhwc_fwd(const void* x, void* y, uint8_t* idx, int B, int H, int W, int C,
+extern "C" int hiast_maxpool3x3s2_nhwc_fwd(const void* x, void* y, uint8_t* idx, int B, int H, int W, int C, int fmt,
                                            hiast_stream_t stream)
 {
+    if (fmt != HIAST_FMT_BF16 && fmt != HIAST_FMT_FP16) return HIAST_E_RANGE;
     int e = maxpool_cl_check(x, y, idx, B, H, W, C);
     if (e) return e;
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     long long nb = ((long long)B * Ho * Wo * (C / 8) + 255) / 256;
     nb = nb > 16384 ? 16384 : nb;
-    hipLaunchKernelGGL(hiast::maxpool_cl_fwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream,
-                       (const unsigned short*)x, (unsigned short*)y, idx, B, H, W, C, Ho, Wo);
+    if (fmt == HIAST_FMT_FP16)
+        hipLaunchKernelGGL(hiast::maxpool_cl_fwd_kernel<true>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream,
+                           (const unsigned short*)x, (unsigned short*)y, idx, B, H, W, C, Ho, Wo);
+    else
+        hipLaunchKernelGGL(hiast::maxpool_cl_fwd_kernel<false>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream,
+                           (const unsigned short*)x, (unsigned short*)y, idx, B, H, W, C, Ho, Wo);
     HIAST_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int hiast_maxpool3x3s2_nhwc_bwd(const void* dy, const uint8_t* idx, void* dx, int B, int H, int W, int C,
-                                           hiast_stream_t stream)
+                                           int fmt, hiast_stream_t stream)
 {
+    if (fmt != HIAST_FMT_BF16 && fmt != HIAST_FMT_FP16) return HIAST_E_RANGE;
     int e = maxpool_cl_check(dy, dx, idx, B, H, W, C);
     if (e) return e;
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     long long nb = ((long long)B * H * W * (C / 8) + 255) / 256;
     nb = nb > 32768 ? 32768 : nb;
-    hipLaunchKernelGGL(hiast::maxpool_cl_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream,
-                       (const unsigned short*)dy, idx, (unsigned short*)dx, B, H, W, C, Ho, Wo);
+    if (fmt == HIAST_FMT_FP16)
+        hipLaunchKernelGGL(hiast::maxpool_cl_bwd_kernel<true>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream,
+                           (const unsigned short*)dy, idx, (unsigned short*)dx, B, H, W, C, Ho, Wo);
+    else
+        hipLaunchKernelGGL(hiast::maxpool_cl_bwd_kernel<false>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream,
+                           (const unsigned short*)dy, idx, (unsigned short*)dx, B, H, W, C, Ho, Wo);
     HIAST_CHECK_LAUNCH();
     return 0;
 }

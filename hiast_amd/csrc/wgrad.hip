@@ -78,7 +78,8 @@ constexpr int WG_ROWS = 64;                       // pixels per k-step
 constexpr int WG_SUB = WG_ROWS * 256;             // one [64][128] sub-tile: 16 KiB
 constexpr int WG_STAGE = 4 * WG_SUB;              // dY (2 sub-tiles) + X (2 sub-tiles)
 
-template <int TAPS>
+// F16: dY and X rows are IEEE fp16 (HIAST_FMT_FP16) instead of bf16; the kernel never decodes a value, only the MFMA differs
+template <int TAPS, bool F16 = false>
 __global__ __launch_bounds__(512) void wgrad_tn_kernel(const unsigned short* __restrict__ dY,
                                                        const unsigned short* __restrict__ X, float* __restrict__ P,
                                                        int M, int N, int K, WGeo geo, int m_per_split)
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(512) void wgrad_tn_kernel(const unsigned short* __r
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1][a], fb[kk & 1][b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = H16<F16>::mfma32(fa[kk & 1][a], fb[kk & 1][b], acc[a][b]);
         }
     }
 
@@ -307,9 +308,11 @@ extern "C" size_t hiast_conv_wgrad_workspace_bytes(int B, int Ho, int Wo, int Ci
 }
 
 extern "C" int hiast_conv_wgrad_nhwc(const void* dy, const void* x, float* dw, int B, int H, int W, int Cin, int Cout,
-                                     int taps, int stride, int dil, void* workspace, size_t workspace_bytes,
+                                     int taps, int stride, int dil, int fmt, void* workspace, size_t workspace_bytes,
                                      hiast_stream_t stream)
 {
+    if (fmt != HIAST_FMT_BF16 && fmt != HIAST_FMT_FP16) return HIAST_E_RANGE;
+    const bool f16 = fmt == HIAST_FMT_FP16;
     if (!dy || !x || !dw || !workspace) return HIAST_E_ARG;
     if (B <= 0 || H <= 0 || W <= 0 || stride <= 0 || dil <= 0) return HIAST_E_ARG;
     if (Cin % 256 != 0 || Cout % 256 != 0 || (taps != 1 && taps != 9) || (taps == 1 && stride != 1)) return HIAST_E_RANGE;
@@ -326,12 +329,12 @@ extern "C" int hiast_conv_wgrad_nhwc(const void* dy, const void* x, float* dw, i
     hiast::WGeo geo = {H, W, Ho, Wo, stride, dil};
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(tiles, nsplit);
-    if (taps == 1)
-        hipLaunchKernelGGL(hiast::wgrad_tn_kernel<1>, grid, dim3(512), 0, st, (const unsigned short*)dy,
-                           (const unsigned short*)x, (float*)workspace, (int)M, Cout, Cin, geo, mps);
-    else
-        hipLaunchKernelGGL(hiast::wgrad_tn_kernel<9>, grid, dim3(512), 0, st, (const unsigned short*)dy,
-                           (const unsigned short*)x, (float*)workspace, (int)M, Cout, Cin, geo, mps);
+#define WL(T, F)                                                                                                \
+    hipLaunchKernelGGL((hiast::wgrad_tn_kernel<T, F>), grid, dim3(512), 0, st, (const unsigned short*)dy,        \
+                       (const unsigned short*)x, (float*)workspace, (int)M, Cout, Cin, geo, mps)
+    if (taps == 1) { if (f16) WL(1, true); else WL(1, false); }
+    else { if (f16) WL(9, true); else WL(9, false); }
+#undef WL
     HIAST_CHECK_LAUNCH();
     const long long total = (long long)Cout * Cin * taps / 4;           // float4 per thread (Cin % 256 == 0)
     hipLaunchKernelGGL(hiast::wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,

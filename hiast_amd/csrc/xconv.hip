@@ -38,10 +38,6 @@ __device__ __forceinline__ void xc_dma16(__amdgpu_buffer_rsrc_t rs, unsigned cha
 // same image as igemm.hip: 16-byte chunk c of row r of a [rows][128 B] slab tile lives at chunk c ^ ((r >> 1) & 7)
 __device__ __forceinline__ int xc_lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-__device__ __forceinline__ unsigned xc_pack2(float a, float b)
-{
-    return (unsigned)__bfloat16_as_ushort(__float2bfloat16(a)) | ((unsigned)__bfloat16_as_ushort(__float2bfloat16(b)) << 16);
-}
 
 // LDS fragment read as inline asm: the compiler orders every LDS load it knows about behind ALL pending LDS-DMA
 // (s_waitcnt vmcnt(0) in front of the first ds_read after a buffer_load ... lds — it cannot tell the stage being read
@@ -67,7 +63,8 @@ __device__ __forceinline__ int xc_chan(int g, int b, int r) { return (b >> 1) * 
 //   RES     o += R[m][n]                 (GATE: only where bit (n & 7) of Rg[m][n / 8] is set)
 //   RELU    o = max(o, 0)
 //   STATS   per-block sums Σy, Σy² of the STORED (bf16-rounded) values -> stats[stream][N][2]
-template <int KC, bool BN, bool RES, bool RELU, bool GATE, bool STATS>
+// F16: the rows are IEEE fp16 (HIAST_FMT_FP16) instead of bf16 — H16<F16> decodes / encodes / multiplies (common.h)
+template <int KC, bool BN, bool RES, bool RELU, bool GATE, bool STATS, bool F16 = false>
 __global__ __launch_bounds__(512) void xconv_kernel(const unsigned short* __restrict__ X,
                                                     const unsigned short* __restrict__ Wp,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -203,7 +200,7 @@ __global__ __launch_bounds__(512) void xconv_kernel(const unsigned short* __rest
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
                     for (int b = 0; b < 4; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[b][s], xa[s & one][a], acc[a][b], 0, 0, 0);
+                        acc[a][b] = H16<F16>::mfma16(wr[b][s], xa[s & one][a], acc[a][b]);
                 if (s + 1 < KS) {
                     if (!DB) {
                         xa[0][0] = frag(s + 1, 0);
@@ -245,8 +242,8 @@ __global__ __launch_bounds__(512) void xconv_kernel(const unsigned short* __rest
                     const unsigned w0[4] = {r0.x, r0.y, r0.z, r0.w}, w1[4] = {r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        float a0 = __uint_as_float(w0[q] << 16), a1 = __uint_as_float(w0[q] & 0xFFFF0000u);
-                        float b0 = __uint_as_float(w1[q] << 16), b1 = __uint_as_float(w1[q] & 0xFFFF0000u);
+                        float a0 = H16<F16>::lo(w0[q]), a1 = H16<F16>::hi(w0[q]);
+                        float b0 = H16<F16>::lo(w1[q]), b1 = H16<F16>::hi(w1[q]);
                         if (GATE) {
                             a0 = ((gate0 >> (2 * q)) & 1u) ? a0 : 0.f;
                             a1 = ((gate0 >> (2 * q + 1)) & 1u) ? a1 : 0.f;
@@ -264,14 +261,29 @@ __global__ __launch_bounds__(512) void xconv_kernel(const unsigned short* __rest
                     for (int q = 0; q < 16; ++q) o[q] = o[q] > 0.f ? o[q] : 0.f;
                 }
                 unsigned pk[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) pk[q] = xc_pack2(o[2 * q], o[2 * q + 1]);
-                if (STATS && ok) {
+                if (STATS && F16) {
+                    // fp16 statistics variant: pair by pair, each pair finished before the next is converted (the cvt
+                    // temporaries of eight pairs in flight at once pushed this variant 3 registers over the file)
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
-                        const float v0 = __uint_as_float(pk[q] << 16), v1 = __uint_as_float(pk[q] & 0xFFFF0000u);
-                        st1[2 * q] += v0; st2[2 * q] = fmaf(v0, v0, st2[2 * q]);
-                        st1[2 * q + 1] += v1; st2[2 * q + 1] = fmaf(v1, v1, st2[2 * q + 1]);
+                        pk[q] = H16<F16>::pack(o[2 * q], o[2 * q + 1]);
+                        if (ok) {
+                            const float v0 = H16<F16>::lo(pk[q]), v1 = H16<F16>::hi(pk[q]);
+                            st1[2 * q] += v0; st2[2 * q] = fmaf(v0, v0, st2[2 * q]);
+                            st1[2 * q + 1] += v1; st2[2 * q + 1] = fmaf(v1, v1, st2[2 * q + 1]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) pk[q] = H16<F16>::pack(o[2 * q], o[2 * q + 1]);
+                    if (STATS && ok) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const float v0 = H16<F16>::lo(pk[q]), v1 = H16<F16>::hi(pk[q]);
+                            st1[2 * q] += v0; st2[2 * q] = fmaf(v0, v0, st2[2 * q]);
+                            st1[2 * q + 1] += v1; st2[2 * q + 1] = fmaf(v1, v1, st2[2 * q + 1]);
+                        }
                     }
                 }
                 if (ok) {
@@ -337,14 +349,23 @@ int hiast_xconv_stats_rows(int64_t M, int N)
 
 int hiast_xconv_launch(const void* x, const void* wp, const float* gamma, const float* beta, const float* mean,
                        const float* var, float eps, const void* res, int relu, void* y, int64_t M, int K, int N,
-                       float* stats, const void* res_gate, hipStream_t st)
+                       float* stats, const void* res_gate, int f16, hipStream_t st)
 {
     using namespace hiast;
     const dim3 grid((unsigned)xc_blocks(M, N));
 #define XL(BNF, RESF, RELUF, GATEF, STATSF)                                                                          \
-    hipLaunchKernelGGL((xconv_kernel<256, BNF, RESF, RELUF, GATEF, STATSF>), grid, dim3(512), 0, st,                  \
-                       (const unsigned short*)x, (const unsigned short*)wp, gamma, beta, mean, var, eps,              \
-                       (const unsigned short*)res, (const unsigned char*)res_gate, (unsigned short*)y, (int)M, N, stats)
+    do {                                                                                                             \
+        if (f16)                                                                                                     \
+            hipLaunchKernelGGL((xconv_kernel<256, BNF, RESF, RELUF, GATEF, STATSF, true>), grid, dim3(512), 0, st,    \
+                               (const unsigned short*)x, (const unsigned short*)wp, gamma, beta, mean, var, eps,      \
+                               (const unsigned short*)res, (const unsigned char*)res_gate, (unsigned short*)y, (int)M, N, \
+                               stats);                                                                               \
+        else                                                                                                         \
+            hipLaunchKernelGGL((xconv_kernel<256, BNF, RESF, RELUF, GATEF, STATSF>), grid, dim3(512), 0, st,          \
+                               (const unsigned short*)x, (const unsigned short*)wp, gamma, beta, mean, var, eps,      \
+                               (const unsigned short*)res, (const unsigned char*)res_gate, (unsigned short*)y, (int)M, N, \
+                               stats);                                                                               \
+    } while (0)
     const bool bn = mean != nullptr;
     if (stats) { XL(false, false, false, false, true); }
     else if (res_gate) { XL(false, true, false, true, false); }

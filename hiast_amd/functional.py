@@ -11,6 +11,8 @@ import torch
 from . import kernels as K
 
 ASPP_DILATIONS = (6, 12, 18, 24)
+H16 = (torch.bfloat16, torch.float16)       # the two 16-bit types of the mixed-precision path (K.FMT_BF16 / K.FMT_FP16):
+                                            # bf16 = round 1/2's kernels, fp16 = the reference's apex-O1 type
 
 
 class _AsppFn(torch.autograd.Function):
@@ -57,8 +59,8 @@ class _Aspp2Fn(torch.autograd.Function):
     def forward(ctx, x, w0, w1, w2, w3, b0, b1, b2, b3, dil, need_bwd):
         ws = [w.detach().float().contiguous() for w in (w0, w1, w2, w3)]
         bs = [b.detach().float().contiguous() for b in (b0, b1, b2, b3)]
-        if need_bwd and x.dtype != torch.bfloat16:
-            raise TypeError("the channels-last ASPP backward is the bf16 one; fp32 training uses hiast_amd.functional.aspp")
+        if need_bwd and x.dtype not in H16:
+            raise TypeError("the channels-last ASPP backward is the 16-bit one; fp32 training uses hiast_amd.functional.aspp")
         wt, wd, bias = K.aspp2_pack_weights(ws, bs, need_dgrad=need_bwd and ctx.needs_input_grad[0])
         y = K.aspp2_fwd(x, wt, bias, dil)
         ctx.save_for_backward(x, wd)
@@ -321,9 +323,9 @@ class _ConvNhwcFn(torch.autograd.Function):
         if packed is not None and packed[0] is not None and (not need_adj or packed[1] is not None):
             wp, ctx.wpt = packed                   # kernel-format copies kept current by ResNet.prepack (one launch)
         elif need_adj:                             # forward + adjoint (data-gradient) weight in one pack launch
-            wp, ctx.wpt = K.pack_conv_weight(weight, 1, both=True)
+            wp, ctx.wpt = K.pack_conv_weight(weight, K.fmt_of(x), both=True)
         else:
-            wp = K.pack_conv_weight(weight, 1)
+            wp = K.pack_conv_weight(weight, K.fmt_of(x))
         ctx.save_for_backward(x, weight)
         ctx.geo = (stride, dil)
         if want_stats:       # + per-block Σy, Σy² of the stored outputs for the BatchNorm that follows
@@ -339,8 +341,8 @@ class _ConvNhwcFn(torch.autograd.Function):
             return None, None, None, None, None, None, None, None
         x, weight = ctx.saved_tensors
         stride, dil = ctx.geo
-        if dy.dtype != torch.bfloat16:
-            dy = dy.to(torch.bfloat16)
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
         dy = dy.contiguous(memory_format=torch.channels_last)
         k = weight.shape[2]
         pad = dil if k == 3 else 0
@@ -348,7 +350,7 @@ class _ConvNhwcFn(torch.autograd.Function):
         dx = dw = None
         lib_x = need_x and stride != 1
         if need_x and stride == 1:
-            wpt = ctx.wpt if ctx.wpt is not None else K.pack_conv_weight(weight, 1, transpose=True)
+            wpt = ctx.wpt if ctx.wpt is not None else K.pack_conv_weight(weight, K.fmt_of(x), transpose=True)
             gated = ctx.box.pop("gated", None) if ctx.box is not None else None
             if ctx.in_bn is not None and gated is None:
                 bx, sm, si, gamma, beta = ctx.in_bn["bn"]
@@ -379,9 +381,9 @@ class _ConvNhwcFn(torch.autograd.Function):
                 dw = K.conv_wgrad_nhwc(dy.permute(0, 2, 3, 1), x.permute(0, 2, 3, 1), k, stride, dil)
                 need_w = False
             if need_w or lib_x:
-                wl = torch.empty(weight.shape, dtype=torch.bfloat16, device=weight.device)
+                wl = torch.empty(weight.shape, dtype=x.dtype, device=weight.device)
                 if lib_x:
-                    wl = weight.to(torch.bfloat16)
+                    wl = weight.to(x.dtype)
                 gx, gw, _ = torch.ops.aten.convolution_backward(dy, x, wl, None, (stride, stride), (pad, pad), (dil, dil),
                                                                 False, (0, 0), 1, (lib_x, need_w, False))
                 if lib_x:
@@ -571,7 +573,7 @@ def wgrad_stream_join():
 def conv_nhwc_ok(x, conv):
     """the trunk convolutions this path covers: bf16 channels-last input, bias-free 1x1 (stride 1) or 3x3 with
     padding == dilation, channel counts the kernel tiles (multiples of 64)"""
-    if not (x.is_cuda and x.dtype == torch.bfloat16 and _is_cl(x)) or conv.bias is not None or conv.groups != 1:
+    if not (x.is_cuda and x.dtype in H16 and _is_cl(x)) or conv.bias is not None or conv.groups != 1:
         return False
     k = conv.kernel_size
     if k not in ((1, 1), (3, 3)) or conv.stride[0] != conv.stride[1] or conv.in_channels % 64 or conv.out_channels % 64:
@@ -589,22 +591,22 @@ class _MaxPool3x3s2ClFn(torch.autograd.Function):
     def forward(ctx, x):
         y, idx = K.maxpool3x3s2_cl_fwd(x)
         ctx.save_for_backward(idx)
-        ctx.hw = tuple(x.shape[2:])
+        ctx.hw, ctx.dtype = tuple(x.shape[2:]), x.dtype
         ctx.mark_non_differentiable(idx)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         idx, = ctx.saved_tensors
-        if dy.dtype != torch.bfloat16:
-            dy = dy.to(torch.bfloat16)
+        if dy.dtype != ctx.dtype:
+            dy = dy.to(ctx.dtype)
         return K.maxpool3x3s2_cl_bwd(dy.contiguous(memory_format=torch.channels_last), idx, *ctx.hw)
 
 
 def maxpool(x, pool):
     """pool(x) for an nn.MaxPool2d; the stem's 3x3 / stride 2 / padding 1 pooling of a channels-last bf16 device
     activation runs on the K18 kernels (HIAST_LIB_MAXPOOL=1: the library's)"""
-    if (x.is_cuda and x.dtype == torch.bfloat16 and _is_cl(x) and x.shape[1] % 8 == 0
+    if (x.is_cuda and x.dtype in H16 and _is_cl(x) and x.shape[1] % 8 == 0
             and (pool.kernel_size, pool.stride, pool.padding, pool.dilation, pool.ceil_mode) == (3, 2, 1, 1, False)
             and not pool.return_indices and os.environ.get("HIAST_LIB_MAXPOOL", "0") != "1"):
         return _MaxPool3x3s2ClFn.apply(x)
@@ -632,8 +634,9 @@ def conv_nhwc(x, conv, want_stats=False, box=None, in_bn=None):
     """-> y, or (y, partial) with want_stats (see igemm_bn_act); box: identity-branch hand-off of a bottleneck;
     in_bn: statistics hand-off of the BatchNorm whose output x is (bn_act(..., stat_box=in_bn))"""
     w = conv.weight
-    fwd = conv.__dict__.get("_hiast_packed", {}).get(1)
-    adj = conv.__dict__.get("_hiast_packed_adj")
+    fmt = K.fmt_of(x)
+    fwd = conv.__dict__.get("_hiast_packed", {}).get(fmt)
+    adj = conv.__dict__.get("_hiast_packed_adj", {}).get(fmt)
     ok = lambda e: e is not None and e[0] == w._version and e[1] == w.data_ptr()
     packed = (fwd[2] if ok(fwd) else None, adj[2] if ok(adj) else None)
     stride = conv.stride[0]
@@ -656,7 +659,7 @@ def bn_act(x, bn, res=None, relu=True, partial=None, box=None, stat_box=None):
     if training and bn.track_running_stats and bn.num_batches_tracked is not None and not _nbt_batched[0]:
         bn.num_batches_tracked.add_(1)
     momentum = 0.1 if bn.momentum is None else bn.momentum
-    if (training and x.dtype == torch.bfloat16 and _is_cl(x) and not x.is_contiguous()
+    if (training and x.dtype in H16 and _is_cl(x) and not x.is_contiguous()
             and K.bn_nhwc_supported(x.shape[1]) and (res is None or (res.dtype == x.dtype and _is_cl(res)))):
         return _BnActNhwcFn.apply(x, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, momentum, bn.eps, relu,
                                   _sync_world(bn), partial, box, stat_box)

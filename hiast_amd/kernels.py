@@ -324,6 +324,39 @@ def aspp_bwd_weight(x, dy, dil, workspace=None):
     return dws, db
 
 
+# ------------------------------------------------------------------------------- 16-bit operand formats
+# HIAST_FMT_* of include/hiast_hip.h.  On the torch side a bf16-row tensor IS a torch.bfloat16 tensor and an fp16-row
+# tensor a torch.float16 one; split planes are opaque bfloat16 tensors with twice the channels.
+FMT_BF16, FMT_SPLIT_BF16, FMT_FP16 = 1, 2, 3
+_H16 = (torch.bfloat16, torch.float16)
+
+
+def fmt_of(t, planes=1):
+    """operand format of a 16-bit activation / packed-weight tensor (planes = 2: split-bf16 planes)"""
+    if int(planes) == 2:
+        if t.dtype != torch.bfloat16:
+            raise TypeError("split planes are bfloat16 tensors, got %s" % t.dtype)
+        return FMT_SPLIT_BF16
+    if t.dtype == torch.bfloat16:
+        return FMT_BF16
+    if t.dtype == torch.float16:
+        return FMT_FP16
+    raise TypeError("16-bit kernels take bfloat16 or float16 tensors, got %s" % t.dtype)
+
+
+def fmt_dtype(fmt):
+    return torch.float16 if int(fmt) == FMT_FP16 else torch.bfloat16
+
+
+def _req16(t, ndim, name):
+    """HIP tensor, bfloat16 or float16, contiguous"""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.HiastLibraryError("%s must be a CUDA(HIP) tensor: the HIP path has no CPU fallback" % name)
+    if t.dtype not in _H16 or t.dim() != ndim or not t.is_contiguous():
+        raise TypeError("%s must be a contiguous %d-d bfloat16 / float16 tensor (got %s, %s)" % (name, ndim, t.dtype, tuple(t.shape)))
+    return t
+
+
 # ------------------------------------------------------------------------------- K1b ASPP on NHWC (GEMM + shift-add)
 def _nhwc_view(x):
     """logical [B,C,h,w] tensor whose memory is channels-last contiguous -> ([B,h,w,C] contiguous view, dtype code)"""
@@ -337,8 +370,10 @@ def _nhwc_view(x):
     if x.dtype == torch.float32:
         return v, 0
     if x.dtype == torch.bfloat16:
-        return v, 1
-    raise TypeError("aspp_nhwc takes float32 or bfloat16 activations, got %s" % x.dtype)
+        return v, FMT_BF16
+    if x.dtype == torch.float16:
+        return v, FMT_FP16
+    raise TypeError("aspp_nhwc takes float32, bfloat16 or float16 activations, got %s" % x.dtype)
 
 
 def aspp2_pack_weights(weights, biases, need_dgrad=True):
@@ -394,11 +429,11 @@ def aspp2_fwd(x, wt, bias, dil, workspace=None, planes=None):
 
 
 def aspp2_bwd(x, dy, wd, dil, want_dx=True, want_dw=True, workspace=None):
-    """x bf16 channels-last (logical [B,Cin,h,w]); dy [B,Cout,h,w] fp32; wd fp32 [Cin,NP] from aspp2_pack_weights
-    -> (dx bf16 channels-last or None, [dW_i fp32 [Cout,Cin,3,3]] or None, db or None)"""
+    """x bf16 / fp16 channels-last (logical [B,Cin,h,w]); dy [B,Cout,h,w] fp32; wd fp32 [Cin,NP] from aspp2_pack_weights
+    -> (dx like x or None, [dW_i fp32 [Cout,Cin,3,3]] or None, db or None)"""
     xv, dt = _nhwc_view(x)
-    if dt != 1:
-        raise TypeError("aspp2_bwd is the mixed-precision backward: x must be bfloat16")
+    if dt not in (FMT_BF16, FMT_FP16):
+        raise TypeError("aspp2_bwd is the mixed-precision backward: x must be bfloat16 or float16")
     B, h, w, Cin = xv.shape
     _req(dy, torch.float32, 4, "dy")
     Cout = dy.shape[1]
@@ -409,13 +444,13 @@ def aspp2_bwd(x, dy, wd, dil, want_dx=True, want_dw=True, workspace=None):
     if want_dx:
         _req(wd, torch.float32, 2, "wd")
         assert tuple(wd.shape) == (Cin, NP)
-        wdp = pack_conv_weight(wd, 1)
+        wdp = pack_conv_weight(wd, dt)
     ws = workspace if workspace is not None else aspp2_workspace(B, Cin, h, w, Cout, True, x.device)
-    dx = torch.empty((B, h, w, Cin), dtype=torch.bfloat16, device=x.device) if want_dx else None
+    dx = torch.empty((B, h, w, Cin), dtype=x.dtype, device=x.device) if want_dx else None
     dws = [torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=x.device) for _ in range(4)] if want_dw else [None] * 4
     db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_dw else None
     check(lib.hiast_aspp2_bwd(_ptr(xv), _ptr(dy), _ptr(wdp), _ptr(dx),
-                              *[_ptr(t) for t in dws], _ptr(db), B, Cin, h, w, Cout, _dil(dil), _ptr(ws),
+                              *[_ptr(t) for t in dws], _ptr(db), B, Cin, h, w, Cout, _dil(dil), dt, _ptr(ws),
                               ws.numel() * 4, _stream()), "hiast_aspp2_bwd")
     return (dx.permute(0, 3, 1, 2) if want_dx else None), (dws if want_dw else None), db
 
@@ -541,8 +576,18 @@ class AdamPlan:
         self.table = torch.empty(len(numels) * self.REC.itemsize, dtype=torch.uint8, device=device)
 
 
-def adam_step(plan, params, grads, exp_avgs, exp_avg_sqs, lrs, bc1s, bc2_sqrts, beta1, beta2, eps, weight_decay):
-    """one launch over all tensors; p/m/v updated in place"""
+def adam_step(plan, params, grads, exp_avgs, exp_avg_sqs, lrs, bc1s, bc2_sqrts, beta1, beta2, eps, weight_decay,
+              ctl=None, grad_scale=None, found_inf=None):
+    """one launch over all tensors; p/m/v updated in place.  ctl: float32 [8] device control block (hiast_adam_ctl: element
+    0 = applied steps so far): the step count / bias corrections then live on the device (bc1s / bc2_sqrts are ignored),
+    gradients are multiplied by 1 / grad_scale and the whole update is skipped when found_inf != 0 (device scalars of a
+    torch.amp.GradScaler) — no host synchronisation"""
+    if ctl is not None:
+        _req(ctl, torch.float32, 1, "ctl")
+        assert ctl.numel() == 8
+    for t, nm in ((grad_scale, "grad_scale"), (found_inf, "found_inf")):
+        if t is not None and not (t.is_cuda and t.dtype == torch.float32 and t.numel() == 1):
+            raise ValueError("adam_step: %s must be a float32 device scalar" % nm)
     h = plan.host
     for i, (p, g, m, v) in enumerate(zip(params, grads, exp_avgs, exp_avg_sqs)):
         for t, nm in ((p, "param"), (g, "grad"), (m, "exp_avg"), (v, "exp_avg_sq")):
@@ -552,7 +597,8 @@ def adam_step(plan, params, grads, exp_avgs, exp_avg_sqs, lrs, bc1s, bc2_sqrts, 
         h[i] = (p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lrs[i], bc1s[i], bc2_sqrts[i], 0.0)
     h2d_async(h.view(np.uint8).reshape(-1), plan.table.device, out=plan.table)
     check(_lib.load().hiast_adam_step(_ptr(plan.table), _ptr(plan.chunk_tensor), _ptr(plan.chunk_start), plan.n_chunks,
-                                      float(beta1), float(beta2), float(eps), float(weight_decay), _stream()),
+                                      float(beta1), float(beta2), float(eps), float(weight_decay), _ptr(ctl),
+                                      _ptr(grad_scale), _ptr(found_inf), _stream()),
           "hiast_adam_step")
 
 
@@ -653,6 +699,11 @@ def _act_dtype(t):
     raise TypeError("NHWC conv kernels take float32 or bfloat16 activations, got %s" % t.dtype)
 
 
+def _act_dtype16(t):
+    """0 fp32 | 1 bf16 | 2 fp16 (hiast_stem_tail's input code)"""
+    return 2 if t.dtype == torch.float16 else _act_dtype(t)
+
+
 def _bn_params(bn):
     return (_ptr(bn.weight), _ptr(bn.bias), _ptr(bn.running_mean), _ptr(bn.running_var), float(bn.eps))
 
@@ -708,40 +759,42 @@ def bn_act_nhwc_infer(x2d, bn, relu=True):
 
 
 def maxpool3x3s2_cl_fwd(x):
-    """K18: x logical [B,C,H,W] bf16 with channels-last memory -> (y like x at [B,C,Ho,Wo], idx uint8 [B,Ho,Wo,C])"""
-    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.permute(0, 2, 3, 1).is_contiguous()):
-        raise ValueError("maxpool3x3s2_cl: x must be a channels-last bfloat16 HIP tensor [B,C,H,W]")
+    """K18: x logical [B,C,H,W] bf16 / fp16 with channels-last memory -> (y like x at [B,C,Ho,Wo], idx uint8 [B,Ho,Wo,C])"""
+    if not (x.is_cuda and x.dtype in _H16 and x.dim() == 4 and x.permute(0, 2, 3, 1).is_contiguous()):
+        raise ValueError("maxpool3x3s2_cl: x must be a channels-last bfloat16 / float16 HIP tensor [B,C,H,W]")
     B, C, H, W = x.shape
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     y = torch.empty((B, C, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     idx = torch.empty((B, Ho, Wo, C), dtype=torch.uint8, device=x.device)
-    check(_lib.load().hiast_maxpool3x3s2_nhwc_fwd(_ptr(x), _ptr(y), _ptr(idx), B, H, W, C, _stream()),
+    check(_lib.load().hiast_maxpool3x3s2_nhwc_fwd(_ptr(x), _ptr(y), _ptr(idx), B, H, W, C, fmt_of(x), _stream()),
           "hiast_maxpool3x3s2_nhwc_fwd")
     return y, idx
 
 
 def maxpool3x3s2_cl_bwd(dy, idx, H, W):
-    """dy logical [B,C,Ho,Wo] bf16 channels-last, idx from the forward -> dx [B,C,H,W] bf16 channels-last"""
-    if not (dy.is_cuda and dy.dtype == torch.bfloat16 and dy.dim() == 4 and dy.permute(0, 2, 3, 1).is_contiguous()):
-        raise ValueError("maxpool3x3s2_cl: dy must be a channels-last bfloat16 HIP tensor [B,C,Ho,Wo]")
+    """dy logical [B,C,Ho,Wo] bf16 / fp16 channels-last, idx from the forward -> dx [B,C,H,W] like dy, channels-last"""
+    if not (dy.is_cuda and dy.dtype in _H16 and dy.dim() == 4 and dy.permute(0, 2, 3, 1).is_contiguous()):
+        raise ValueError("maxpool3x3s2_cl: dy must be a channels-last bfloat16 / float16 HIP tensor [B,C,Ho,Wo]")
     B, C, Ho, Wo = dy.shape
     assert tuple(idx.shape) == (B, Ho, Wo, C) and idx.dtype == torch.uint8
     dx = torch.empty((B, C, H, W), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
-    check(_lib.load().hiast_maxpool3x3s2_nhwc_bwd(_ptr(dy), _ptr(idx), _ptr(dx), B, H, W, C, _stream()),
+    check(_lib.load().hiast_maxpool3x3s2_nhwc_bwd(_ptr(dy), _ptr(idx), _ptr(dx), B, H, W, C, fmt_of(dy), _stream()),
           "hiast_maxpool3x3s2_nhwc_bwd")
     return dx
 
 
-def stem_tail(x, bn, planes):
+def stem_tail(x, bn, fmt):
     """K9f: bn (eval) -> ReLU -> MaxPool2d(3, 2, 1) of the stem convolution's output in one pass.
-    x: logical [B,C,H,W] with channels-last memory, fp32 or bf16 -> bf16 [B,Ho,Wo,planes*C] (planes = 2: split planes)"""
-    dt = _act_dtype(x)
+    x: logical [B,C,H,W] with channels-last memory, fp32 / bf16 / fp16 -> [B,Ho,Wo,planes*C] in operand format `fmt`
+    (FMT_BF16 | FMT_SPLIT_BF16 | FMT_FP16)"""
+    dt = _act_dtype16(x)
+    fmt = int(fmt)
     B, C, H, W = x.shape
     assert x.permute(0, 2, 3, 1).is_contiguous(), "stem_tail: x must be channels-last"
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-    out = torch.empty((B, Ho, Wo, int(planes) * C), dtype=torch.bfloat16, device=x.device)
+    out = torch.empty((B, Ho, Wo, (2 if fmt == FMT_SPLIT_BF16 else 1) * C), dtype=fmt_dtype(fmt), device=x.device)
     g, b, mu, var, eps = _bn_params(bn)
-    check(_lib.load().hiast_stem_tail(_ptr(x), dt, g, b, mu, var, eps, _ptr(out), int(planes), B, H, W, C, _stream()),
+    check(_lib.load().hiast_stem_tail(_ptr(x), dt, g, b, mu, var, eps, _ptr(out), fmt, B, H, W, C, _stream()),
           "hiast_stem_tail")
     return out
 
@@ -767,10 +820,12 @@ def merge_planes(p):
     return x
 
 
-def pack_conv_weight(weight, planes, transpose=False, both=False):
-    """fp32 conv weight [N,K,kh,kw] (torch layout) -> packed bf16 [N, kh*kw, planes*K]; transpose=True packs the
-    adjoint (data-gradient) convolution's weight [K, kh*kw (flipped), planes*N]; both=True -> (forward, adjoint) in
-    one launch"""
+def pack_conv_weight(weight, fmt, transpose=False, both=False):
+    """fp32 conv weight [N,K,kh,kw] (torch layout) -> packed [N, kh*kw, planes*K] in operand format `fmt` (FMT_BF16 = 1,
+    FMT_SPLIT_BF16 = 2: two bf16 planes, FMT_FP16 = 3); transpose=True packs the adjoint (data-gradient) convolution's
+    weight [K, kh*kw (flipped), planes*N]; both=True -> (forward, adjoint) in one launch"""
+    fmt = int(fmt)
+    planes, h16 = (2 if fmt == FMT_SPLIT_BF16 else 1), fmt_dtype(fmt)
     w = weight.detach()
     if w.dim() == 2:
         w = w.reshape(w.shape[0], w.shape[1], 1, 1)
@@ -779,13 +834,13 @@ def pack_conv_weight(weight, planes, transpose=False, both=False):
     fwd_shape, adj_shape = (N, kh * kw, planes * K_), (K_, kh * kw, planes * N)
     wpt = None
     if both:
-        wp = torch.empty(fwd_shape, dtype=torch.bfloat16, device=w.device)
-        wpt = torch.empty(adj_shape, dtype=torch.bfloat16, device=w.device)
+        wp = torch.empty(fwd_shape, dtype=h16, device=w.device)
+        wpt = torch.empty(adj_shape, dtype=h16, device=w.device)
         mode = 2
     else:
-        wp = torch.empty(adj_shape if transpose else fwd_shape, dtype=torch.bfloat16, device=w.device)
+        wp = torch.empty(adj_shape if transpose else fwd_shape, dtype=h16, device=w.device)
         mode = 1 if transpose else 0
-    check(_lib.load().hiast_pack_conv_weight(_ptr(w), N, K_, kh * kw, planes, mode, _ptr(wp), _ptr(wpt), _stream()),
+    check(_lib.load().hiast_pack_conv_weight(_ptr(w), N, K_, kh * kw, fmt, mode, _ptr(wp), _ptr(wpt), _stream()),
           "hiast_pack_conv_weight")
     return (wp, wpt) if both else wp
 
@@ -797,11 +852,14 @@ class PackPlan:
     REC = np.dtype([("w", np.int64), ("wp", np.int64), ("wpt", np.int64), ("N", np.int32), ("K", np.int32),
                     ("taps", np.int32), ("planes", np.int32), ("mode", np.int32), ("pad", np.int32)])
 
-    def __init__(self, weights, planes, adjoint):
-        """weights: list of fp32 [N,K,kh,kw] parameters; adjoint: list of bool (also keep the data-gradient form)"""
+    def __init__(self, weights, fmt, adjoint):
+        """weights: list of fp32 [N,K,kh,kw] parameters; fmt: operand format (FMT_*); adjoint: list of bool (also keep the
+        data-gradient form)"""
         assert len(weights) > 0 and len(weights) == len(adjoint)
         dev = weights[0].device
-        self.weights, self.planes = list(weights), int(planes)
+        fmt = int(fmt)
+        planes, h16 = (2 if fmt == FMT_SPLIT_BF16 else 1), fmt_dtype(fmt)
+        self.weights, self.fmt = list(weights), fmt
         self.wp, self.wpt = [], []
         host = np.zeros(len(weights), dtype=self.REC)
         lists = {}                     # taps -> ([record index per block], [tile index per block]): one launch per kernel size
@@ -809,11 +867,11 @@ class PackPlan:
             _req(w.detach(), torch.float32, 4, "weight")
             N, K_, kh, kw = w.shape
             taps = kh * kw
-            wp = torch.empty((N, taps, planes * K_), dtype=torch.bfloat16, device=dev)
-            wpt = torch.empty((K_, taps, planes * N), dtype=torch.bfloat16, device=dev) if adj else None
+            wp = torch.empty((N, taps, planes * K_), dtype=h16, device=dev)
+            wpt = torch.empty((K_, taps, planes * N), dtype=h16, device=dev) if adj else None
             self.wp.append(wp)
             self.wpt.append(wpt)
-            host[i] = (w.data_ptr(), wp.data_ptr(), wpt.data_ptr() if adj else 0, N, K_, taps, planes, 2 if adj else 0, 0)
+            host[i] = (w.data_ptr(), wp.data_ptr(), wpt.data_ptr() if adj else 0, N, K_, taps, fmt, 2 if adj else 0, 0)
             if N % 64 or K_ % 64 or taps > 9:
                 raise ValueError("PackPlan: channel counts must be multiples of 64 (got %d x %d)" % (N, K_))
             ct, cs = lists.setdefault(taps, ([], []))
@@ -842,13 +900,14 @@ class PackPlan:
 
 
 def igemm_bn_act(x, wp, planes, bn, res, relu, stride=1, dil=1, out_f32=False, want_stats=False, res_gate=None):
-    """x: bf16 [B,H,W,planes*Cin] (planes = 2 split planes | 1 plain bf16); wp from pack_conv_weight (same planes);
-    bn: BatchNorm2d in eval mode or None (plain GEMM); res: like the output or None
-    -> y bf16 [B,Ho,Wo,planes*Cout], or fp32 [B,Ho,Wo,Cout] if out_f32;
+    """x: [B,H,W,planes*Cin] (planes = 2: split-bf16 planes | 1: plain bf16 or fp16 rows — the tensor's dtype says which);
+    wp from pack_conv_weight (same format); bn: BatchNorm2d in eval mode or None (plain GEMM); res: like the output or None
+    -> y like x [B,Ho,Wo,planes*Cout], or fp32 [B,Ho,Wo,Cout] if out_f32;
     want_stats (planes = 1): -> (y, partial fp32 [rows, Cout, 2]) per-block Σy, Σy² for a following BatchNorm"""
-    _req(x, torch.bfloat16, 4, "x")
-    _req(wp, torch.bfloat16, 3, "wp")
-    PL = int(planes)
+    _req16(x, 4, "x")
+    PL = 2 if int(planes) == 2 else 1
+    fmt = fmt_of(x, PL)
+    _req(wp, x.dtype, 3, "wp")
     B, H, W, CC = x.shape
     Cin = CC // PL
     N, taps, KK = wp.shape
@@ -862,9 +921,9 @@ def igemm_bn_act(x, wp, planes, bn, res, relu, stride=1, dil=1, out_f32=False, w
         y = torch.empty((B, Ho, Wo, N), dtype=torch.float32, device=x.device)
         assert res is None
     else:
-        y = torch.empty((B, Ho, Wo, PL * N), dtype=torch.bfloat16, device=x.device)
+        y = torch.empty((B, Ho, Wo, PL * N), dtype=x.dtype, device=x.device)
     if res is not None:
-        _req(res, torch.bfloat16, 4, "res")
+        _req(res, x.dtype, 4, "res")
         assert tuple(res.shape) == tuple(y.shape)
     gate_mask = 0
     if res_gate is not None:        # residual added only where the gate is open (planes = 1)
@@ -874,7 +933,7 @@ def igemm_bn_act(x, wp, planes, bn, res, relu, stride=1, dil=1, out_f32=False, w
             assert tuple(res_gate.shape) == (B * Ho * Wo, N // 8)
             gate_mask = 1
         else:                                    # values: gate = res_gate > 0
-            _req(res_gate, torch.bfloat16, 4, "res_gate")
+            _req(res_gate, x.dtype, 4, "res_gate")
             assert tuple(res_gate.shape) == tuple(res.shape)
     if bn is not None:
         g, b, mu, var, eps = _bn_params(bn)
@@ -884,10 +943,10 @@ def igemm_bn_act(x, wp, planes, bn, res, relu, stride=1, dil=1, out_f32=False, w
     partial = None
     if want_stats:
         assert PL == 1 and not out_f32
-        rows = _lib.load().hiast_igemm_stats_rows(B * Ho * Wo, Cin, N, taps, PL)     # one row per block of the kernel
+        rows = _lib.load().hiast_igemm_stats_rows(B * Ho * Wo, Cin, N, taps, fmt)    # one row per block of the kernel
         partial = torch.empty((rows, N, 2), dtype=torch.float32, device=x.device)
     check(_lib.load().hiast_igemm_bn_act(_ptr(x), _ptr(wp), g, b, mu, var, eps, _ptr(res), int(bool(relu)), _ptr(y),
-                                         B, H, W, Cin, N, taps, int(stride), int(dil), PL, int(bool(out_f32)),
+                                         B, H, W, Cin, N, taps, int(stride), int(dil), fmt, int(bool(out_f32)),
                                          _ptr(partial), _ptr(res_gate), gate_mask, _stream()), "hiast_igemm_bn_act")
     return (y, partial) if want_stats else y
 
@@ -897,21 +956,21 @@ def igemm_dgrad_bn_stats(dy, wpt, dil, bn_x, gamma, beta, save_mean, save_invstd
     dy bf16 [B,H,W,Cin'], wpt = adjoint packed weight [Cout', taps, Cin'] -> (dA bf16 [B,H,W,Cout'],
     partial fp32 [rows, Cout', 2] = per-block (Σg, Σ g*xhat) of that BatchNorm's backward; bn_nhwc_stats_from_partial
     reduces them to the sums bn_nhwc_bwd_apply takes).  bn_x: bf16 [B,H,W,Cout'] (channels-last rows)."""
-    _req(dy, torch.bfloat16, 4, "dy")
-    _req(wpt, torch.bfloat16, 3, "wpt")
-    _req(bn_x, torch.bfloat16, 4, "bn_x")
+    _req16(dy, 4, "dy")
+    _req(wpt, dy.dtype, 3, "wpt")
+    _req(bn_x, dy.dtype, 4, "bn_x")
     B, H, W, Cin = dy.shape
     N, taps, KK = wpt.shape
     assert KK == Cin and taps in (1, 9) and tuple(bn_x.shape) == (B, H, W, N), (tuple(dy.shape), tuple(wpt.shape), tuple(bn_x.shape))
     _req(save_mean, torch.float32, 1, "save_mean")
     _req(save_invstd, torch.float32, 1, "save_invstd")
     lib = _lib.load()
-    da = torch.empty((B, H, W, N), dtype=torch.bfloat16, device=dy.device)
+    da = torch.empty((B, H, W, N), dtype=dy.dtype, device=dy.device)
     rows = lib.hiast_igemm_dgrad_bn_stats_rows(B * H * W)
     partial = torch.empty((rows, N, 2), dtype=torch.float32, device=dy.device)
     check(lib.hiast_igemm_dgrad_bn_stats(_ptr(dy), _ptr(wpt), _ptr(da), B, H, W, Cin, N, taps, int(dil), _ptr(bn_x),
                                          _ptr(gamma), _ptr(beta), _ptr(save_mean), _ptr(save_invstd), _ptr(partial),
-                                         _stream()), "hiast_igemm_dgrad_bn_stats")
+                                         fmt_of(dy), _stream()), "hiast_igemm_dgrad_bn_stats")
     return da, partial
 
 
@@ -920,8 +979,8 @@ def _bnh_view(t, name):
     """logical [B,C,H,W] bf16 tensor with channels-last memory -> ([M,C] view, M, C)"""
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise _lib.HiastLibraryError("%s must be a CUDA(HIP) tensor: the HIP path has no CPU fallback" % name)
-    if t.dtype != torch.bfloat16 or t.dim() != 4:
-        raise TypeError("%s must be a 4-d bfloat16 tensor" % name)
+    if t.dtype not in _H16 or t.dim() != 4:
+        raise TypeError("%s must be a 4-d bfloat16 / float16 tensor" % name)
     v = t.permute(0, 2, 3, 1)
     if not v.is_contiguous():
         raise ValueError("%s must be channels-last contiguous" % name)
@@ -951,7 +1010,7 @@ def bn_nhwc_stats(x):
     xv, M, C = _bnh_view(x, "x")
     sums = torch.empty((C, 2), dtype=torch.float64, device=x.device)
     ws = _bnh_workspace(C, x.device)
-    check(_lib.load().hiast_bn_nhwc_stats(_ptr(xv), M, C, _ptr(sums), _ptr(ws), ws.numel() * 4, _stream()),
+    check(_lib.load().hiast_bn_nhwc_stats(_ptr(xv), M, C, _ptr(sums), _ptr(ws), ws.numel() * 4, fmt_of(x), _stream()),
           "hiast_bn_nhwc_stats")
     return sums
 
@@ -981,7 +1040,7 @@ def bn_nhwc_apply(x, res, gamma, beta, running_mean, running_var, sums, count, m
     si = torch.empty(C, dtype=torch.float32, device=x.device)
     check(_lib.load().hiast_bn_nhwc_apply(_ptr(xv), _ptr(rv), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(running_mean),
                                           _ptr(running_var), _ptr(sums), float(count), float(momentum), float(eps),
-                                          int(bool(relu)), _ptr(sm), _ptr(si), M, C, _ptr(mask), _stream()),
+                                          int(bool(relu)), _ptr(sm), _ptr(si), M, C, _ptr(mask), fmt_of(x), _stream()),
           "hiast_bn_nhwc_apply")
     return (y, sm, si, mask) if want_mask else (y, sm, si)
 
@@ -1000,7 +1059,7 @@ def bn_nhwc_apply_partial(x, res, gamma, beta, running_mean, running_var, partia
     check(_lib.load().hiast_bn_nhwc_apply_partial(_ptr(xv), _ptr(rv), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(running_mean),
                                                   _ptr(running_var), _ptr(partial), partial.shape[0], float(count),
                                                   float(momentum), float(eps), int(bool(relu)), _ptr(sm), _ptr(si), M, C,
-                                                  _ptr(mask), _stream()), "hiast_bn_nhwc_apply_partial")
+                                                  _ptr(mask), fmt_of(x), _stream()), "hiast_bn_nhwc_apply_partial")
     return (y, sm, si, mask) if want_mask else (y, sm, si)
 
 
@@ -1015,7 +1074,7 @@ def bn_nhwc_bwd_stats(dy, y, x, gamma, beta, save_mean, save_invstd, gate):
     ws = _bnh_workspace(C, x.device)
     check(_lib.load().hiast_bn_nhwc_bwd_stats(_ptr(dv), _ptr(yv), _ptr(xv), _ptr(gamma), _ptr(beta), _ptr(save_mean),
                                               _ptr(save_invstd), int(gate), M, C, _ptr(sums), _ptr(ws), ws.numel() * 4,
-                                              _stream()), "hiast_bn_nhwc_bwd_stats")
+                                              fmt_of(x), _stream()), "hiast_bn_nhwc_bwd_stats")
     return sums
 
 
@@ -1029,7 +1088,7 @@ def bn_nhwc_bwd_apply(dy, y, x, gamma, beta, save_mean, save_invstd, sums, count
     db = torch.empty(C, dtype=torch.float32, device=x.device) if want_dparam else None
     check(_lib.load().hiast_bn_nhwc_bwd_apply(_ptr(dv), _ptr(yv), _ptr(xv), _ptr(gamma), _ptr(beta), _ptr(save_mean),
                                               _ptr(save_invstd), _ptr(sums), float(count), int(gate), _ptr(dx),
-                                              _ptr(dres), _ptr(dg), _ptr(db), M, C, _stream()),
+                                              _ptr(dres), _ptr(dg), _ptr(db), M, C, fmt_of(x), _stream()),
           "hiast_bn_nhwc_bwd_apply")
     return dx, dres, dg, db
 
@@ -1056,9 +1115,9 @@ def conv_wgrad_preferred(Cin, Cout, k, stride):
 
 
 def conv_wgrad_nhwc(dy, x, k, stride, dil):
-    """dy [B,Ho,Wo,Cout], x [B,H,W,Cin] bf16 channels-last rows -> dW fp32 [Cout,Cin,k,k]"""
-    _req(dy, torch.bfloat16, 4, "dy")
-    _req(x, torch.bfloat16, 4, "x")
+    """dy [B,Ho,Wo,Cout], x [B,H,W,Cin] bf16 / fp16 channels-last rows (same type) -> dW fp32 [Cout,Cin,k,k]"""
+    _req16(dy, 4, "dy")
+    _req(x, dy.dtype, 4, "x")
     B, H, W, Cin = x.shape
     Bo, Ho, Wo, Cout = dy.shape
     taps = k * k
@@ -1073,6 +1132,6 @@ def conv_wgrad_nhwc(dy, x, k, stride, dil):
         ws = torch.empty((n + 3) // 4, dtype=torch.float32, device=x.device)
         _wgrad_ws[key] = ws
     dw = torch.empty((Cout, Cin, k, k), dtype=torch.float32, device=x.device)
-    check(lib.hiast_conv_wgrad_nhwc(_ptr(dy), _ptr(x), _ptr(dw), B, H, W, Cin, Cout, taps, int(stride), int(dil), _ptr(ws),
-                                    ws.numel() * 4, _stream()), "hiast_conv_wgrad_nhwc")
+    check(lib.hiast_conv_wgrad_nhwc(_ptr(dy), _ptr(x), _ptr(dw), B, H, W, Cin, Cout, taps, int(stride), int(dil), fmt_of(dy),
+                                    _ptr(ws), ws.numel() * 4, _stream()), "hiast_conv_wgrad_nhwc")
     return dw

@@ -28,7 +28,7 @@ def bn_act(bn, x, res=None, relu=True):
 def conv(m, x):
     """a trunk nn.Conv2d: on channels-last bf16 device activations (the mixed-precision training step) it runs on
     the hand-written implicit-GEMM kernel, otherwise as the plain torch module"""
-    if x.is_cuda and x.dtype == torch.bfloat16 and HF.conv_nhwc_ok(x, m):
+    if x.is_cuda and x.dtype in HF.H16 and HF.conv_nhwc_ok(x, m):
         return HF.conv_nhwc(x, m)
     return m(x)
 
@@ -37,7 +37,7 @@ def conv_bn_act(cv, bn, x, res=None, relu=True, conv_box=None, bn_box=None, in_b
     """relu?(bn(conv(x)) [+ res]).  On the channels-last bf16 training path the convolution's epilogue also
     delivers the per-block sums the BatchNorm needs (one pass over the activation less); stat_box / in_bn: the same for
     the BACKWARD sums — this BatchNorm registers itself in stat_box, the next conv_bn_act gets that dict as in_bn."""
-    if x.is_cuda and x.dtype == torch.bfloat16 and bn.training and HF.conv_nhwc_ok(x, cv):
+    if x.is_cuda and x.dtype in HF.H16 and bn.training and HF.conv_nhwc_ok(x, cv):
         y, partial = HF.conv_nhwc(x, cv, want_stats=True, box=conv_box, in_bn=in_bn)
         return HF.bn_act(y, bn, res, relu, partial=partial, box=bn_box, stat_box=stat_box)
     return bn_act(bn, conv(cv, x), res, relu)
@@ -54,17 +54,17 @@ def _from2d(y2d, B, H, W):
     return y2d.view(B, H, W, y2d.shape[1]).permute(0, 3, 1, 2)
 
 
-def packed_weight(conv, PL):
-    """the conv's weight in the LDS-DMA kernels' operand format (hiast_pack_conv_weight), cached on the module until
-    the parameter is modified (its version counter or storage changes)"""
+def packed_weight(conv, fmt):
+    """the conv's weight in the LDS-DMA kernels' operand format `fmt` (K.FMT_*; hiast_pack_conv_weight), cached on the
+    module until the parameter is modified (its version counter or storage changes)"""
     from hiast_amd import kernels as K
     w = conv.weight
     cache = conv.__dict__.setdefault("_hiast_packed", {})
-    ent = cache.get(PL)
+    ent = cache.get(fmt)
     if ent is not None and ent[0] == w._version and ent[1] == w.data_ptr():
         return ent[2]
-    wp = K.pack_conv_weight(w, PL)
-    cache[PL] = (w._version, w.data_ptr(), wp)
+    wp = K.pack_conv_weight(w, fmt)
+    cache[fmt] = (w._version, w.data_ptr(), wp)
     return wp
 
 
@@ -93,21 +93,22 @@ class Bottleneck(nn.Module):
         o = conv_bn_act(self.conv2, self.bn2, o, in_bn=sb1, stat_box=sb2)
         return conv_bn_act(self.conv3, self.bn3, o, res=idt, bn_box=box, in_bn=sb2)        # += identity, ReLU
 
-    def forward_eval_planes(self, x, PL):
-        """inference on channels-last 16-bit activations [B,H,W,PL*C] (PL = 2: split planes, fp32-class — the
-        pseudo-label forward; PL = 1: bf16 — the teacher forward under autocast): every conv runs as one LDS-DMA
-        implicit-GEMM kernel fused with BN(eval) + (residual) + ReLU (hiast_igemm_bn_act)."""
+    def forward_eval_planes(self, x, fmt):
+        """inference on channels-last 16-bit activations [B,H,W,planes*C] in operand format `fmt` (K.FMT_SPLIT_BF16: split
+        planes, fp32-class — the pseudo-label forward; K.FMT_BF16 / K.FMT_FP16: the teacher forward under autocast): every
+        conv runs as one LDS-DMA implicit-GEMM kernel fused with BN(eval) + (residual) + ReLU (hiast_igemm_bn_act)."""
         from hiast_amd import kernels as K
-        o = K.igemm_bn_act(x, packed_weight(self.conv1, PL), PL, self.bn1, None, True)
-        o = K.igemm_bn_act(o, packed_weight(self.conv2, PL), PL, self.bn2, None, True, self.conv2.stride[0],
+        PL = 2 if fmt == K.FMT_SPLIT_BF16 else 1
+        o = K.igemm_bn_act(x, packed_weight(self.conv1, fmt), PL, self.bn1, None, True)
+        o = K.igemm_bn_act(o, packed_weight(self.conv2, fmt), PL, self.bn2, None, True, self.conv2.stride[0],
                            self.conv2.dilation[0])
         if self.downsample is None:
             idt = x
         else:
             dconv, dbn = self.downsample[0], self.downsample[1]
             xs = x if dconv.stride == (1, 1) else x[:, ::dconv.stride[0], ::dconv.stride[1]].contiguous()
-            idt = K.igemm_bn_act(xs, packed_weight(dconv, PL), PL, dbn, None, False)
-        return K.igemm_bn_act(o, packed_weight(self.conv3, PL), PL, self.bn3, idt, True)
+            idt = K.igemm_bn_act(xs, packed_weight(dconv, fmt), PL, dbn, None, False)
+        return K.igemm_bn_act(o, packed_weight(self.conv3, fmt), PL, self.bn3, idt, True)
 
 
 class ResNet(nn.Module):
@@ -145,7 +146,8 @@ class ResNet(nn.Module):
     def prepack(self, PL, adjoint=False):
         """bring the packed (kernel-format) copies of every bottleneck convolution weight up to date with ONE launch
         (hiast_pack_conv_weight_multi) — they go stale whenever the optimiser or the EMA update has run — and publish
-        them in the per-module caches packed_weight() / conv_nhwc() look at.  adjoint: also the data-gradient forms."""
+        them in the per-module caches packed_weight() / conv_nhwc() look at.  PL: the operand format (K.FMT_BF16 = 1,
+        K.FMT_SPLIT_BF16 = 2, K.FMT_FP16 = 3); adjoint: also the data-gradient forms."""
         from hiast_amd import kernels as K
         plans = self.__dict__.setdefault("_hiast_plans", {})
         ent = plans.get((PL, adjoint))
@@ -167,23 +169,24 @@ class ResNet(nn.Module):
                 w = c.weight
                 c.__dict__.setdefault("_hiast_packed", {})[PL] = (w._version, w.data_ptr(), plan.wp[i])
                 if plan.wpt[i] is not None:
-                    c.__dict__["_hiast_packed_adj"] = (w._version, w.data_ptr(), plan.wpt[i])
+                    c.__dict__.setdefault("_hiast_packed_adj", {})[PL] = (w._version, w.data_ptr(), plan.wpt[i])
             plan.published = True
 
     def fast_eval_planes(self, x):
-        """-> 2 / 1 / 0: inference without autograd on the device runs on the 16-bit channels-last kernels: split
-        planes (fp32-class) for an fp32 forward — the pseudo-label pass —, plain bf16 under bf16 autocast — the
-        teacher forward of the mixed-precision step; 0 = use the module path"""
+        """-> operand format (K.FMT_*) or 0: inference without autograd on the device runs on the 16-bit channels-last
+        kernels: split planes (2, fp32-class) for an fp32 forward — the pseudo-label pass —, plain bf16 (1) / fp16 (3)
+        rows under bf16 / fp16 autocast — the teacher forward of the mixed-precision step; 0 = use the module path"""
         if self.training or not x.is_cuda or torch.is_grad_enabled() or x.dtype != torch.float32:
             return 0
         if os.environ.get("HIAST_NO_FAST_EVAL", "0") == "1":
             return 0
         if not torch.is_autocast_enabled():
             return 2
-        return 1 if torch.get_autocast_dtype("cuda") == torch.bfloat16 else 0
+        amp = torch.get_autocast_dtype("cuda")
+        return 1 if amp == torch.bfloat16 else (3 if amp == torch.float16 else 0)
 
     def forward_eval_planes(self, x, PL):
-        """-> trunk feature as a 16-bit channels-last tensor [B,h,w,PL*2048]"""
+        """PL: operand format (K.FMT_*) -> trunk feature as a 16-bit channels-last tensor [B,h,w,planes*2048]"""
         from hiast_amd import kernels as K
         self.prepack(PL)
         x = x.contiguous(memory_format=torch.channels_last)
@@ -191,7 +194,7 @@ class ResNet(nn.Module):
         o = o.contiguous(memory_format=torch.channels_last)
         mp = self.maxpool
         if ((mp.kernel_size, mp.stride, mp.padding, mp.dilation, mp.ceil_mode) == (3, 2, 1, 1, False)
-                and o.shape[1] % 32 == 0 and o.dtype in (torch.float32, torch.bfloat16)
+                and o.shape[1] % 32 == 0 and o.dtype in (torch.float32, torch.bfloat16, torch.float16)
                 and os.environ.get("HIAST_NO_STEM_TAIL", "0") != "1"):
             # bn1 -> ReLU -> maxpool -> operand format of the trunk kernels in one pass over the stem's output (K9f)
             o = K.stem_tail(o, self.bn1, PL)
@@ -207,7 +210,7 @@ class ResNet(nn.Module):
         if PL == 2:
             o = K.split_planes(o2d.float()).view(B, H, W, 2 * C)
         else:
-            o = o2d.to(torch.bfloat16).view(B, H, W, C)
+            o = o2d.to(K.fmt_dtype(PL)).view(B, H, W, C)
         for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
             for blk in stage:
                 o = blk.forward_eval_planes(o, PL)
@@ -227,11 +230,11 @@ class ResNet(nn.Module):
             PL = self.fast_eval_planes(x)
             if PL:
                 return self.planes_to_feature(self.forward_eval_planes(x, PL), PL)
-        if (x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
+        if (x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") in HF.H16
                 and os.environ.get("HIAST_TRAIN_NCHW", "0") != "1"):
-            # mixed-precision step: the whole trunk runs channels-last (library stem -> bf16 NHWC activations)
+            # mixed-precision step: the whole trunk runs channels-last (library stem -> 16-bit NHWC activations)
             if self.training and torch.is_grad_enabled():
-                self.prepack(1, adjoint=True)
+                self.prepack(3 if torch.get_autocast_dtype("cuda") == torch.float16 else 1, adjoint=True)
             x = x.contiguous(memory_format=torch.channels_last)
             x = self.conv1(x).contiguous(memory_format=torch.channels_last)
         else:

@@ -45,8 +45,8 @@ class ASPP_V2(nn.Module):
         if x.is_cuda:
             ws, bs = self._wb()
             gemm_ok = self.planes_ok()
-            if gemm_ok and x.dtype == torch.bfloat16:
-                # mixed-precision step (teacher / student under autocast): channels-last GEMM + shift-add, bf16 MFMA
+            if gemm_ok and x.dtype in HF.H16:
+                # mixed-precision step (teacher / student under autocast): channels-last GEMM + shift-add, 16-bit MFMA
                 return HF.aspp_nhwc(x.contiguous(memory_format=torch.channels_last), ws, bs, self.dilations)
             if (gemm_ok and x.dtype == torch.float32 and not torch.is_grad_enabled()
                     and x.permute(0, 2, 3, 1).is_contiguous()):

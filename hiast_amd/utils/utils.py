@@ -160,11 +160,36 @@ def update_ema_model(ema_model, model, gamma):
 class FusedAdam(torch.optim.Optimizer):
     """torch.optim.Adam (L2 weight decay, no amsgrad) whose step is ONE HIP launch over every parameter
     (hiast_adam_step) instead of a per-tensor / foreach sequence of elementwise kernels.  Same param_groups /
-    state layout ('step', 'exp_avg', 'exp_avg_sq'), so LR schedulers and checkpoints are interchangeable."""
+    state layout ('step', 'exp_avg', 'exp_avg_sq'), so LR schedulers and checkpoints are interchangeable.
+
+    Dynamic loss scaling (fp16, torch.amp.GradScaler = apex's amp.scale_loss of base_trainer.py:129-131) is handled ON
+    THE DEVICE (`_step_supports_amp_scaling`): scaler.step(opt) hands over its device scalars `grad_scale` / `found_inf`;
+    the kernel unscales the gradients and skips the whole update — moments and step count included — on an overflow.
+    The stock path (`scaler.unscale_` + `if not found_inf.item(): opt.step()`) waits for the device once per iteration."""
+    _step_supports_amp_scaling = True
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._plan = None
+        self._ctl = {}          # hyper-parameter key -> device control block (element 0: number of APPLIED steps)
+
+    def applied_steps(self):
+        """number of updates actually applied (overflow steps excluded); reads the device counter (synchronises)"""
+        return max([int(c[0].item()) for c in self._ctl.values()], default=0)
+
+    def state_dict(self):
+        # the step count lives on the device (skipped steps are decided there): bring the per-parameter 'step' entries
+        # of torch's layout up to date before they are saved
+        if self._ctl:
+            n = float(self.applied_steps())
+            for st in self.state.values():
+                if "step" in st:
+                    st["step"] = torch.tensor(n)
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._ctl = {}          # re-created from the loaded 'step' entries at the next step
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -173,6 +198,7 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        grad_scale, found_inf = getattr(self, "grad_scale", None), getattr(self, "found_inf", None)
         by_hyper = {}
         for group in self.param_groups:
             key = (group["betas"], group["eps"], group["weight_decay"])
@@ -184,21 +210,27 @@ class FusedAdam(torch.optim.Optimizer):
                     st["step"] = torch.tensor(0.0)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] += 1
                 by_hyper.setdefault(key, []).append((p, group["lr"], st))
-        for (betas, eps, wd), items in by_hyper.items():
+        for key, items in by_hyper.items():
+            betas, eps, wd = key
             ps = [p for p, _, _ in items]
-            t = [float(st["step"]) for _, _, st in items]
+            ctl = self._ctl.get(key)
+            if ctl is None:     # applied steps so far: 0, or what a loaded checkpoint says
+                ctl = torch.zeros(8, dtype=torch.float32)
+                ctl[0] = max(float(st["step"]) for _, _, st in items)
+                ctl = self._ctl[key] = ctl.to(ps[0].device)
+            for _, _, st in items:
+                st["step"] += 1     # (host copy: attempted steps; state_dict() replaces it by the device's applied count)
             plan = self._plan.get(len(ps)) if isinstance(self._plan, dict) else None
             numels = tuple(p.numel() for p in ps)
             if plan is None or plan.numels != numels:
                 plan = K.AdamPlan(numels, ps[0].device)
                 self._plan = dict(self._plan or {})
                 self._plan[len(ps)] = plan
+            one = [1.0] * len(ps)       # bias corrections: computed on the device from the applied-step count
             K.adam_step(plan, [p.data for p in ps], [p.grad.contiguous() for p in ps], [st["exp_avg"] for _, _, st in items],
-                        [st["exp_avg_sq"] for _, _, st in items], [lr for _, lr, _ in items],
-                        [1.0 - betas[0] ** k for k in t], [(1.0 - betas[1] ** k) ** 0.5 for k in t], betas[0], betas[1],
-                        eps, wd)
+                        [st["exp_avg_sq"] for _, _, st in items], [lr for _, lr, _ in items], one, one, betas[0], betas[1],
+                        eps, wd, ctl=ctl, grad_scale=grad_scale, found_inf=found_inf)
             # raw-pointer writes do not move Parameter._version by themselves; the packed-weight caches key on it
             torch.autograd.graph.increment_version(ps)
         return loss

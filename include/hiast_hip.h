@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HIAST_ABI_VERSION 1
+#define HIAST_ABI_VERSION 2
 
 #define HIAST_E_ARG   (-1) /* null pointer / non-positive extent */
 #define HIAST_E_RANGE (-2) /* extent outside what the kernels are built for */
@@ -40,6 +40,15 @@ extern "C" {
 /* Σ max-prob is accumulated exactly as an integer: prob * 2^30 (prob >= 2^-7). */
 #define HIAST_PROB_FX_SHIFT 30
 #define HIAST_MAX_CLASSES 32
+/* Operand formats of the 16-bit channels-last kernels (K9c-K9e, K10b, K1b, K18; the `fmt` arguments below):
+ *   HIAST_FMT_BF16        rows of bf16 values (slab = 64 channels)
+ *   HIAST_FMT_SPLIT_BF16  fp32-class values as bf16 hi|lo planes (slab = 32 channels; inference only)
+ *   HIAST_FMT_FP16        rows of IEEE fp16 values — the type the reference trains in under apex O1
+ *                         (code/utils/default_config.py:109, code/utils/utils.py:126-132)
+ * bf16 and fp16 rows share every layout and kernel structure; the matrix cores run both at the same rate. */
+#define HIAST_FMT_BF16 1
+#define HIAST_FMT_SPLIT_BF16 2
+#define HIAST_FMT_FP16 3
 #define HIAST_IGNORE 255
 
 typedef void* hiast_stream_t;
@@ -181,6 +190,7 @@ int hiast_aspp2_fwd(const void* x_nhwc, int dtype, const void* wt, const float* 
                     hiast_stream_t stream);
 int hiast_aspp2_bwd(const void* x_nhwc, const float* dy, const void* wd, void* dx_nhwc, float* dw0, float* dw1,
                     float* dw2, float* dw3, float* db, int B, int Cin, int h, int w, int Cout, const int* dil,
+                    int fmt /* HIAST_FMT_BF16 | HIAST_FMT_FP16: type of x, dx (and of the gathered dY) */,
                     void* workspace, size_t workspace_bytes, hiast_stream_t stream);
 
 /* ---- K10: BatchNorm2d (+ residual) (+ ReLU), fused ----------------------------------------
@@ -259,11 +269,12 @@ int hiast_bn_act_nhwc_infer(const void* x, void* y, const float* gamma, const fl
  * res_gate is the [M][Cout/8] bit mask written by hiast_bn_nhwc_apply instead of a tensor of values. */
 int hiast_igemm_bn_act(const void* x, const void* wp, const float* gamma, const float* beta, const float* mean,
                        const float* var, float eps, const void* res, int relu, void* y, int B, int H, int W, int Cin,
-                       int Cout, int taps, int stride, int dil, int planes, int out_f32, float* stats,
+                       int Cout, int taps, int stride, int dil, int fmt /* HIAST_FMT_*: "planes" above = 2 for SPLIT_BF16, 1 otherwise;
+                       FP16: everything said of planes = 1 with fp16 rows */, int out_f32, float* stats,
                        const void* res_gate, int gate_mask, hiast_stream_t stream);
 /* host: number of partial-sum rows hiast_igemm_bn_act writes into `stats` [rows][Cout][2] for M = B*Ho*Wo output pixels
  * (one row per block of the kernel chosen for the shape) */
-int hiast_igemm_stats_rows(int64_t M, int Cin, int Cout, int taps, int planes);
+int hiast_igemm_stats_rows(int64_t M, int Cin, int Cout, int taps, int fmt);
 /* Data gradient of a stride-1 trunk convolution, dA = conv(dy, adjoint weight) (wpt: hiast_pack_conv_weight with
  * transpose; Cin = channels of dy, Cout = channels of dA; bf16 channels-last rows), for the case that A = relu(bn(x)):
  * the epilogue also emits the per-block sums of that BatchNorm's backward pass, partial[rows][Cout][2] = (Σg, Σ g*xhat)
@@ -274,9 +285,10 @@ int hiast_igemm_stats_rows(int64_t M, int Cin, int Cout, int taps, int planes);
  * data gradient + ATen batch_norm_backward reduce, each a pass of its own). */
 int hiast_igemm_dgrad_bn_stats(const void* dy, const void* wpt, void* da, int B, int H, int W, int Cin, int Cout, int taps,
                                int dil, const void* bn_x, const float* gamma, const float* beta, const float* save_mean,
-                               const float* save_invstd, float* partial, hiast_stream_t stream);
+                               const float* save_invstd, float* partial, int fmt /* HIAST_FMT_BF16 | HIAST_FMT_FP16 */,
+                               hiast_stream_t stream);
 int hiast_igemm_dgrad_bn_stats_rows(int64_t M);
-int hiast_pack_conv_weight(const float* w, int N, int K, int taps, int planes, int transpose, void* wp, void* wpt,
+int hiast_pack_conv_weight(const float* w, int N, int K, int taps, int fmt, int transpose, void* wp, void* wpt,
                            hiast_stream_t stream);
 int hiast_split_planes(float* x, void* planes, int64_t M, int C, int inverse, hiast_stream_t stream);
 /* K9f hiast_stem_tail: bn1 (eval) -> ReLU -> MaxPool2d(3, stride 2, padding 1) of the stem convolution's output
@@ -284,14 +296,15 @@ int hiast_split_planes(float* x, void* planes, int64_t M, int C, int inverse, hi
  * operand format of the trunk kernels.  x: channels-last [B,H,W,C] fp32 (dtype 0) or bf16 (dtype 1; the ReLU output is
  * rounded to bf16 before the maximum, as a bf16 module path does); out: planes = 2: split planes [B,Ho,Wo,2*C] (C % 32 == 0),
  * planes = 1: bf16 [B,Ho,Wo,C]; Ho = (H-1)/2+1, Wo = (W-1)/2+1; C % 8 == 0; gamma / beta may be NULL (1 / 0). */
-int hiast_stem_tail(const void* x, int dtype, const float* gamma, const float* beta, const float* mean, const float* var,
-                    float eps, void* out, int planes, int B, int H, int W, int C, hiast_stream_t stream);
+int hiast_stem_tail(const void* x, int dtype /* 0 fp32 | 1 bf16 | 2 fp16 */, const float* gamma, const float* beta,
+                    const float* mean, const float* var, float eps, void* out, int fmt /* HIAST_FMT_* of out */, int B, int H,
+                    int W, int C, hiast_stream_t stream);
 /* hiast_pack_conv_weight for a list of weights in ONE launch (a trunk's 104 convolutions after every optimiser / EMA
  * update).  table: device array of records (mode = the `transpose` argument above; N, K multiples of 64, taps <= 9);
  * one block per 64 x 64 (n, k) tile of one weight: chunk_tensor[b] = record index, chunk_start[b] = index of the tile
  * within that weight, row-major over (N/64, K/64).  max_taps >= the largest `taps` of the records a block of this launch
  * may meet (sizes the LDS tile: list the 1x1 and the 3x3 weights in separate launches to keep the 1x1 blocks small). */
-typedef struct { const float* w; void* wp; void* wpt; int32_t N, K, taps, planes, mode, pad; } hiast_pack_rec;
+typedef struct { const float* w; void* wp; void* wpt; int32_t N, K, taps, planes /* = HIAST_FMT_* */, mode, pad; } hiast_pack_rec;
 int hiast_pack_conv_weight_multi(const hiast_pack_rec* table, const int32_t* chunk_tensor, const int64_t* chunk_start,
                                  int n_chunks, int max_taps, hiast_stream_t stream);
 
@@ -303,7 +316,8 @@ int hiast_pack_conv_weight_multi(const hiast_pack_rec* table, const int32_t* chu
  * a fixed order (bitwise reproducible).  workspace: hiast_conv_wgrad_workspace_bytes(...) (0 = unsupported shape). */
 size_t hiast_conv_wgrad_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout, int taps);
 int hiast_conv_wgrad_nhwc(const void* dy, const void* x, float* dw, int B, int H, int W, int Cin, int Cout, int taps,
-                          int stride, int dil, void* workspace, size_t workspace_bytes, hiast_stream_t stream);
+                          int stride, int dil, int fmt /* HIAST_FMT_BF16 | HIAST_FMT_FP16: type of dy and x */,
+                          void* workspace, size_t workspace_bytes, hiast_stream_t stream);
 
 /* ---- K10b: BatchNorm2d (+ residual) (+ ReLU), TRAINING mode, on channels-last bf16 activations [M = B*H*W][C] ------
  * Same arithmetic and passes as K10 (resnet.py:78-98 in train(): batch statistics even with frozen affine
@@ -311,17 +325,18 @@ int hiast_conv_wgrad_nhwc(const void* dy, const void* x, float* dw, int B, int H
  * C a power of two in [8, 2048].  sums [C][2] double: (Σx, Σx²) forward, (Σg, Σ g*xhat) backward — all-reduce them
  * across ranks between the stats and the apply call for SyncBN.  workspace: hiast_bn_nhwc_workspace_bytes(C). */
 size_t hiast_bn_nhwc_workspace_bytes(int C);
-int hiast_bn_nhwc_stats(const void* x, int64_t M, int C, double* sums, void* workspace, size_t workspace_bytes,
+/* fmt (every call below): HIAST_FMT_BF16 | HIAST_FMT_FP16, the type of the activation tensors x, res, y, dy, dx, dres */
+int hiast_bn_nhwc_stats(const void* x, int64_t M, int C, double* sums, void* workspace, size_t workspace_bytes, int fmt,
                         hiast_stream_t stream);
 int hiast_bn_nhwc_stats_from_partial(const float* partial, int nblk, int C, double* sums, hiast_stream_t stream);
 /* single-rank forward straight from the per-block partial sums (no all-reduce point): statistics + apply */
 int hiast_bn_nhwc_apply_partial(const void* x, const void* res, void* y, const float* gamma, const float* beta,
                                 float* running_mean, float* running_var, const float* partial, int nblk, double count,
                                 float momentum, float eps, int relu, float* save_mean, float* save_invstd, int64_t M,
-                                int C, void* mask, hiast_stream_t stream);
+                                int C, void* mask, int fmt, hiast_stream_t stream);
 int hiast_bn_nhwc_apply(const void* x, const void* res, void* y, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, const double* sums, double count, float momentum,
-                        float eps, int relu, float* save_mean, float* save_invstd, int64_t M, int C, void* mask,
+                        float eps, int relu, float* save_mean, float* save_invstd, int64_t M, int C, void* mask, int fmt,
                         hiast_stream_t stream);
 /* apply: mask (may be NULL) receives the bits y > 0, [M][C/8] bytes (bit k of byte (m, g) = channel 8g + k).
  * relu of the backward calls: 0 = no ReLU in the forward, 1 = gate y > 0 read from y, 2 = gate recomputed as
@@ -329,10 +344,11 @@ int hiast_bn_nhwc_apply(const void* x, const void* res, void* y, const float* ga
  * bit mask written by the forward (1/16 of y's bytes) */
 int hiast_bn_nhwc_bwd_stats(const void* dy, const void* y, const void* x, const float* gamma, const float* beta,
                             const float* save_mean, const float* save_invstd, int relu, int64_t M, int C, double* sums,
-                            void* workspace, size_t workspace_bytes, hiast_stream_t stream);
+                            void* workspace, size_t workspace_bytes, int fmt, hiast_stream_t stream);
 int hiast_bn_nhwc_bwd_apply(const void* dy, const void* y, const void* x, const float* gamma, const float* beta,
                             const float* save_mean, const float* save_invstd, const double* sums, double count, int relu,
-                            void* dx, void* dres, float* dgamma, float* dbeta, int64_t M, int C, hiast_stream_t stream);
+                            void* dx, void* dres, float* dgamma, float* dbeta, int64_t M, int C, int fmt,
+                            hiast_stream_t stream);
 
 /* ---- K11: EMA teacher update ---------------------------------------------------------
  * utils/utils.py:115-123 update_ema_model: ema = ema*gamma + p*(1-gamma) over a list of
@@ -351,8 +367,9 @@ int hiast_ema_update(const hiast_ema_rec* table, const int32_t* chunk_tensor,
  * idx: one byte per output element, the position 3*dy + dx of the maximum inside its window (ATen keeps an int64 flat
  * index: 8x the bytes); first maximum in row-major window order, a NaN takes over, as ATen.  The backward gathers, for
  * every input pixel, the gradients of the <= 4 windows whose maximum it is (fp32 sum, one rounding). */
-int hiast_maxpool3x3s2_nhwc_fwd(const void* x, void* y, uint8_t* idx, int B, int H, int W, int C, hiast_stream_t stream);
-int hiast_maxpool3x3s2_nhwc_bwd(const void* dy, const uint8_t* idx, void* dx, int B, int H, int W, int C,
+int hiast_maxpool3x3s2_nhwc_fwd(const void* x, void* y, uint8_t* idx, int B, int H, int W, int C,
+                                int fmt /* HIAST_FMT_BF16 | HIAST_FMT_FP16 */, hiast_stream_t stream);
+int hiast_maxpool3x3s2_nhwc_bwd(const void* dy, const uint8_t* idx, void* dx, int B, int H, int W, int C, int fmt,
                                 hiast_stream_t stream);
 
 /* ---- K14: ToTensor + Normalize on the device ------------------------------------------------------
@@ -374,8 +391,16 @@ int hiast_multi_copy(const hiast_copy_rec* table, int n_tensors, hiast_stream_t 
  * table: device array of records {p, g, m (exp_avg), v (exp_avg_sq), n, lr, bc1 = 1-b1^t, bc2_sqrt = sqrt(1-b2^t)};
  * chunk tables as for K11. */
 typedef struct { float* p; const float* g; float* m; float* v; int64_t n; float lr; float bc1; float bc2_sqrt; float pad; } hiast_adam_rec;
+/* ctl (may be NULL): device control block for mixed precision with dynamic loss scaling (apex amp.scale_loss /
+ * torch GradScaler, base_trainer.py:129-131): a one-thread kernel ahead of the update reads the scaler's device scalars
+ * grad_scale (may be NULL = 1) and found_inf (may be NULL = 0), and writes skip / 1/scale / the number of APPLIED steps
+ * and its bias corrections; the update multiplies every gradient by 1/scale and is skipped entirely (no moment update,
+ * no step count) when found_inf != 0 — without the host ever reading found_inf.  With ctl the records' bc1 / bc2_sqrt
+ * are ignored (the count lives in ctl->step; zero it once when the optimiser is created). */
+typedef struct { float step; float skip; float inv_scale; float bc1; float bc2_sqrt; float pad[3]; } hiast_adam_ctl;
 int hiast_adam_step(const hiast_adam_rec* table, const int32_t* chunk_tensor, const int64_t* chunk_start,
-                    int n_chunks, double beta1, double beta2, float eps, float weight_decay, hiast_stream_t stream);
+                    int n_chunks, double beta1, double beta2, float eps, float weight_decay, hiast_adam_ctl* ctl,
+                    const float* grad_scale, const float* found_inf, hiast_stream_t stream);
 
 /* ---- K15: discriminator input map (adversarial warm-up stage) -----------------------------
  * sseg/models/segmentors/adversarial_warmup_segmentor.py: F.interpolate(logits, size, bilinear,
