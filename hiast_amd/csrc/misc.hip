@@ -232,63 +232,6 @@ extern "C" int hiast_adam_step(const hiast_adam_rec* table, const int32_t* chunk
     return 0;
 }
 
-namespace hiast {
-struct HardSet {
-    uint32_t w[8];        // bit c set: class c is pasted
-};
-// K17: CopyPaste.run_original's composite (sseg/datasets/preprocessor.py:101-112) on device-resident uint8 frames:
-//   sel = hard[lbl_src];  img[sel] = img_src[sel];  lbl[sel] = lbl_src[sel];  mask = sel ? lbl_src : 255
-// four pixels per thread: one 4-byte label word, three 4-byte colour words of each frame
-__global__ __launch_bounds__(256) void copy_paste_kernel(uint32_t* __restrict__ img, uint32_t* __restrict__ lbl,
-                                                         uint32_t* __restrict__ mask, const uint32_t* __restrict__ img_src,
-                                                         const uint32_t* __restrict__ lbl_src, HardSet hs, long long nquad)
-{
-    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < nquad; q += (long long)gridDim.x * 256) {
-        const uint32_t ls = lbl_src[q];
-        uint32_t selb = 0;                    // 0xFF in byte i where pixel i is pasted
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t c = (ls >> (8 * i)) & 0xFFu;
-            if ((hs.w[c >> 5] >> (c & 31)) & 1u) selb |= 0xFFu << (8 * i);
-        }
-        mask[q] = (ls & selb) | (~selb);      // 255 where nothing is pasted
-        if (selb == 0) continue;
-        lbl[q] = (lbl[q] & ~selb) | (ls & selb);
-        // 12 colour bytes: byte j belongs to pixel j / 3
-        uint32_t m3[3] = {0, 0, 0};
-#pragma unroll
-        for (int j = 0; j < 12; ++j)
-            if ((selb >> (8 * (j / 3))) & 1u) m3[j >> 2] |= 0xFFu << (8 * (j & 3));
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            if (m3[k] == 0) continue;
-            const long long o = 3 * q + k;
-            img[o] = (img[o] & ~m3[k]) | (img_src[o] & m3[k]);
-        }
-    }
-}
-}  // namespace hiast
-
-extern "C" int hiast_copy_paste_u8(uint8_t* img, uint8_t* lbl, uint8_t* mask, const uint8_t* img_src,
-                                   const uint8_t* lbl_src, const uint8_t* hard_classes, int n_hard, int64_t npix,
-                                   hiast_stream_t stream)
-{
-    if (!img || !lbl || !mask || !img_src || !lbl_src || (!hard_classes && n_hard > 0)) return HIAST_E_ARG;
-    if (npix <= 0 || n_hard < 0) return HIAST_E_ARG;
-    if (npix % 4 != 0 || n_hard > 256) return HIAST_E_RANGE;
-    if ((((uintptr_t)img) | ((uintptr_t)lbl) | ((uintptr_t)mask) | ((uintptr_t)img_src) | ((uintptr_t)lbl_src)) & 3)
-        return HIAST_E_RANGE;
-    hiast::HardSet hs = {{0, 0, 0, 0, 0, 0, 0, 0}};
-    for (int i = 0; i < n_hard; ++i) hs.w[hard_classes[i] >> 5] |= 1u << (hard_classes[i] & 31);     // host array
-    const long long nquad = npix / 4;
-    long long nb = (nquad + 255) / 256;
-    nb = nb > 4096 ? 4096 : nb;
-    hipLaunchKernelGGL(hiast::copy_paste_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (uint32_t*)img,
-                       (uint32_t*)lbl, (uint32_t*)mask, (const uint32_t*)img_src, (const uint32_t*)lbl_src, hs, nquad);
-    HIAST_CHECK_LAUNCH();
-    return 0;
-}
-
 extern "C" int hiast_multi_copy(const hiast_copy_rec* table, int n_tensors, hiast_stream_t stream)
 {
     if (!table) return HIAST_E_ARG;

@@ -510,22 +510,6 @@ def normalize_u8(img_u8, mean, std):
     return out
 
 
-def copy_paste_u8(img, lbl, img_src, lbl_src, hard_classes):
-    """CopyPaste composite on the device (hiast_copy_paste_u8): img [..,H,W,3] / lbl [..,H,W] uint8 are updated in place
-    from img_src / lbl_src wherever lbl_src is one of `hard_classes`; -> mask uint8 like lbl (pasted label | 255)"""
-    for t, nm in ((img, "img"), (lbl, "lbl"), (img_src, "img_src"), (lbl_src, "lbl_src")):
-        _req(t, torch.uint8, None, nm)
-    if img.shape != img_src.shape or lbl.shape != lbl_src.shape or tuple(img.shape) != tuple(lbl.shape) + (3,):
-        raise ValueError("copy_paste_u8: img [..,H,W,3] and lbl [..,H,W] must match their sources")
-    hard = np.ascontiguousarray(np.asarray(hard_classes, dtype=np.uint8))
-    mask = torch.empty_like(lbl)
-    if lbl.numel():
-        check(_lib.load().hiast_copy_paste_u8(_ptr(img), _ptr(lbl), _ptr(mask), _ptr(img_src), _ptr(lbl_src),
-                                              hard.ctypes.data_as(ctypes.c_void_p), int(hard.size), lbl.numel(),
-                                              _stream()), "hiast_copy_paste_u8")
-    return mask
-
-
 class CopyPlan:
     """device table for copying a fixed list of (small) tensors in one launch"""
 

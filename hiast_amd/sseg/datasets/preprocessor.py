@@ -74,24 +74,6 @@ class CopyPaste:
                 return c
         return np.random.choice(usable, p=p_usable / p_usable.sum())
 
-    def run_device(self, img, lbl):
-        """run_original for device-resident frames (uint8 torch tensors [H,W,3] / [H,W] on the HIP device, updated in
-        place): the class / source-image draws are the host ones (same np.random sequence), the composite is one kernel
-        (hiast_copy_paste_u8).  -> (img, lbl, copy_paste_mask)"""
-        import torch
-        from hiast_amd import kernels as K
-        c = self.random_select(self.hard_classes)
-        if c is None:
-            return img, lbl, torch.full_like(lbl, 255)
-        name = np.random.choice(self.samples_with_class[c])
-        img_, lbl_, _ = self.dataset_copy_from.load_data(self.dataset_copy_from.get_file_to_idx(name))
-        if tuple(img.shape) != img_.shape:
-            img_, lbl_ = self.resize(img_, lbl_, tuple(lbl.shape))
-        src_i = torch.from_numpy(np.ascontiguousarray(img_)).to(img.device, non_blocking=True)
-        src_l = torch.from_numpy(np.ascontiguousarray(lbl_)).to(img.device, non_blocking=True)
-        mask = K.copy_paste_u8(img, lbl, src_i, src_l, self.hard_classes)
-        return img, lbl, mask
-
     def run_original(self, img, lbl):
         """Returns (img, lbl, copy_paste_mask).  The reference's retry loop (up to 3 source images)
         always ends after the first paste, because the first pass marks every hard class as

@@ -420,15 +420,6 @@ int hiast_confusion_hist(const int64_t* pred, const int64_t* target, int64_t N, 
                          int64_t* inter, int64_t* area_pred, int64_t* area_tgt,
                          hiast_stream_t stream);
 
-/* ---- K17: hard-aware CopyPaste composite on device-resident frames ----------------------------------------------
- * CopyPaste.run_original, sseg/datasets/preprocessor.py:101-112:
- *   mask = U_{c in hard} (lbl_src == c);  img[mask] = img_src[mask];  lbl[mask] = lbl_src[mask]
- * img / img_src uint8 [npix,3] (HWC as decoded), lbl / lbl_src uint8 [npix]; img and lbl are updated IN PLACE;
- * mask uint8 [npix] out: the pasted label where a pixel was pasted, 255 elsewhere (the reference's copy_paste_mask).
- * hard_classes: HOST array of n_hard class ids.  npix % 4 == 0 (several frames may be stacked). */
-int hiast_copy_paste_u8(uint8_t* img, uint8_t* lbl, uint8_t* mask, const uint8_t* img_src, const uint8_t* lbl_src,
-                        const uint8_t* hard_classes, int n_hard, int64_t npix, hiast_stream_t stream);
-
 #ifdef __cplusplus
 }
 #endif

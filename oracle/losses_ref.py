@@ -56,3 +56,45 @@ def st_losses(logits_lr, teacher_lr, plbl, size, region="ignored", w_t=1.0, w_k=
         "ent_ignored_loss": w_e * s["ent"] / (C * s["n_ign"]),
         "cst_loss": w_c * s["cst"] / s["cst_cnt"],
     }
+
+
+def registry_loss(kind, logits, labels, weights=None, ignore_index=255, refer_labels=None, region="confident"):
+    """LOSS[kind](logits, labels, weights, ignore_index, refer_labels, region) of the reference on the FULL argument
+    surface (sseg/models/modules/losses.py:10-41 registry entries, :44-65 SoftCELoss, :68-72 compute_loss,
+    :75-89 compute_loss_by_selected_pixel).  Pinned by tests/golden/loss_registry.npz.
+
+    refer_labels is None -> the criterion's own mean (CE: over labels != ignore_index, weighted mean with `weights`;
+    SoftCE: sum / numel; MSE / KLDIV: element mean).  Otherwise the per-element loss tensor is multiplied by the
+    region mask [B,1,H,W] — for CE the per-pixel tensor is [B,H,W], so the product BROADCASTS to [B,B,H,W]
+    (out[i,j] = loss[j] * mask[i], :86-87) — and the sum is divided by the number of non-zero elements (:89).
+    SoftCE scales the target by the class weights first (:57-59; the reference does so IN PLACE)."""
+    if kind == "CE":
+        if refer_labels is None:
+            return F.cross_entropy(logits, labels, weight=weights, ignore_index=ignore_index)
+        t = F.cross_entropy(logits, labels, weight=weights, reduction="none")            # [B,H,W]
+    elif kind == "SoftCE":
+        q = labels if weights is None else labels * weights.view(1, -1, 1, 1).to(labels.dtype)
+        t = -F.log_softmax(logits, dim=1) * q                                              # [B,C,H,W]
+        if refer_labels is None:
+            return t.sum() / q.numel()
+    elif kind == "MSE":
+        if refer_labels is None:
+            return F.mse_loss(logits, labels)
+        t = F.mse_loss(logits, labels, reduction="none")
+    elif kind == "KLDIV":
+        lp, q = F.log_softmax(logits, dim=1), F.softmax(labels, dim=1)
+        if refer_labels is None:
+            return F.kl_div(lp, q, reduction="mean")
+        t = F.kl_div(lp, q, reduction="none")
+    else:
+        raise ValueError(kind)
+    if region == "ignored":
+        mask = refer_labels == ignore_index
+    elif region == "confident":
+        mask = refer_labels != ignore_index
+    elif region == "all":
+        mask = torch.ones_like(refer_labels, dtype=torch.bool)
+    else:
+        raise ValueError("{} is not a valid region".format(region))
+    t = t * mask.unsqueeze(1)
+    return t.sum() / (t != 0).sum()

@@ -225,6 +225,69 @@ def g_losses():
     save("losses", **out)
 
 
+# ---------------------------------------------------------------------------------- G6b
+LOSS_REGISTRY_CASES = [   # (name, loss, per-class weights?, refer_labels?, region, ignore_index)
+    ("ce_plain", "CE", False, False, "confident", 255),
+    ("ce_weights", "CE", True, False, "confident", 255),
+    ("ce_refer_conf", "CE", False, True, "confident", 255),
+    ("ce_refer_ign", "CE", False, True, "ignored", 255),
+    ("ce_refer_all_w", "CE", True, True, "all", 255),
+    ("softce_plain", "SoftCE", False, False, "confident", 255),
+    ("softce_weights", "SoftCE", True, False, "confident", 255),
+    ("softce_refer_ign", "SoftCE", False, True, "ignored", 255),
+    ("softce_refer_conf_w", "SoftCE", True, True, "confident", 255),
+    ("mse_refer_ign", "MSE", False, True, "ignored", 255),
+    ("kldiv_refer_conf", "KLDIV", False, True, "confident", 255),
+    ("ce_refer_ign_idx7", "CE", False, True, "ignored", 7),
+]
+
+
+def loss_registry_inputs(name, B=2, C=19, H=12, W=20):
+    """seeded inputs of one LOSS-registry case (shared by the generator and the tests)"""
+    k = [c[0] for c in LOSS_REGISTRY_CASES].index(name)
+    seed = 7600 + 10 * k
+    z = synth.normal_f32(seed, (B, C, H, W), 2.0)
+    hard = synth.pseudo_labels(seed + 1, B, H, W, C, 0.3, np.int64)
+    soft = np.exp(synth.normal_f32(seed + 2, (B, C, H, W), 1.5))
+    soft = (soft / soft.sum(1, keepdims=True)).astype(np.float32)
+    refer = synth.pseudo_labels(seed + 3, B, H, W, C, 0.45, np.int64)
+    weights = (0.5 + synth.rng(seed + 4).random(C)).astype(np.float32)
+    return z, hard, soft, refer, weights
+
+
+def g_loss_registry():
+    """LOSS['CE'|'SoftCE'|'MSE'|'KLDIV'] of the reference (sseg/models/modules/losses.py:10-89) on the argument combinations no
+    HIAST config uses but the registry signature offers: per-class weights, refer_labels + region with every loss (incl. the
+    [B,H,W] x [B,1,H,W] broadcast of CE's per-pixel loss against the mask, :86-87), SoftCE's plain mean, another
+    ignore_index.  Values + gradients w.r.t. the logits."""
+    losses_mod = ref_import.ref("sseg.models.modules.losses")
+    out = {}
+    for name, kind, use_w, use_refer, region, ign in LOSS_REGISTRY_CASES:
+        z, hard, soft, refer, weights = loss_registry_inputs(name)
+        zt = torch.from_numpy(z).requires_grad_(True)
+        wt = torch.from_numpy(weights) if use_w else None
+        rt = torch.from_numpy(refer) if use_refer else None
+        if kind == "CE":
+            lbl = torch.from_numpy(hard.copy())
+            if ign != 255:
+                lbl[lbl == 255] = ign
+            if use_refer:       # reduction='none' has no ignore_index: every label must be a class
+                lbl[(lbl == 255) | (lbl == ign)] = 0
+            val = losses_mod.LOSS["CE"](zt, lbl, weights=wt, ignore_index=ign, refer_labels=rt, region=region)
+        elif kind == "SoftCE":
+            val = losses_mod.LOSS["SoftCE"](zt, torch.from_numpy(soft.copy()), weights=wt, ignore_index=ign, refer_labels=rt,
+                                            region=region)
+        elif kind == "MSE":
+            val = losses_mod.LOSS["MSE"](zt, torch.from_numpy(soft.copy()), ignore_index=ign, refer_labels=rt, region=region)
+        else:
+            t2 = torch.from_numpy(synth.normal_f32(7999, tuple(z.shape), 2.0))
+            val = losses_mod.LOSS["KLDIV"](zt, t2, ignore_index=ign, refer_labels=rt, region=region)
+        val.backward()
+        out["val_" + name] = np.float64(val.item())
+        out["grad_" + name] = zt.grad.numpy()
+    save("loss_registry", **out)
+
+
 # ---------------------------------------------------------------------------------- G1
 def g_aspp():
     """ASPP_V2 (deeplab_v2.py:8-24) forward + autograd on a 2048-channel 9x17 map."""
@@ -650,7 +713,7 @@ def g_tta():
 
 ALL = {"policies": g_policies, "tta": g_tta, "upsample": g_upsample, "stage_a": g_stage_a, "ias": g_ias, "losses": g_losses,
        "aspp": g_aspp, "deeplab": g_deeplab, "metrics": g_metrics, "copy_paste": g_copy_paste,
-       "ema_optim": g_ema_optim, "warmup": g_warmup}
+       "ema_optim": g_ema_optim, "warmup": g_warmup, "loss_registry": g_loss_registry}
 
 if __name__ == "__main__":
     torch.set_num_threads(8)

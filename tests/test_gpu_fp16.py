@@ -49,7 +49,7 @@ def test_pack_conv_weight_fp16_layout(K, shape):
     assert torch.equal(K.pack_conv_weight(w, K.FMT_FP16, transpose=True).view(torch.int16), wpt.view(torch.int16))
 
 
-@pytest.mark.parametrize("case", IGEMM_CASES[1:6])
+@pytest.mark.parametrize("case", IGEMM_CASES[1:5])
 def test_igemm_fp16(K, case):
     """the implicit-GEMM tile kernel on fp16 rows: BN(eval) (+res) + ReLU, plain, fp32 output, statistics epilogue"""
     B, H, W, Cin, Cout, taps, stride, dil, has_res = case

@@ -80,50 +80,6 @@ def test_packed_trunk_weights_follow_adam_and_ema():
     assert float((y32_1 - ref).abs().max()) <= 1e-3 * float(ref.abs().max())
 
 
-def test_copy_paste_on_device_matches_reference_golden(golden):
-    """K17: the hard-aware CopyPaste composite as one kernel on device-resident frames, bit for bit against the outputs
-    of the reference's CopyPaste.run (tests/golden/copy_paste.npz) and against the host path on ragged sizes"""
-    from hiast_amd import kernels as K
-    from hiast_amd.utils.default_config import get_default_cfg
-    from hiast_amd.utils.registry import register  # noqa: F401
-    from hiast_amd.utils.registry.registries import PREPROCESSOR
-    g = golden("copy_paste")
-    N, H, W, C = [int(v) for v in g["shape"]]
-    imgs = synth.images_u8(1100, N, H, W)
-    lbls = np.stack([synth.pseudo_labels(1110 + i, 1, H, W, C, 0.3)[0] for i in range(N)])
-    names = ["img_%d.png" % i for i in range(N)]
-    swc = {c: [names[i] for i in range(N) if (lbls[i] == c).any()] for c in range(C)}
-
-    class DS:
-        def get_samples_with_class(self):
-            return swc
-
-        def get_file_to_idx(self, f):
-            return names.index(f)
-
-        def load_data(self, i):
-            return imgs[i].copy(), lbls[i].copy(), names[i]
-
-    c = get_default_cfg()
-    c.dataset.source.type = "GTAV"
-    cp = PREPROCESSOR["CopyPaste"](c, DS(), g["class_value"].copy())
-    np.random.seed(888)
-    for i in range(N):
-        im, lb, mk = cp.run_device(torch.from_numpy(imgs[i].copy()).cuda(), torch.from_numpy(lbls[i].copy()).cuda())
-        assert np.array_equal(im.cpu().numpy(), g["img"][i]) and np.array_equal(lb.cpu().numpy(), g["lbl"][i])
-        assert np.array_equal(mk.cpu().numpy(), g["mask"][i])
-    # full-size frame (2048 x 1024), random hard set: against the definition
-    Hh, Ww = 1024, 2048
-    a, b = synth.images_u8(1, 1, Hh, Ww)[0], synth.images_u8(2, 1, Hh, Ww)[0]
-    la, lb_ = synth.pseudo_labels(3, 1, Hh, Ww, 19, 0.3)[0], synth.pseudo_labels(4, 1, Hh, Ww, 19, 0.3)[0]
-    hard = [0, 3, 7, 18]
-    sel = np.isin(lb_, hard)
-    da, dl = torch.from_numpy(a.copy()).cuda(), torch.from_numpy(la.copy()).cuda()
-    mk = K.copy_paste_u8(da, dl, torch.from_numpy(b).cuda(), torch.from_numpy(lb_).cuda(), hard)
-    assert np.array_equal(da.cpu().numpy(), np.where(sel[..., None], b, a))
-    assert np.array_equal(dl.cpu().numpy(), np.where(sel, lb_, la)) and np.array_equal(mk.cpu().numpy(), np.where(sel, lb_, 255))
-
-
 @pytest.mark.parametrize("case", [(2, 24, 40, 1024, 256, 1, 1), (1, 20, 36, 256, 256, 9, 2), (2, 9, 13, 128, 64, 9, 1),
                                   (1, 16, 16, 512, 128, 1, 1)])
 def test_dgrad_epilogue_delivers_bn_backward_sums(case):

@@ -166,6 +166,36 @@ def test_warmup_losses_registry(K):
         LOSS["MSE"](a.cpu(), one.cpu())
 
 
+def _registry_names():
+    from make_golden import LOSS_REGISTRY_CASES
+    return [c[0] for c in LOSS_REGISTRY_CASES]
+
+
+@pytest.mark.parametrize("name", _registry_names())
+def test_loss_registry_full_argument_surface_vs_reference(K, golden, name):
+    """LOSS['CE'|'SoftCE'|'MSE'|'KLDIV'] with per-class weights, refer_labels + region, SoftCE's plain mean and another
+    ignore_index — the part of the registry signature (sseg/models/modules/losses.py:10-89) no HIAST config uses — against
+    the reference's own outputs (tests/golden/loss_registry.npz): values 2e-5 relative, gradients 1e-4 of their maximum
+    (the fused kernel's class where it serves the case); SoftCE scales its target by the weights in place, as the reference"""
+    from hiast_amd.utils.registry import register  # noqa: F401
+    from hiast_amd.utils.registry.registries import LOSS
+    from test_oracle_golden import _loss_registry_case
+    g = golden("loss_registry")
+    kind, z, lbl, w, ign, refer, region = _loss_registry_case(name)
+    zt = dev(z).requires_grad_(True)
+    lt = dev(lbl)
+    soft_before = lt.clone() if kind == "SoftCE" else None
+    val = LOSS[kind](zt, lt, weights=None if w is None else dev(w), ignore_index=ign,
+                     refer_labels=None if refer is None else dev(refer), region=region)
+    val.backward()
+    want = float(g["val_" + name])
+    assert abs(float(val) - want) <= 2e-5 * max(1.0, abs(want)), (float(val), want)
+    gw = g["grad_" + name]
+    assert np.abs(zt.grad.cpu().numpy() - gw).max() <= 1e-4 * np.abs(gw).max() + 1e-9
+    if kind == "SoftCE" and w is not None:
+        assert torch.allclose(lt, soft_before * dev(w).view(1, -1, 1, 1))
+
+
 # ------------------------------------------------------------------------------------------ trainers end to end
 H, W, C = 128, 256, 19
 

@@ -389,3 +389,39 @@ def test_validator_run_miou_vs_reference(golden):
     m19, _, _ = metrics_ref.miou(inter.astype(np.float64), union.astype(np.float64))
     assert abs(m19 - g["run_miou_GTAV"][0]) <= 6e-5
     assert iou[9] == 0 and iou[14] == 0 and iou[16] == 0
+
+
+def _loss_registry_case(name):
+    from make_golden import LOSS_REGISTRY_CASES, loss_registry_inputs
+    _, kind, use_w, use_refer, region, ign = [c for c in LOSS_REGISTRY_CASES if c[0] == name][0]
+    z, hard, soft, refer, weights = loss_registry_inputs(name)
+    if kind == "CE":
+        lbl = hard.copy()
+        if ign != 255:
+            lbl[lbl == 255] = ign
+        if use_refer:
+            lbl[(lbl == 255) | (lbl == ign)] = 0
+    elif kind == "KLDIV":
+        lbl = synth.normal_f32(7999, tuple(z.shape), 2.0)
+    else:
+        lbl = soft.copy()
+    return kind, z, lbl, (weights if use_w else None), ign, (refer if use_refer else None), region
+
+
+def loss_registry_names():
+    from make_golden import LOSS_REGISTRY_CASES
+    return [c[0] for c in LOSS_REGISTRY_CASES]
+
+
+@pytest.mark.parametrize("name", loss_registry_names())
+def test_loss_registry_oracle_vs_reference(golden, name):
+    """oracle/losses_ref.registry_loss against the reference's own LOSS[...] outputs on the argument combinations the HIAST
+    configs do not use (weights, refer_labels + region with every loss, SoftCE plain mean, another ignore_index)"""
+    g = golden("loss_registry")
+    kind, z, lbl, w, ign, refer, region = _loss_registry_case(name)
+    zt = torch.from_numpy(z).requires_grad_(True)
+    val = losses_ref.registry_loss(kind, zt, torch.from_numpy(lbl), None if w is None else torch.from_numpy(w), ign,
+                                   None if refer is None else torch.from_numpy(refer), region)
+    val.backward()
+    assert abs(float(val) - float(g["val_" + name])) <= 1e-6 * max(1.0, abs(float(g["val_" + name])))
+    assert np.abs(zt.grad.numpy() - g["grad_" + name]).max() <= 1e-6 * max(1e-6, np.abs(g["grad_" + name]).max())
