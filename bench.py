@@ -700,6 +700,10 @@ def main():
         t_tr = sum(e[3].elapsed_time(e[4]) for e in ser) * 1e-3 * args.steps
     timer.on = False
     marker()
+    # unprofiled device-side gap at the step boundary: time between the event behind the last launch of step i (after the
+    # EMA update / buffer copy) and the event in front of the first launch of step i + 1, on the main stream.  If the host
+    # enqueues ahead of the device the two events complete back to back (~0); a host that arrives late shows as a gap.
+    gaps = [marks[i][4].elapsed_time(marks[i + 1][0]) for i in range(1, len(marks) - 1)]      # (step 0 is the serial one)
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -750,6 +754,9 @@ def main():
             # host time spent ENQUEUING each part (steps without per-launch events; the third entry includes the wait
             # for the histogram): the sum must stay below ms_per_step or the step is launch-bound
             "final_losses": final_losses, "ranks_agree": ranks_agree,
+            "step_boundary_gap_ms": ({"mean": float(np.mean(gaps)), "max": float(np.max(gaps)), "steps": len(gaps),
+                                      "note": "HIP events on the main stream behind the last launch of a step and in front "
+                                              "of the first launch of the next (unprofiled run)"} if gaps else None),
             "host_enqueue_ms": dict(zip(["plabel_fwd_pass1", "train_forwards", "hist_wait_thresholds_pass2",
                                          "loss_bwd_adam_ema"] if hp.pipelined else
                                         ["plabel_fwd_pass1", "hist_wait_thresholds_pass2", "-", "train_step"],

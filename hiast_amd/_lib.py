@@ -77,8 +77,8 @@ SIGNATURES = {
     "hiast_maxpool3x3s2_nhwc_fwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "hiast_maxpool3x3s2_nhwc_bwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "hiast_multi_copy": (c_int, [c_vp, c_int, c_vp]),
-    "hiast_adam_step": (c_int, [c_vp, c_vp, c_vp, c_int, ctypes.c_double, ctypes.c_double, c_f32, c_f32, c_vp, c_vp, c_vp,
-                                c_vp]),
+    "hiast_adam_prepare": (c_int, [c_vp, c_vp, c_vp, c_vp]),
+    "hiast_adam_step": (c_int, [c_vp, c_vp, c_vp, c_int, ctypes.c_double, ctypes.c_double, c_f32, c_f32, c_vp, c_vp]),
     "hiast_confusion_hist": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp]),
 }
 

@@ -83,34 +83,35 @@ __global__ __launch_bounds__(256) void multi_copy_kernel(const hiast_copy_rec* _
 // ENTIRELY (no moment update, no step count).  Both decisions are taken on the device: adam_prepare_kernel turns the
 // scaler's device scalars (scale, found_inf) into a control block — skip flag, 1 / scale, the count of APPLIED steps and
 // the bias corrections that count implies — and adam_kernel reads it; the host never waits for found_inf (GradScaler's
-// own `if not found_inf.item(): optimizer.step()` drains the launch queue once per iteration).
+// own `if not found_inf.item(): optimizer.step()` drains the launch queue once per iteration).  The host keeps counting
+// ATTEMPTED steps per tensor (record field `step`); the device counts the skipped ones; a tensor's applied-step count is
+// the difference, so tensors that join later or sit out a step (grad None) keep their own counts, as in torch.
 __global__ void adam_prepare_kernel(hiast_adam_ctl* __restrict__ ctl, const float* __restrict__ grad_scale,
-                                    const float* __restrict__ found_inf, double beta1, double beta2)
+                                    const float* __restrict__ found_inf)
 {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     const bool skip = found_inf && *found_inf != 0.f;
-    float t = ctl->step;
-    if (!skip) t += 1.0f;
-    ctl->step = t;
+    if (skip) ctl->skipped += 1.0f;
     ctl->skip = skip ? 1.0f : 0.0f;
     ctl->inv_scale = grad_scale ? (float)(1.0 / (double)*grad_scale) : 1.0f;
-    ctl->bc1 = (float)(1.0 - pow(beta1, (double)t));             // torch: 1 - beta1 ** step, sqrt(1 - beta2 ** step), in double
-    ctl->bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)t));
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(const hiast_adam_rec* __restrict__ table,
                                                    const int32_t* __restrict__ chunk_tensor,
                                                    const int64_t* __restrict__ chunk_start, float beta1, float beta2,
                                                    float omb1, float omb2, float eps, float wd,
-                                                   const hiast_adam_ctl* __restrict__ ctl)
+                                                   const hiast_adam_ctl* __restrict__ ctl, double beta1d, double beta2d)
 {
     const hiast_adam_rec r = table[chunk_tensor[blockIdx.x]];
     const int64_t s = chunk_start[blockIdx.x];
     const int64_t e = (s + 65536 < r.n) ? s + 65536 : r.n;
     float bc1 = r.bc1, bc2_sqrt = r.bc2_sqrt, inv_scale = 1.0f;
-    if (ctl) {                                // device-side control block: skipped step / loss scale / applied-step count
+    if (ctl) {                                // device-side control block: skipped step / loss scale / skipped-step count
         if (ctl->skip != 0.f) return;
-        bc1 = ctl->bc1; bc2_sqrt = ctl->bc2_sqrt; inv_scale = ctl->inv_scale;
+        inv_scale = ctl->inv_scale;
+        const double t = (double)(r.step - ctl->skipped);            // applied steps of THIS tensor, this one included
+        bc1 = (float)(1.0 - pow(beta1d, t));  // torch: 1 - beta1 ** step and sqrt(1 - beta2 ** step), formed in double
+        bc2_sqrt = (float)sqrt(1.0 - pow(beta2d, t));
     }
     const float step_size = r.lr / bc1;       // omb1 / omb2 = float(1 - beta) formed in double on the host, as torch does
     auto upd = [&](float& p, float g, float& m, float& v) {
@@ -214,20 +215,22 @@ extern "C" int hiast_confusion_hist(const int64_t* pred, const int64_t* target, 
 
 extern "C" int hiast_adam_step(const hiast_adam_rec* table, const int32_t* chunk_tensor, const int64_t* chunk_start,
                                int n_chunks, double beta1, double beta2, float eps, float weight_decay,
-                               hiast_adam_ctl* ctl, const float* grad_scale, const float* found_inf,
-                               hiast_stream_t stream)
+                               const hiast_adam_ctl* ctl, hiast_stream_t stream)
 {
     if (!table || !chunk_tensor || !chunk_start) return HIAST_E_ARG;
     if (n_chunks <= 0) return HIAST_E_ARG;
-    if (!ctl && (grad_scale || found_inf)) return HIAST_E_ARG;      // the device-side decisions need the control block
-    if (ctl) {
-        hipLaunchKernelGGL(hiast::adam_prepare_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ctl, grad_scale, found_inf,
-                           beta1, beta2);
-        HIAST_CHECK_LAUNCH();
-    }
     hipLaunchKernelGGL(hiast::adam_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, table, chunk_tensor,
                        chunk_start, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), eps,
-                       weight_decay, (const hiast_adam_ctl*)ctl);
+                       weight_decay, ctl, beta1, beta2);
+    HIAST_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int hiast_adam_prepare(hiast_adam_ctl* ctl, const float* grad_scale, const float* found_inf,
+                                  hiast_stream_t stream)
+{
+    if (!ctl) return HIAST_E_ARG;
+    hipLaunchKernelGGL(hiast::adam_prepare_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ctl, grad_scale, found_inf);
     HIAST_CHECK_LAUNCH();
     return 0;
 }

@@ -560,29 +560,35 @@ class AdamPlan:
         self.table = torch.empty(len(numels) * self.REC.itemsize, dtype=torch.uint8, device=device)
 
 
-def adam_step(plan, params, grads, exp_avgs, exp_avg_sqs, lrs, bc1s, bc2_sqrts, beta1, beta2, eps, weight_decay,
-              ctl=None, grad_scale=None, found_inf=None):
-    """one launch over all tensors; p/m/v updated in place.  ctl: float32 [8] device control block (hiast_adam_ctl: element
-    0 = applied steps so far): the step count / bias corrections then live on the device (bc1s / bc2_sqrts are ignored),
-    gradients are multiplied by 1 / grad_scale and the whole update is skipped when found_inf != 0 (device scalars of a
-    torch.amp.GradScaler) — no host synchronisation"""
-    if ctl is not None:
-        _req(ctl, torch.float32, 1, "ctl")
-        assert ctl.numel() == 8
+def adam_prepare(ctl, grad_scale=None, found_inf=None):
+    """once per optimiser step, before its adam_step launches: the scaler's device scalars -> control block (skip flag,
+    1 / scale, count of skipped steps).  ctl: float32 [8] device tensor (hiast_adam_ctl), zeroed when created"""
+    _req(ctl, torch.float32, 1, "ctl")
+    assert ctl.numel() == 8
     for t, nm in ((grad_scale, "grad_scale"), (found_inf, "found_inf")):
         if t is not None and not (t.is_cuda and t.dtype == torch.float32 and t.numel() == 1):
-            raise ValueError("adam_step: %s must be a float32 device scalar" % nm)
+            raise ValueError("adam_prepare: %s must be a float32 device scalar" % nm)
+    check(_lib.load().hiast_adam_prepare(_ptr(ctl), _ptr(grad_scale), _ptr(found_inf), _stream()), "hiast_adam_prepare")
+
+
+def adam_step(plan, params, grads, exp_avgs, exp_avg_sqs, lrs, bc1s, bc2_sqrts, beta1, beta2, eps, weight_decay,
+              ctl=None, steps=None):
+    """one launch over all tensors; p/m/v updated in place.  With ctl (a control block adam_prepare has filled for this
+    step) and steps (per-tensor count of ATTEMPTED steps, this one included) the bias corrections are formed on the device
+    from steps[i] - skipped (bc1s / bc2_sqrts are ignored), the gradients are multiplied by 1 / grad_scale and the whole
+    update is skipped on an overflow — no host synchronisation"""
+    assert (ctl is None) == (steps is None)
     h = plan.host
     for i, (p, g, m, v) in enumerate(zip(params, grads, exp_avgs, exp_avg_sqs)):
         for t, nm in ((p, "param"), (g, "grad"), (m, "exp_avg"), (v, "exp_avg_sq")):
             if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == plan.numels[i]):
                 raise ValueError("adam_step: %s %d must be a contiguous float32 HIP tensor of %d elements"
                                  % (nm, i, plan.numels[i]))
-        h[i] = (p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lrs[i], bc1s[i], bc2_sqrts[i], 0.0)
+        h[i] = (p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lrs[i], bc1s[i], bc2_sqrts[i],
+                0.0 if steps is None else float(steps[i]))
     h2d_async(h.view(np.uint8).reshape(-1), plan.table.device, out=plan.table)
     check(_lib.load().hiast_adam_step(_ptr(plan.table), _ptr(plan.chunk_tensor), _ptr(plan.chunk_start), plan.n_chunks,
-                                      float(beta1), float(beta2), float(eps), float(weight_decay), _ptr(ctl),
-                                      _ptr(grad_scale), _ptr(found_inf), _stream()),
+                                      float(beta1), float(beta2), float(eps), float(weight_decay), _ptr(ctl), _stream()),
           "hiast_adam_step")
 
 

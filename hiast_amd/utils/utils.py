@@ -171,25 +171,38 @@ class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._plan = None
-        self._ctl = {}          # hyper-parameter key -> device control block (element 0: number of APPLIED steps)
+        self._ctl = None        # device control block (element 0: number of steps SKIPPED on an overflow so far)
+        self._attempts = {}     # id(param) -> steps attempted since the counts were last folded into state['step']
+
+    def _skipped(self):
+        return 0 if self._ctl is None else int(self._ctl[0].item())       # (synchronises)
+
+    def _fold_steps(self):
+        """state['step'] := steps actually applied (attempts minus the overflow steps the device skipped); the device
+        counter restarts at 0.  Synchronises: called when the counts are read or saved, never inside a step."""
+        if self._ctl is None:
+            return
+        k = float(self._skipped())
+        for p, st in self.state.items():
+            if "step" in st and self._attempts.get(id(p)):
+                st["step"] = torch.tensor(float(st["step"]) - k)
+        self._attempts = {}
+        self._ctl.zero_()
 
     def applied_steps(self):
-        """number of updates actually applied (overflow steps excluded); reads the device counter (synchronises)"""
-        return max([int(c[0].item()) for c in self._ctl.values()], default=0)
+        """number of updates actually applied to the most-stepped parameter (overflow steps excluded); synchronises"""
+        self._fold_steps()
+        return max([int(st["step"]) for st in self.state.values() if "step" in st], default=0)
 
     def state_dict(self):
-        # the step count lives on the device (skipped steps are decided there): bring the per-parameter 'step' entries
-        # of torch's layout up to date before they are saved
-        if self._ctl:
-            n = float(self.applied_steps())
-            for st in self.state.values():
-                if "step" in st:
-                    st["step"] = torch.tensor(n)
+        self._fold_steps()      # torch's layout: per-parameter 'step' = applied steps
         return super().state_dict()
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
-        self._ctl = {}          # re-created from the loaded 'step' entries at the next step
+        self._attempts = {}
+        if self._ctl is not None:
+            self._ctl.zero_()
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -207,30 +220,34 @@ class FusedAdam(torch.optim.Optimizer):
                     continue
                 st = self.state[p]
                 if not st:
+                    if self._attempts:      # a tensor joins later: its count must not inherit earlier skipped steps
+                        self._fold_steps()
                     st["step"] = torch.tensor(0.0)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 by_hyper.setdefault(key, []).append((p, group["lr"], st))
+        dev = next((p.device for items in by_hyper.values() for p, _, _ in items), None)
+        if dev is None:
+            return loss
+        if self._ctl is None:
+            self._ctl = torch.zeros(8, dtype=torch.float32, device=dev)
+        K.adam_prepare(self._ctl, grad_scale, found_inf)      # ONE decision per step, shared by every launch below
         for key, items in by_hyper.items():
             betas, eps, wd = key
             ps = [p for p, _, _ in items]
-            ctl = self._ctl.get(key)
-            if ctl is None:     # applied steps so far: 0, or what a loaded checkpoint says
-                ctl = torch.zeros(8, dtype=torch.float32)
-                ctl[0] = max(float(st["step"]) for _, _, st in items)
-                ctl = self._ctl[key] = ctl.to(ps[0].device)
-            for _, _, st in items:
-                st["step"] += 1     # (host copy: attempted steps; state_dict() replaces it by the device's applied count)
+            for p, _, st in items:      # host side: ATTEMPTED steps; the device subtracts the ones it skipped (overflow)
+                st["step"] += 1
+                self._attempts[id(p)] = self._attempts.get(id(p), 0) + 1
             plan = self._plan.get(len(ps)) if isinstance(self._plan, dict) else None
             numels = tuple(p.numel() for p in ps)
             if plan is None or plan.numels != numels:
                 plan = K.AdamPlan(numels, ps[0].device)
                 self._plan = dict(self._plan or {})
                 self._plan[len(ps)] = plan
-            one = [1.0] * len(ps)       # bias corrections: computed on the device from the applied-step count
+            one = [1.0] * len(ps)       # bias corrections: formed on the device from (attempted - skipped) steps
             K.adam_step(plan, [p.data for p in ps], [p.grad.contiguous() for p in ps], [st["exp_avg"] for _, _, st in items],
                         [st["exp_avg_sq"] for _, _, st in items], [lr for _, lr, _ in items], one, one, betas[0], betas[1],
-                        eps, wd, ctl=ctl, grad_scale=grad_scale, found_inf=found_inf)
+                        eps, wd, ctl=self._ctl, steps=[float(st["step"]) for _, _, st in items])
             # raw-pointer writes do not move Parameter._version by themselves; the packed-weight caches key on it
             torch.autograd.graph.increment_version(ps)
         return loss

@@ -390,17 +390,19 @@ int hiast_multi_copy(const hiast_copy_rec* table, int n_tensors, hiast_stream_t 
  * formulas in its operation order (L2 weight decay folded into the gradient, bias-corrected step).
  * table: device array of records {p, g, m (exp_avg), v (exp_avg_sq), n, lr, bc1 = 1-b1^t, bc2_sqrt = sqrt(1-b2^t)};
  * chunk tables as for K11. */
-typedef struct { float* p; const float* g; float* m; float* v; int64_t n; float lr; float bc1; float bc2_sqrt; float pad; } hiast_adam_rec;
+typedef struct { float* p; const float* g; float* m; float* v; int64_t n; float lr; float bc1; float bc2_sqrt; float step; } hiast_adam_rec;
 /* ctl (may be NULL): device control block for mixed precision with dynamic loss scaling (apex amp.scale_loss /
  * torch GradScaler, base_trainer.py:129-131): a one-thread kernel ahead of the update reads the scaler's device scalars
- * grad_scale (may be NULL = 1) and found_inf (may be NULL = 0), and writes skip / 1/scale / the number of APPLIED steps
- * and its bias corrections; the update multiplies every gradient by 1/scale and is skipped entirely (no moment update,
- * no step count) when found_inf != 0 — without the host ever reading found_inf.  With ctl the records' bc1 / bc2_sqrt
- * are ignored (the count lives in ctl->step; zero it once when the optimiser is created). */
-typedef struct { float step; float skip; float inv_scale; float bc1; float bc2_sqrt; float pad[3]; } hiast_adam_ctl;
+ * grad_scale (may be NULL = 1) and found_inf (may be NULL = 0) and writes skip / 1/scale / the running count of SKIPPED
+ * steps (hiast_adam_prepare: ONCE per optimiser step, before the hiast_adam_step launches of that step); the update multiplies every gradient by 1/scale and is skipped entirely (no moment update) when found_inf != 0 —
+ * without the host ever reading found_inf.  With ctl the records' bc1 / bc2_sqrt are ignored: a record's `step` field is
+ * the number of steps ATTEMPTED on that tensor (this one included, host-side count) and the bias corrections are formed
+ * on the device from step - ctl->skipped.  Zero ctl once when the optimiser is created. */
+typedef struct { float skipped; float skip; float inv_scale; float pad[5]; } hiast_adam_ctl;
+int hiast_adam_prepare(hiast_adam_ctl* ctl, const float* grad_scale, const float* found_inf, hiast_stream_t stream);
 int hiast_adam_step(const hiast_adam_rec* table, const int32_t* chunk_tensor, const int64_t* chunk_start,
-                    int n_chunks, double beta1, double beta2, float eps, float weight_decay, hiast_adam_ctl* ctl,
-                    const float* grad_scale, const float* found_inf, hiast_stream_t stream);
+                    int n_chunks, double beta1, double beta2, float eps, float weight_decay, const hiast_adam_ctl* ctl,
+                    hiast_stream_t stream);
 
 /* ---- K15: discriminator input map (adversarial warm-up stage) -----------------------------
  * sseg/models/segmentors/adversarial_warmup_segmentor.py: F.interpolate(logits, size, bilinear,

@@ -180,10 +180,14 @@ def test_conv_nhwc_autograd_fp16_vs_fp64(K, cfg, monkeypatch):
     yd = torch.nn.functional.conv2d(xd, wd, None, stride, dil if k == 3 else 0, dil if k == 3 else 1)
     yd.backward(torch.from_numpy(gy).double())
     tol = lambda ref: 2.0 ** -10 * ref.abs() + 3e-4 * ref.abs().max()
+    # where the library still serves (weight gradients below 256 channels, the data gradient of the strided 3x3) its result
+    # arrives as an fp16 tensor accumulated its own way: one more fp16 rounding and a larger share of the maximum
+    tol_lib = lambda ref: 2.0 ** -9 * ref.abs() + 2e-3 * ref.abs().max()
+    own_w = K.conv_wgrad_preferred(Cin, Cout, k, stride)
     assert ((y.double().cpu() - yd.detach()).abs() <= tol(yd.detach())).all()
-    assert ((xt.grad.double().cpu() - xd.grad).abs() <= tol(xd.grad)).all()
+    assert ((xt.grad.double().cpu() - xd.grad).abs() <= (tol if stride == 1 or k == 1 else tol_lib)(xd.grad)).all()
     assert conv.weight.grad.dtype == torch.float32
-    assert ((conv.weight.grad.double().cpu() - wd.grad).abs() <= tol(wd.grad)).all()
+    assert ((conv.weight.grad.double().cpu() - wd.grad).abs() <= (tol if own_w else tol_lib)(wd.grad)).all()
     with torch.autocast("cuda", dtype=H16):
         y2, partial = HF.conv_nhwc(xt.detach(), conv, want_stats=True)
     assert torch.equal(y2, y.detach())
@@ -237,7 +241,8 @@ def test_aspp2_fp16_fwd_bwd_vs_torch(K, shape):
     assert ((xt.grad.double().cpu() - xd.grad).abs() <= 2.0 ** -9 * xd.grad.abs() + 2e-3 * xd.grad.abs().max()).all()
     for i in range(4):
         assert np.abs(wt[i].grad.double().cpu().numpy() - wd[i].grad.numpy()).max() <= 3e-3 * float(wd[i].grad.abs().max()), i
-        assert torch.allclose(bt[i].grad.double().cpu(), bd[i].grad, rtol=1e-4, atol=1e-4)
+        db_ref = torch.from_numpy(gy).double().sum(dim=(0, 2, 3))      # the bias gradient sums the fp32 dy itself
+        assert torch.allclose(bt[i].grad.double().cpu(), db_ref, rtol=1e-4, atol=1e-4)
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 37, 53), (2, 16, 5, 4)])
@@ -284,6 +289,7 @@ def test_fused_adam_handles_the_loss_scale_on_the_device(K):
     own = FusedAdam(p_own, lr=1e-2, betas=(0.9, 0.999), weight_decay=5e-4)
     ref = torch.optim.Adam(p_ref, lr=1e-2, betas=(0.9, 0.999), weight_decay=5e-4)
     scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 10, growth_factor=2.0, backoff_factor=0.5, growth_interval=1000)
+    scaler.scale(torch.zeros((), device="cuda"))        # (the scale tensor is created lazily by the first scale() call)
     applied = 0
     for it in range(6):
         gs = [torch.randn(s, device="cuda") for s in shapes]

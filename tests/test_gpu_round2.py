@@ -60,7 +60,7 @@ def test_packed_trunk_weights_follow_adam_and_ema():
     assert conv.weight._version > v1, "the optimiser step must move Parameter._version"
     ent = conv.__dict__["_hiast_packed"][1]
     assert torch.equal(ent[2], K.pack_conv_weight(w_after_1, 1)), "student forward ran on stale packed weights"
-    adj = conv.__dict__["_hiast_packed_adj"]
+    adj = conv.__dict__["_hiast_packed_adj"][1]        # (keyed by operand format: 1 = bf16)
     assert torch.equal(adj[2], K.pack_conv_weight(w_after_1, 1, transpose=True)), "stale adjoint (data-gradient) weights"
 
     y16_0, y32_0 = teacher_eval(True), teacher_eval(False)
