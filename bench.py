@@ -51,7 +51,7 @@ def parse():
     p.add_argument("--same-device", action="store_true", help="testing: every rank uses cuda:0")
     p.add_argument("--cpu-threads", type=int, default=64, help="upper bound; the usable CPUs of the box decide")
     p.add_argument("--cpu-reps", type=int, default=3)
-    p.add_argument("--amp-dtype", default=os.environ.get("HIAST_BENCH_AMP", "bf16"), choices=["bf16", "fp16"],
+    p.add_argument("--amp-dtype", default=os.environ.get("HIAST_BENCH_AMP", "fp16"), choices=["bf16", "fp16"],
                    help="16-bit type of the mixed-precision training step: fp16 = the reference's apex-O1 arithmetic (dynamic "
                         "loss scaling, handled on the device), bf16 = no loss scaling; both run on the same hand-written kernels")
     p.add_argument("--trainer", default="ConsistencySelfTrainingTrainer",
@@ -59,7 +59,7 @@ def parse():
     return p.parse_args()
 
 
-def make_cfg(world, trainer, amp_dtype="bf16"):
+def make_cfg(world, trainer, amp_dtype="fp16"):
     from hiast_amd.utils.default_config import get_default_cfg
     c = get_default_cfg()
     c.trainer = trainer
@@ -649,16 +649,15 @@ def main():
     HF.enable_wgrad_overlap(True)
     sync()
     # fp16: the dynamic loss scale starts at 2^16 (apex) and is halved on every overflow; a step that overflows skips its
-    # optimiser update.  No such step may sit in the timed region: extra (untimed) steps until one has been APPLIED at the
-    # current scale, and the applied-step counter is compared again after the timed steps.
-    settle = 0
+    # optimiser update.  No such step may sit in the timed region: extra (untimed) steps until six in a row have been APPLIED
+    # at the current scale, and the applied-step counter is compared again after the timed steps (reported in the JSON).
+    settle, clean = 0, 0
     if hp.scaler is not None:
-        while settle < 24:
+        while settle < 40 and clean < 6:        # until six consecutive steps have been applied at the current scale
             before = hp.opt.applied_steps()
             hp.step()
             settle += 1
-            if hp.opt.applied_steps() == before + 1:
-                break
+            clean = clean + 1 if hp.opt.applied_steps() == before + 1 else 0
         sync()
     applied_before = hp.opt.applied_steps() if hp.scaler is not None else None
 

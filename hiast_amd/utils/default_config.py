@@ -149,9 +149,9 @@ train:
   optimizer: Adam
   resume_from: null
   apex_opt: O1
-  amp_dtype: bf16                 # (not in the reference) 16-bit type of the O1+ mixed-precision step: bf16 = the MI355X
-                                  # fast path (hand-written channels-last kernels, no loss scaling) | fp16 = the
-                                  # reference's apex-O1 arithmetic (half-precision library convolutions, dynamic loss scaling)
+  amp_dtype: fp16                 # (not in the reference) 16-bit type of the O1+ mixed-precision step, both on the same
+                                  # hand-written channels-last kernels: fp16 = the reference's apex-O1 arithmetic (dynamic
+                                  # loss scaling, decided on the device) | bf16 = 8 exponent bits, no loss scaling
   gpu_num: 2
   random_seed: 888
   port: 6789

@@ -63,6 +63,7 @@ def _make_trainer(root, world, rank, apex_opt):
     c.cst_training.ema_model.gamma = 0.5
     c.train.lr, c.train.optimizer, c.train.total_iter = 1e-3, "Adam", 10
     c.train.apex_opt = apex_opt
+    c.train.amp_dtype = "bf16"       # (O1 here = the 16-bit step WITHOUT loss scaling: _step() below calls backward() itself)
     c.train.gpu_num = world
     c.train.resume_from = os.path.join(root, "init.pth")
     c.work_dir = os.path.join(root, "work_w%d_%s" % (world, apex_opt))
