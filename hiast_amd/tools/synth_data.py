@@ -107,3 +107,24 @@ def synthetic_cfg(root, n_train=8, n_val=4, h=256, w=512, seed=1, num_classes=19
     c.validate.batch_size = 2
     c.work_dir = os.path.join(root, "work")
     return c
+
+
+def calibrate_bn(model, x):
+    """Give a seeded / random-init network the BatchNorm running statistics of the data it will see: one training-mode
+    forward of `x` with momentum 1 (running := batch statistics), in place.  A checkpoint whose running statistics do not
+    belong to its weights lets the activations of an eval-mode forward grow block by block (nothing renormalises them) — in
+    fp16, the reference's training type, past 65504 within the 33 blocks of a ResNet-101.  Trained checkpoints are
+    calibrated by construction; synthetic ones need this."""
+    import torch
+    bns = [m for m in model.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+    mom = [m.momentum for m in bns]
+    was = model.training
+    with torch.no_grad():
+        for m in bns:
+            m.momentum = 1.0
+        model.train()
+        model(x, lowres=True) if "lowres" in model.forward.__code__.co_varnames else model(x)
+        for m, v in zip(bns, mom):
+            m.momentum = v
+    model.train(was)
+    return model

@@ -27,12 +27,17 @@ def world(tmp_path_factory):
     cfg = synth_data.synthetic_cfg(root, n_train=6, n_val=4, h=H, w=W)
     m = MODEL["SelfTrainingSegmentor"](cfg)
     sd = {"seg_model." + k: v for k, v in seeded_state_dict(m.seg_model, 777).items()}
-    # calibrate the random-init head so that max-probs are spread over (0.1, 1): logits std ~ 3
+    # the state of a trained checkpoint as far as ranges go: running statistics = those of the data (an eval forward on
+    # statistics that do not belong to the weights grows block by block — past fp16's range), head calibrated so that
+    # max-probs are spread over (0.1, 1): logits std ~ 3
     m.load_state_dict(sd)
     m = m.cuda().eval()
-    ds = synth_data.make_sample(5, H, W)[0].astype(np.float32).transpose(2, 0, 1)[None] / 255.0
+    ds = np.stack([synth_data.make_sample(5 + i, H, W)[0].astype(np.float32).transpose(2, 0, 1) for i in range(2)]) / 255.0
+    xs = torch.from_numpy((ds - 0.45) / 0.225).cuda()
+    synth_data.calibrate_bn(m, xs)
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
     with torch.no_grad():
-        z = m(torch.from_numpy((ds - 0.45) / 0.225).cuda(), lowres=True)["logits_lowres"]
+        z = m(xs[:1], lowres=True)["logits_lowres"]
     scale = 3.0 / float(z.std())
     for i in range(4):
         sd["seg_model.aspp.conv2d_list.%d.weight" % i] = sd["seg_model.aspp.conv2d_list.%d.weight" % i] * scale

@@ -215,6 +215,12 @@ def world(tmp_path_factory):
     cfg.dataset.target.aug_type = ["PRS-%d-%d" % (H, W)]
     m = MODEL["SourceOnlySegmentor"](cfg)
     sd = {"seg_model." + k: v for k, v in seeded_state_dict(m.seg_model, 778).items()}
+    m.load_state_dict(sd)           # running statistics of the data (see synth_data.calibrate_bn: fp16 range)
+    m = m.cuda()
+    ds = np.stack([synth_data.make_sample(5 + i, H, W)[0].astype(np.float32).transpose(2, 0, 1) for i in range(2)]) / 255.0
+    synth_data.calibrate_bn(m, torch.from_numpy((ds - 0.45) / 0.225).cuda())
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    del m
     ck = os.path.join(root, "imagenet_like.pth")
     torch.save(sd, ck)
     cfg.train.resume_from = ck
