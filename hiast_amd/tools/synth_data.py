@@ -118,13 +118,16 @@ def calibrate_bn(model, x):
     import torch
     bns = [m for m in model.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
     mom = [m.momentum for m in bns]
+    nbt = [None if m.num_batches_tracked is None else m.num_batches_tracked.clone() for m in bns]
     was = model.training
     with torch.no_grad():
         for m in bns:
             m.momentum = 1.0
         model.train()
         model(x, lowres=True) if "lowres" in model.forward.__code__.co_varnames else model(x)
-        for m, v in zip(bns, mom):
+        for m, v, n in zip(bns, mom, nbt):
             m.momentum = v
+            if n is not None:
+                m.num_batches_tracked.copy_(n)       # (the calibration forward is not a training iteration)
     model.train(was)
     return model

@@ -25,6 +25,10 @@ def world(tmp_path_factory):
     from make_golden import seeded_state_dict
     root = str(tmp_path_factory.mktemp("e2e"))
     cfg = synth_data.synthetic_cfg(root, n_train=6, n_val=4, h=H, w=W)
+    # the 2-3 iteration plumbing tests below use the 16-bit type WITHOUT loss scaling: under fp16 (the default, apex O1) the
+    # first ~10 iterations of a run are skipped while the dynamic scale comes down from 2^16, as under apex — covered by
+    # tests/test_gpu_fp16.py::test_fp16_training_step_runs_the_trunk_on_the_own_kernels
+    cfg.train.amp_dtype = "bf16"
     m = MODEL["SelfTrainingSegmentor"](cfg)
     sd = {"seg_model." + k: v for k, v in seeded_state_dict(m.seg_model, 777).items()}
     # the state of a trained checkpoint as far as ranges go: running statistics = those of the data (an eval forward on

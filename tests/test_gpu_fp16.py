@@ -353,3 +353,14 @@ def test_fp16_training_step_runs_the_trunk_on_the_own_kernels(K, monkeypatch, tm
         assert calls["conv_fwd"] == [(7, 7), (7, 7)], (amp, calls["conv_fwd"])
         assert calls["igemm"] >= 2 * 28, (amp, calls["igemm"])          # 28 trunk convolutions per forward (+ data gradients)
         assert all(np.isfinite(float(v)) for v in losses.values()), (amp, losses)
+        if amp == "fp16":
+            # apex's dynamic loss scale: starts at 2^16, every overflow halves it and skips the update; within a few
+            # iterations updates are applied (device-side decision: FusedAdam.applied_steps counts them)
+            p0 = next(tr.model.module.seg_model.aspp.parameters()).detach().clone()
+            for _ in range(15):
+                losses = tr.train_on(dev(weak), dev(strong), dev(plbl))
+                tr.update_model(tr.g_optimizer, tr.d_optimizer, losses)
+            applied, scale = tr.g_optimizer.applied_steps(), float(tr.scaler.get_scale())
+            assert 1 <= applied <= 16 and scale <= 2.0 ** 16 and scale == 2.0 ** 16 / 2 ** (16 - applied), (applied, scale)
+            assert not torch.equal(p0, next(tr.model.module.seg_model.aspp.parameters()).detach()), "student did not move"
+            assert all(np.isfinite(float(v)) for v in losses.values()), losses
