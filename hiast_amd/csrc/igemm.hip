@@ -193,6 +193,11 @@ int hiast_xconv_stats_rows(int64_t M, int N);
 int hiast_xconv_launch(const void* x, const void* wp, const float* gamma, const float* beta, const float* mean,
                        const float* var, float eps, const void* res, int relu, void* y, int64_t M, int K, int N,
                        float* stats, const void* res_gate, int f16, hipStream_t st);
+// K9g (xconv2.hip): the same idea for the split-plane 256 -> N launches with BatchNorm(eval) (+ residual + ReLU)
+int hiast_xconv2_ok(int64_t M, int K, int N, int planes, int taps, int out_f32, int has_bn, int has_res, int relu,
+                    int has_gate, int has_stats);
+int hiast_xconv2_launch(const void* x, const void* wp, const float* gamma, const float* beta, const float* mean,
+                        const float* var, float eps, const void* res, int relu, void* y, int64_t M, int N, hipStream_t st);
 // igemm_f16.hip: the fp16 instantiations of the tile kernel (a translation unit of its own: build time)
 int hiast_igemm_launch_f16(const void* x, const void* wp, const float* gamma, const float* beta, const float* mean,
                            const float* var, float eps, const void* res, int relu, void* y, int64_t M, int K, int N, int taps,
@@ -236,6 +241,9 @@ static int igemm_launch_mode(const void* x, const void* wp, const float* gamma, 
         hiast_xconv_ok(M, K, N, planes, taps, out_f32, mean != nullptr, res != nullptr, relu, res_gate != nullptr, gate_mask,
                        stats != nullptr))
         return hiast_xconv_launch(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, stats, res_gate, f16, st);
+    if (stats_mode == 0 && !f16 &&
+        hiast_xconv2_ok(M, K, N, planes, taps, out_f32, mean != nullptr, res != nullptr, relu, res_gate != nullptr, stats != nullptr))
+        return hiast_xconv2_launch(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, N, st);
     if (f16)
         return hiast_igemm_launch_f16(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, stats, res_gate,
                                       gate_mask, st, stats_mode, out_f32);

@@ -115,6 +115,7 @@ __global__ __launch_bounds__(512) void xconv_kernel(const unsigned short* __rest
             s_sc[c] = sc;
             s_sh[c] = fmaf(-mean[n], sc, beta ? beta[n] : 0.0f);
         }
+        __syncthreads();                                 // (the loop's barriers are bare: they publish no LDS stores)
     }
 
     // ---- DMA: a panel = 64 rows x SL slabs = 8 row groups x SL; wave w moves row group w of every slab
@@ -147,9 +148,14 @@ __global__ __launch_bounds__(512) void xconv_kernel(const unsigned short* __rest
         // (First iteration: only the DMA of the second panel is younger.)  No scratch traffic may hide in this count:
         // the variants are built without spills (checked in the build log: private_segment_fixed_size == 0).
         constexpr int NRES = RES ? (GATE ? 8 : 4) : 0;          // residual (+ gate) loads per 32-row half
-        if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SL) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SL + 8 + NRES) : "memory");
-        __syncthreads();                                         // everyone's has; everyone left the stage of panel p - 1
+        // A bare s_barrier behind the counted wait (round 3): behind __syncthreads() the compiler (ROCm 7.2) emits
+        // `s_waitcnt vmcnt(0) lgkmcnt(0)` — every store of the previous panel had to be acknowledged by the memory side and
+        // the DMA of the next panel had to land before any wave went on, once per panel (found in the ISA of xconv2.hip;
+        // this loop had the same drain, which is what held the residual variants at 4.3 TB/s).  The fragment reads are
+        // asm with their own lgkmcnt waits, so nothing else needs the implied wait.
+        if (it == 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(SL) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(SL + 8 + NRES) : "memory");      // everyone's has landed;
+                                                                 // everyone left the stage of panel p - 1
         // residual rows (and gate bytes) of a 32-row half are requested before its MFMAs
         uint4 rres[RES ? 2 : 1][2];
         unsigned rgate[GATE ? 2 : 1][2];

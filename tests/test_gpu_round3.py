@@ -1,0 +1,91 @@
+"""Round-3 kernels: K9g (xconv2.hip) — the split-plane 256 -> N 1x1 launches of the pseudo-label forward with
+register-resident weights — against float64 on the operand values the kernel multiplies and against the tile kernel
+(HIAST_XCONV2=0) on the same inputs; K9e (xconv.hip) after its loop barrier became a bare s_barrier behind a counted wait."""
+import numpy as np
+import pytest
+import torch
+
+import synth
+from test_gpu_kernels import _igemm_ref, _mk_bn, _planes_ref, dev
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def K():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from hiast_amd import kernels
+    return kernels
+
+
+@pytest.mark.parametrize("M_hw", [(1, 64, 128), (2, 50, 77), (1, 64, 65), (8, 64, 128)])
+@pytest.mark.parametrize("Cout", [1024, 256])
+def test_xconv2_split_plane_expanding_1x1(K, M_hw, Cout, monkeypatch):
+    """conv3 of a layer3 bottleneck in the fp32-class forward (256 -> 1024, + BN(eval) + identity + ReLU): every variant of
+    the register-resident-weight kernel vs float64 and vs the tile kernel; ragged M (a tail panel with rows beyond M),
+    many panels per block (B = 8: 16 per stream), the stored planes are a valid split (hi + lo re-splits to itself)"""
+    B, H, W = M_hw
+    Cin = 256
+    x = synth.normal_f32(3100, (B, H, W, Cin))
+    w = synth.normal_f32(3101, (Cout, Cin, 1, 1), (2.0 / Cin) ** 0.5)
+    res = synth.normal_f32(3102, (B, H, W, Cout))
+    bn, bnref = _mk_bn(3103, Cout)
+    xp = K.split_planes(dev(x).view(-1, Cin)).view(B, H, W, 2 * Cin)
+    wp = K.pack_conv_weight(dev(w), 2)
+    resp = K.split_planes(dev(res).view(-1, Cout)).view(B, H, W, 2 * Cout)
+    xh, xl = _planes_ref(x)
+    wh, wl = _planes_ref(w)
+    rr = sum(_planes_ref(res))
+    lib = K._lib.load()
+    for name, r_dev, r_ref, relu in (("bn_res_relu", resp, rr, True), ("bn_relu", None, None, True), ("bn", None, None, False)):
+        guard = torch.full((64,), 7, dtype=torch.int16, device="cuda")        # canary behind the output (tail rows)
+        y = K.igemm_bn_act(xp, wp, 2, bn, r_dev, relu)
+        monkeypatch.setenv("HIAST_XCONV2", "0")
+        y_tile = K.igemm_bn_act(xp, wp, 2, bn, r_dev, relu)
+        monkeypatch.delenv("HIAST_XCONV2")
+        assert bool((guard == 7).all())
+        got = K.merge_planes(y.view(-1, 2 * Cout)).view(B, H, W, Cout).cpu().numpy()
+        want = _igemm_ref(xh + xl, wh + wl, bnref, r_ref, relu, 1, 1, 1)
+        tol = 3e-5 * max(1.0, np.abs(want).max())
+        assert np.abs(got - want).max() <= tol, (name, np.abs(got - want).max(), tol)
+        tile = K.merge_planes(y_tile.view(-1, 2 * Cout)).view(B, H, W, Cout).cpu().numpy()
+        assert np.abs(got - tile).max() <= 2e-5 * max(1.0, np.abs(want).max()), name      # another summation order only
+        v = K.merge_planes(y.view(-1, 2 * Cout))
+        assert torch.equal(K.merge_planes(K.split_planes(v)), v), name
+    # the shape really takes the new kernel (M >= 4096) — and smaller maps stay on the tile kernel
+    assert (B * H * W >= 4096)
+
+
+def test_xconv_variants_after_the_bare_barrier(K, monkeypatch):
+    """K9e with the counted wait + bare s_barrier in its panel loop: many panels per block (B = 8), both 16-bit types,
+    every epilogue variant vs the tile kernel on the same inputs (the unit tests of the variants vs float64 are
+    test_xconv_expanding_1x1 / test_xconv_fp16)"""
+    B, H, W, Cin, Cout = 8, 64, 128, 256, 1024
+    x = synth.normal_f32(3200, (B, H, W, Cin))
+    w = synth.normal_f32(3201, (Cout, Cin, 1, 1), (2.0 / Cin) ** 0.5)
+    res = synth.normal_f32(3202, (B, H, W, Cout))
+    bits = (torch.rand(B * H * W, Cout // 8, device="cuda") * 256).to(torch.uint8)
+    bn, _ = _mk_bn(3203, Cout)
+    for dt, fmt in ((torch.float16, K.FMT_FP16), (torch.bfloat16, K.FMT_BF16)):
+        xp, resp = dev(x).to(dt), dev(res).to(dt)
+        wp = K.pack_conv_weight(dev(w), fmt)
+        cases = [dict(bn=None, res=None, relu=False), dict(bn=bn, res=resp, relu=True), dict(bn=bn, res=None, relu=True),
+                 dict(bn=None, res=resp, relu=False), dict(bn=None, res=resp, relu=False, res_gate=bits)]
+        for kw in cases:
+            args = (xp, wp, 1, kw["bn"], kw["res"], kw["relu"], 1, 1)
+            extra = {k: v for k, v in kw.items() if k == "res_gate"}
+            for rep in range(3):        # (a race between panels would not repeat identically)
+                y = K.igemm_bn_act(*args, **extra)
+                if rep == 0:
+                    first = y.clone()
+                assert torch.equal(y, first), (dt, kw.keys(), rep)
+            monkeypatch.setenv("HIAST_XCONV", "0")
+            y_tile = K.igemm_bn_act(*args, **extra)
+            monkeypatch.delenv("HIAST_XCONV")
+            d = (y.float() - y_tile.float()).abs()
+            ulp = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10
+            assert float((d > ulp * y_tile.float().abs() + 1e-5).float().mean()) == 0.0, (dt, list(kw))
+        y, part = K.igemm_bn_act(xp, wp, 1, None, None, False, 1, 1, want_stats=True)
+        yd = y.float().view(-1, Cout).double()
+        sums = part.double().sum(0)
+        assert torch.allclose(sums[:, 0], yd.sum(0), rtol=1e-5, atol=1e-2) and torch.allclose(sums[:, 1], (yd * yd).sum(0), rtol=1e-5)
