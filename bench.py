@@ -177,16 +177,21 @@ def roofline_of(key, avg_ms, n, steps):
     peak = 2500.0 / 3.0 if PL == 2 else 2500.0
     alg_bytes = (B * Hh * Ww * CC + Cout * taps * CC) * 2 + M * Cout * (4 if out_f32 else 2 * PL) * (2 if has_res else 1)
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r02_pmc_igemm.json")
-    if os.path.exists(pmc):
-        for ent in json.load(open(pmc)).get("kernels", []):
-            if ent.get("key") == [B, Hh, Ww, Cin, Cout, taps, PL, dil]:
-                traffic = ent["hbm_bytes_per_launch"]
+    for pmc in ("r03_pmc_igemm.json", "r02_pmc_igemm.json"):       # (the newest collection that has this launch shape)
+        pmc = os.path.join(ROOT, "profiles", pmc)
+        if traffic is None and os.path.exists(pmc):
+            for ent in json.load(open(pmc)).get("kernels", []):
+                if ent.get("key") == [B, Hh, Ww, Cin, Cout, taps, PL, dil]:
+                    traffic = ent["hbm_bytes_per_launch"]
     is_xconv = (PL == 1 and taps == 1 and Cin == 256 and Cout % 512 == 0 and not out_f32 and M >= 4096
                 and os.environ.get("HIAST_XCONV", "1") != "0" and not (has_bn and has_res and not relu))
+    is_xconv2 = (PL == 2 and taps == 1 and Cin == 256 and Cout % 256 == 0 and not out_f32 and M >= 4096 and has_bn
+                 and os.environ.get("HIAST_XCONV2", "1") != "0" and not (has_res and not relu))
     name = ("hiast::xconv_kernel<256,...> (register-resident weights, persistent over 64-row panels; %s%s%s)"
             % ("BN" if has_bn else "plain: student forward / data gradient", " + residual" if has_res else "",
                " + ReLU" if relu else "")) if is_xconv else \
+        ("hiast::xconv2_kernel (split-bf16 planes, register-resident weights, persistent over 32-row panels; BN%s%s)"
+         % (" + residual" if has_res else "", " + ReLU" if relu else "")) if is_xconv2 else \
         "hiast::igemm_bn_act_kernel<PL=%d,%s,taps=%d> (%s LDS-DMA implicit GEMM%s%s%s)" % (
         PL, "f32out" if out_f32 else "16-bit out", taps, "split-bf16" if PL == 2 else "bf16",
         " + BN" if has_bn else " (plain: student forward / data gradient)", " + residual" if has_res else "",
