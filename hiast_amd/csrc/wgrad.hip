@@ -9,8 +9,8 @@
 // LDS exactly as they lie in memory — by LDS-DMA, 4 rows x 256 B per wave-instruction, zero rows for out-of-image
 // taps via the buffer out-of-range rule — and every fragment is built by two transposing ds_read_b64_tr_b16 reads
 // (swizzle (b) of the CDNA4 guide on 256-byte rows: conflict free for the transposed reads).
-// Block = one (256 n) x (256 k) x tap tile of dW over one pixel range; 8 waves (wave tile 128 x 64); k-step = 64
-// pixels; two LDS stages (the DMA of step t+1 flies during the MFMAs of step t).  Pixel ranges are reduced in a fixed
+// Block = one (256 n) x (256 k) x tap tile of dW over one pixel range; 8 waves (wave tile 128 x 64); k-step = 32
+// pixels; a ring of four LDS stages (the DMA of step t+3 flies during the MFMAs of step t).  Pixel ranges are reduced in a fixed
 // order by wgrad_reduce_kernel (bitwise reproducible, no float atomics), which also writes torch's [N][K][kh][kw]
 // layout.
 // The k-step (second form of round 2): the LDS-DMA is issued through inline asm and the transposing reads stay builtins —
@@ -74,17 +74,20 @@ __device__ __forceinline__ wg_bf16x8 wg_join(const wg_s16x4& v0, const wg_s16x4&
 __device__ __forceinline__ int wg_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 __device__ __forceinline__ int wg_off(int row, int ch) { return 256 * row + 16 * (ch ^ wg_swz(row)); }
 
-constexpr int WG_ROWS = 64;                       // pixels per k-step
-constexpr int WG_SUB = WG_ROWS * 256;             // one [64][128] sub-tile: 16 KiB
-constexpr int WG_STAGE = 4 * WG_SUB;              // dY (2 sub-tiles) + X (2 sub-tiles)
+constexpr int WG_ROWS = 32;                       // pixels per k-step
+constexpr int WG_SUB = WG_ROWS * 256;             // one [32][128] sub-tile: 8 KiB
+constexpr int WG_STAGE = 4 * WG_SUB;              // dY (2 sub-tiles) + X (2 sub-tiles): 32 KiB
+constexpr int WG_NST = 4;                         // stages in the LDS ring (128 KiB)
+constexpr int WG_PCS = WG_ROWS / 8;               // DMA pieces (4 rows x 256 B) per wave and k-step
 
 // F16: dY and X rows are IEEE fp16 (HIAST_FMT_FP16) instead of bf16; the kernel never decodes a value, only the MFMA differs
-template <int TAPS, bool F16 = false>
+// S1 (3x3 only): stride 1 and Wo >= 20 — the tap shift is a constant number of pixels and rides in the buffer descriptor
+template <int TAPS, bool F16 = false, bool S1 = false>
 __global__ __launch_bounds__(512) void wgrad_tn_kernel(const unsigned short* __restrict__ dY,
                                                        const unsigned short* __restrict__ X, float* __restrict__ P,
                                                        int M, int N, int K, WGeo geo, int m_per_split)
 {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * WG_STAGE];
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[WG_NST * WG_STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;             // wave tile: n rows [128*wm, +128), k cols [64*wn, +64)
@@ -114,58 +117,92 @@ __global__ __launch_bounds__(512) void wgrad_tn_kernel(const unsigned short* __r
     // Buffer descriptors that END at this block's last pixel row: the tail rows of the last k-step are out of range and
     // arrive as zeros without a per-lane test (3x3: X is addressed per input pixel and keeps its own bounds select).
     const wg_i32x4 yrs = wg_rsrc(dY, (unsigned)((size_t)m_end * N * 2));
-    const wg_i32x4 xrs = wg_rsrc(X, (unsigned)((TAPS == 1 ? (size_t)m_end : in_pix) * K * 2));
+    // S1: input pixel = output pixel + oy * W + ox.  The descriptor starts that many pixels into X (before X for the upper
+    // taps: lanes that would read there are out of the image and never sent) and ends with X, so a fetch is addressed by
+    // the OUTPUT pixel with the per-lane constants and scalar offsets of the dY rows; per lane only the in-image test is left.
+    const long long tap_bytes = S1 ? (long long)(oy * geo.W + ox) * K * 2 : 0;
+    const wg_i32x4 xrs = wg_rsrc((const unsigned char*)X + tap_bytes,
+                                 (unsigned)((long long)((TAPS == 1 ? (size_t)m_end : in_pix) * K * 2) - tap_bytes));
 
-    // DMA pieces of one k-step: 64 wave-instructions (4 sub-tiles x 16 groups of 4 rows).  Wave w owns sub-tile w >> 1
-    // (0, 1: dY columns n0.. / n0+128..; 2, 3: X columns k0.. / k0+128..) and its row groups 8*(w & 1) + pc, pc = 0..7:
-    // row = 32*(w & 1) + 4*pc + (lane >> 4), logical chunk (lane & 15) ^ swz(row) with swz(row) = ((lane>>4 & 3) << 2) |
+    // DMA pieces of one k-step: 32 wave-instructions (4 sub-tiles x 8 groups of 4 rows).  Wave w owns sub-tile w >> 1
+    // (0, 1: dY columns n0.. / n0+128..; 2, 3: X columns k0.. / k0+128..) and its row groups 4*(w & 1) + pc, pc = 0..3:
+    // row = 16*(w & 1) + 4*pc + (lane >> 4), logical chunk (lane & 15) ^ swz(row) with swz(row) = ((lane>>4 & 3) << 2) |
     // (pc & 3).  Everything that depends on pc or on the k-step but not on the lane goes into the instruction's scalar
     // offset: four per-lane offsets (pc & 3) serve all pieces.
     const int sub = wave >> 1, l4 = lane >> 4;
     const bool is_x = sub >= 2;
     const int pitch2 = (is_x ? K : N) * 2;                                    // bytes per pixel row of this wave's operand
     const int col2 = (is_x ? k0 + (sub - 2) * 128 : n0 + sub * 128) * 2;
-    const int row0 = 32 * (wave & 1) + l4;
+    const int row0 = (WG_ROWS / 2) * (wave & 1) + l4;
     int pv[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
         pv[j] = (m_begin + row0) * pitch2 + col2 + 16 * ((lane & 15) ^ (((l4 & 3) << 2) | j));
     const unsigned lds0 = (unsigned)(size_t)smem;
-    const unsigned dst0 = lds0 + (unsigned)(sub * WG_SUB + (wave & 1) * 8 * 1024);
-    // 3x3: (image, row, column) of the output pixel of this lane's row in piece 0 of k-step kt — decoded once per k-step
-    // (float reciprocal + one-step correction: exact for m < 2^24, no integer division) and walked 4 pixels per piece
-    auto issue = [&](int kt, int buf, int pc, bool on, int& d_img, int& d_yo, int& d_xo) {
+    const unsigned dst0 = lds0 + (unsigned)(sub * WG_SUB + (wave & 1) * WG_PCS * 1024);
+    // 3x3: the input pixel of this lane's row is WALKED, not decoded: (xx, yy) = input column / row incl. the tap offset and
+    // lin = its linear pixel index move 4 output pixels per piece and 20 behind the last piece of a step (the next step
+    // starts 32 on), with one row wrap and one image wrap per move (Wo >= 20; narrower maps decode every step).  All
+    // increments are scalars; the only multiply left is one 24-bit mad per piece.  (The first form decoded (image, row,
+    // column) per step and multiplied out the address per piece: five quarter-rate integer multiplies and ~40 VALU
+    // instructions per piece, 0.3 us of VALU time per 32-pixel step on the waves that fetch X — the DMA-only time of
+    // the layer4 3x3 was 207 us against 116 us for the same requests issued without the arithmetic.)
+    const int st_ = geo.stride;
+    const int xx_end = geo.Wo * st_ + ox, yy_end = geo.Ho * st_ + oy;          // first (xx, yy) behind a row / an image
+    const int wo_s = geo.Wo * st_, ho_s = geo.Ho * st_;
+    const int row_jump = st_ * geo.W - wo_s, img_jump = geo.H * geo.W - ho_s * geo.W;
+    const bool walk = geo.Wo >= 20;
+    int cx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cx[j] = col2 + 16 * ((lane & 15) ^ (((l4 & 3) << 2) | j));
+    auto decode = [&](int m, int& xx, int& yy, int& lin) {
+        // float reciprocal + one-step correction: exact for m < 2^24, no integer division
+        const int hw = geo.Ho * geo.Wo;
+        int img = (int)(((float)m + 0.5f) * inv_hw);
+        int r = m - img * hw;
+        const bool lo = r < 0, hi = r >= hw;
+        img += hi ? 1 : (lo ? -1 : 0);
+        r += lo ? hw : (hi ? -hw : 0);
+        int yo = (int)(((float)r + 0.5f) * inv_wo);
+        int xo = r - yo * geo.Wo;
+        const bool lo2 = xo < 0, hi2 = xo >= geo.Wo;
+        yo += hi2 ? 1 : (lo2 ? -1 : 0);
+        xo += lo2 ? geo.Wo : (hi2 ? -geo.Wo : 0);
+        yy = yo * st_ + oy;
+        xx = xo * st_ + ox;
+        lin = (img * geo.H + yy) * geo.W + xx;
+    };
+    auto advance = [&](int n, int& xx, int& yy, int& lin) {       // n output pixels on, n <= Wo
+        xx += n * st_;
+        lin += n * st_;
+        const bool w = xx >= xx_end;
+        xx -= w ? wo_s : 0;
+        yy += w ? st_ : 0;
+        lin += w ? row_jump : 0;
+        const bool w2 = yy >= yy_end;
+        yy -= w2 ? ho_s : 0;
+        lin += w2 ? img_jump : 0;
+    };
+    auto issue = [&](int kt, int buf, int pc, bool on, int& xx, int& yy, int& lin) {
         const unsigned dst = dst0 + (unsigned)(buf * WG_STAGE + pc * 1024);
         if (TAPS == 1 || !is_x) {
             wg_dma16(is_x ? xrs : yrs, dst, on ? pv[pc & 3] : OOB, (kt * WG_ROWS + 4 * pc) * pitch2);
+        } else if (S1) {
+            const bool ok = on & ((unsigned)yy < (unsigned)geo.H) & ((unsigned)xx < (unsigned)geo.W);
+            wg_dma16(xrs, dst, ok ? pv[pc & 3] : OOB, (kt * WG_ROWS + 4 * pc) * pitch2);
+            const int n = (pc == WG_PCS - 1) ? WG_ROWS - 4 * (WG_PCS - 1) : 4;
+            xx += n;
+            const bool w = xx >= xx_end;
+            xx -= w ? wo_s : 0;
+            yy += w ? 1 : 0;
+            yy -= (yy >= yy_end) ? ho_s : 0;
         } else {
-            if (pc == 0) {
-                const int m = m_begin + kt * WG_ROWS + row0;
-                const int hw = geo.Ho * geo.Wo;
-                int img = (int)(((float)m + 0.5f) * inv_hw);
-                int r = m - img * hw;
-                const bool lo = r < 0, hi = r >= hw;
-                img += hi ? 1 : (lo ? -1 : 0);
-                r += lo ? hw : (hi ? -hw : 0);
-                int yo = (int)(((float)r + 0.5f) * inv_wo);
-                int xo = r - yo * geo.Wo;
-                const bool lo2 = xo < 0, hi2 = xo >= geo.Wo;
-                yo += hi2 ? 1 : (lo2 ? -1 : 0);
-                xo += lo2 ? geo.Wo : (hi2 ? -geo.Wo : 0);
-                d_img = img; d_yo = yo; d_xo = xo;
-            }
-            const int m = m_begin + kt * WG_ROWS + row0 + 4 * pc;
-            const int yy = d_yo * geo.stride + oy, xx = d_xo * geo.stride + ox;
+            if (pc == 0 && !walk) decode(m_begin + kt * WG_ROWS + row0, xx, yy, lin);
+            const int m = m_begin + row0 + (kt * WG_ROWS + 4 * pc);
             const bool ok = on & (m < m_end) & ((unsigned)yy < (unsigned)geo.H) & ((unsigned)xx < (unsigned)geo.W);
-            const int voff = ((d_img * geo.H + yy) * geo.W + xx) * pitch2 + col2 + 16 * ((lane & 15) ^ (((l4 & 3) << 2) | (pc & 3)));
+            const int voff = __mul24(lin, pitch2) + cx[pc & 3];
             wg_dma16(xrs, dst, ok ? voff : OOB, 0);
-            d_xo += 4;                                   // the next piece of this wave: 4 pixels on (Wo >= 4)
-            const bool wrap = d_xo >= geo.Wo;
-            d_xo -= wrap ? geo.Wo : 0;
-            d_yo += wrap ? 1 : 0;
-            const bool wrap2 = d_yo >= geo.Ho;
-            d_yo = wrap2 ? 0 : d_yo;
-            d_img += wrap2 ? 1 : 0;
+            advance((pc == WG_PCS - 1 && walk) ? WG_ROWS - 4 * (WG_PCS - 1) : 4, xx, yy, lin);
         }
     };
 
@@ -179,7 +216,7 @@ __global__ __launch_bounds__(512) void wgrad_tn_kernel(const unsigned short* __r
 
     // transposed fragment: 32 columns starting at c0 of a sub-tile, reduction rows kb .. kb+7 for this lane half.
     // Per-lane byte offsets of the two halves (v0: rows kb + fq, v1: rows kb + 4 + fq) for kk = 0; sub-step kk adds
-    // 16 rows = 4096 bytes (the swizzle of a row does not depend on kk).
+    // 16 rows = 4096 bytes (the swizzle of a row does not depend on kk); a stage holds two sub-steps.
     const int grp4 = lane >> 4, t16 = lane & 15;
     const int fq = t16 >> 2, fp = t16 & 3;
     auto frag_off = [&](int c0, int half) {
@@ -197,39 +234,54 @@ __global__ __launch_bounds__(512) void wgrad_tn_kernel(const unsigned short* __r
 #pragma unroll
         for (int h = 0; h < 2; ++h) ob[b][h] = 2 * WG_SUB + (wn >> 1) * WG_SUB + frag_off((wn & 1) * 64 + b * 32, h);
 
-    int d_img = 0, d_yo = 0, d_xo = 0;
+    // Ring of WG_NST stages of 32 pixels.  The barrier at the top of step t says "everyone's pieces of step t + 1 have
+    // landed and everyone has left stage t - 1": the DMA of step t + 3 goes into the stage just left, a piece has two to
+    // three steps (>= 2 us) to arrive, and the first fragments of step t + 1 are read during the last MFMAs of step t — a
+    // wave comes out of the barrier with its operands in registers.  (First form: two stages of 64 pixels, the next stage
+    // requested during the current one, s_waitcnt vmcnt(0) + __syncthreads() per step, fragments read behind the barrier.)
+    // Waits are counted: at the top of step t only the 4 pieces of step t + 2 may still be in flight.
+    int w_xx = 0, w_yy = 0, w_lin = 0;                         // 3x3: (xx, yy, lin) of the walk
+    if (TAPS != 1 && is_x) decode(m_begin + row0, w_xx, w_yy, w_lin);
 #pragma unroll
-    for (int pc = 0; pc < 8; ++pc) issue(0, 0, pc, nk > 0, d_img, d_yo, d_xo);
+    for (int s0 = 0; s0 < WG_NST - 1; ++s0)
+#pragma unroll
+        for (int pc = 0; pc < WG_PCS; ++pc) issue(s0, s0, pc, s0 < nk, w_xx, w_yy, w_lin);
+    wg_bf16x8 fa[2][4], fb[2][2];                                 // fragments of the sub-steps (even | odd set)
+    auto read_set = [&](int set, const unsigned char* st, int kk) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+            fa[set][a] = wg_join(wg_tr_read(st + oa[a][0] + kk * 4096), wg_tr_read(st + oa[a][1] + kk * 4096));
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+            fb[set][b] = wg_join(wg_tr_read(st + ob[b][0] + kk * 4096), wg_tr_read(st + ob[b][1] + kk * 4096));
+    };
+    auto mfma_set = [&](int set) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[a][b] = H16<F16>::mfma32(fa[set][a], fb[set][b], acc[a][b]);
+    };
+    static_assert(WG_ROWS == 32 && WG_NST == 4 && WG_PCS == 4, "the loop below is written for two sub-steps and four stages");
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(WG_PCS * 2) : "memory");          // step 0 is there
+    read_set(0, smem, 0);
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's pieces of k-step kt have landed
-        __syncthreads();                                          // everyone's have; everyone left stage buf ^ 1
-        const bool more = kt + 1 < nk;
-        const unsigned char* st = smem + buf * WG_STAGE;
-        wg_bf16x8 fa[2][4], fb[2][2];                             // fragments of sub-steps kk (even | odd set)
-        auto read_set = [&](int set, int kk) {
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-                fa[set][a] = wg_join(wg_tr_read(st + oa[a][0] + kk * 4096), wg_tr_read(st + oa[a][1] + kk * 4096));
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-                fb[set][b] = wg_join(wg_tr_read(st + ob[b][0] + kk * 4096), wg_tr_read(st + ob[b][1] + kk * 4096));
-        };
-        read_set(0, 0);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            // two DMA pieces of the next k-step, then the fragments of the next sub-step, then this sub-step's MFMAs:
-            // reads and DMA issue ride in the shadow of the MFMAs
-            issue(kt + 1, buf ^ 1, 2 * kk, more, d_img, d_yo, d_xo);
-            issue(kt + 1, buf ^ 1, 2 * kk + 1, more, d_img, d_yo, d_xo);
-            if (kk + 1 < 4) read_set((kk + 1) & 1, kk + 1);
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-                    acc[a][b] = H16<F16>::mfma32(fa[kk & 1][a], fb[kk & 1][b], acc[a][b]);
-        }
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(WG_PCS) : "memory");
+        const bool more = kt + 3 < nk;
+        const int nbuf = (kt + 3) & 3;
+        const unsigned char* st = smem + (kt & 3) * WG_STAGE;
+        const unsigned char* stn = smem + ((kt + 1) & 3) * WG_STAGE;
+        // two DMA pieces of step kt + 3, the fragments of the next sub-step, this sub-step's MFMAs: reads and DMA issue ride
+        // in the shadow of the MFMAs
+        issue(kt + 3, nbuf, 0, more, w_xx, w_yy, w_lin);
+        issue(kt + 3, nbuf, 1, more, w_xx, w_yy, w_lin);
+        read_set(1, st, 1);
+        mfma_set(0);
+        issue(kt + 3, nbuf, 2, more, w_xx, w_yy, w_lin);
+        issue(kt + 3, nbuf, 3, more, w_xx, w_yy, w_lin);
+        read_set(0, stn, 0);                                      // (behind the last step: a stage nobody needs)
+        mfma_set(1);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (the tail's out-of-range pieces)
 
     // partial P[split][n][tap][k]
     float* Ps = P + (size_t)split * N * TAPS * K;
@@ -321,6 +373,8 @@ extern "C" int hiast_conv_wgrad_nhwc(const void* dy, const void* x, float* dw, i
     const long long M = (long long)B * Ho * Wo;
     if ((size_t)M * Cout * 2 >= (1ull << 31) || (size_t)B * H * W * Cin * 2 >= (1ull << 31) || M >= (1ll << 24))
         return HIAST_E_RANGE;
+    // 3x3: the pixel walk moves 4 columns with one row wrap; its linear pixel index feeds a 24-bit multiply
+    if (taps == 9 && (Wo < 4 || (long long)B * H * W + 64 >= (1ll << 23))) return HIAST_E_RANGE;
     const int tiles = (Cout / 256) * (Cin / 256) * taps;
     const int nsplit = hiast::wgrad_nsplit(M, tiles, taps);
     if (workspace_bytes < (size_t)nsplit * Cout * taps * Cin * sizeof(float)) return HIAST_E_WS;
@@ -329,11 +383,13 @@ extern "C" int hiast_conv_wgrad_nhwc(const void* dy, const void* x, float* dw, i
     hiast::WGeo geo = {H, W, Ho, Wo, stride, dil};
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(tiles, nsplit);
-#define WL(T, F)                                                                                                \
-    hipLaunchKernelGGL((hiast::wgrad_tn_kernel<T, F>), grid, dim3(512), 0, st, (const unsigned short*)dy,        \
+#define WL(T, F, S)                                                                                             \
+    hipLaunchKernelGGL((hiast::wgrad_tn_kernel<T, F, S>), grid, dim3(512), 0, st, (const unsigned short*)dy,     \
                        (const unsigned short*)x, (float*)workspace, (int)M, Cout, Cin, geo, mps)
-    if (taps == 1) { if (f16) WL(1, true); else WL(1, false); }
-    else { if (f16) WL(9, true); else WL(9, false); }
+    const bool s1 = stride == 1 && Wo >= 20;
+    if (taps == 1) { if (f16) WL(1, true, false); else WL(1, false, false); }
+    else if (s1) { if (f16) WL(9, true, true); else WL(9, false, true); }
+    else { if (f16) WL(9, true, false); else WL(9, false, false); }
 #undef WL
     HIAST_CHECK_LAUNCH();
     const long long total = (long long)Cout * Cin * taps / 4;           // float4 per thread (Cin % 256 == 0)

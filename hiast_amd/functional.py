@@ -365,7 +365,7 @@ class _ConvNhwcFn(torch.autograd.Function):
             else:
                 dx = K.igemm_bn_act(dy.permute(0, 2, 3, 1), wpt, 1, None, None, False, 1, dil).permute(0, 3, 1, 2)
         own_w = need_w and os.environ.get("HIAST_LIB_WGRAD", "0") != "1" and K.conv_wgrad_preferred(
-            weight.shape[1], weight.shape[0], k, stride)
+            weight.shape[1], weight.shape[0], k, stride) and (k == 1 or dy.shape[3] >= 4)
         # The weight gradient is off the critical path of the backward pass (nothing but the optimiser consumes it)
         # and MFMA-bound, while the BatchNorm backward passes that follow on the main stream are HBM-bound: in a
         # single-process run it goes to a side stream and co-runs with them (wgrad_stream_join() before the optimiser

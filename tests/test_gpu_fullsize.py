@@ -13,6 +13,18 @@ import synth
 pytestmark = pytest.mark.gpu
 
 
+def _record(line):
+    """the measured figures go to gpurun_out/r03_fullsize_parity.txt (-> profiles/), not only to the captured stdout"""
+    print(line)
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, "r03_fullsize_parity.txt"), "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
+
+
 def _calibrated_state(seed, scale_to=3.0):
     """seeded DeepLab_V2 weights whose head is rescaled so that the logits have std ~ scale_to (max-probs spread over
     (1/C, 1) like a trained net's, instead of the near-uniform softmax of a 0.01-std random head)"""
@@ -60,8 +72,8 @@ def test_eval_forward_at_baseline_size_vs_oracle(size):
     assert torch.equal(got.argmax(1)[clear], want.argmax(1)[clear])
     differ = float((got.argmax(1) != want.argmax(1)).float().mean())
     assert differ <= 2e-3, differ
-    print("size %dx%d: max|d|/max|ref| = %.2e, max rel = %.2e, argmax differs on %.2e of the low-res pixels"
-          % (H, W, float(err.max()) / scale, float(rel.max()), differ))
+    _record("forward %dx%d (fp32-class trunk vs torch-CPU oracle): max|d|/max|ref| = %.2e, max rel = %.2e, argmax differs on "
+            "%.2e of the low-res pixels" % (H, W, float(err.max()) / scale, float(rel.max()), differ))
 
 
 def test_generator_labels_from_device_forward_vs_oracle_forward():
@@ -88,7 +100,8 @@ def test_generator_labels_from_device_forward_vs_oracle_forward():
     am_diff = float((am.cpu().numpy() != am_o).mean())
     lbl_diff = float((plbl.cpu().numpy() != plbl_o).mean())
     thr_diff = float(np.abs(thr - st.class_threshold).max())
-    print("argmax differs on %.2e, pseudo labels on %.2e of %d pixels; thresholds by %.2e" % (am_diff, lbl_diff, plbl_o.size, thr_diff))
+    _record("generator 512x1024, B=2 (device forward + HIP pass 1 / IAS / pass 2 vs oracle forward + list / np.quantile IAS): "
+            "argmax differs on %.2e, pseudo labels on %.2e of %d pixels; thresholds by %.2e" % (am_diff, lbl_diff, plbl_o.size, thr_diff))
     assert am_diff <= 1e-3 and lbl_diff <= 5e-3 and thr_diff <= 2e-3
     keep = float((plbl_o != 255).mean())
     assert 0.05 < keep < 0.95, "the calibrated head should leave a mix of kept and ignored pixels (%.3f)" % keep

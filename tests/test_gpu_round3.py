@@ -89,3 +89,27 @@ def test_xconv_variants_after_the_bare_barrier(K, monkeypatch):
         yd = y.float().view(-1, Cout).double()
         sums = part.double().sum(0)
         assert torch.allclose(sums[:, 0], yd.sum(0), rtol=1e-5, atol=1e-2) and torch.allclose(sums[:, 1], (yd * yd).sum(0), rtol=1e-5)
+
+
+@pytest.mark.parametrize("cfg", [(3, 256, 256, 9, 12, 3, 2, 1),      # narrow map: the pixel position is decoded every step
+                                 (2, 256, 256, 33, 24, 3, 1, 2),     # stride 2, Wo = 12: decoded, input pixel != output pixel
+                                 (2, 256, 512, 31, 48, 3, 2, 2),     # stride 2, Wo = 24: the walked form with row / image jumps
+                                 (5, 512, 256, 7, 20, 3, 3, 1),      # stride 1, Wo = 20: tap shift in the descriptor, a 20-pixel
+                                                                     # move crosses a whole row; taps reach 3 rows out of 7
+                                 (2, 256, 256, 64, 128, 3, 12, 1),   # dilation 12 (the shift is 12 rows + 12 pixels)
+                                 (1, 256, 256, 21, 37, 3, 1, 1)])    # odd sizes: ragged last range, lanes past the last pixel
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_conv_wgrad_pixel_walk_forms(K, cfg, dt):
+    """K9d after round 3's k-loop (ring of four 32-pixel stages) and 3x3 addressing (stride 1: tap shift in the buffer
+    descriptor + in-image test per lane; otherwise a walked or decoded input pixel) against the fp32 weight gradient of the
+    same 16-bit operands, every form, both types; bitwise repeatable"""
+    B, Cin, Cout, H, W, k, dil, stride = cfg
+    x = dev(synth.normal_f32(3300, (B, H, W, Cin))).to(dt)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    dy = dev(synth.normal_f32(3301, (B, Ho, Wo, Cout))).to(dt)
+    dw = K.conv_wgrad_nhwc(dy, x, k, stride, dil)
+    ref = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2).float(), (Cout, Cin, k, k), dy.permute(0, 3, 1, 2).float(),
+                                      stride=stride, padding=dil, dilation=dil)
+    err = (dw - ref).abs().max().item()
+    assert err <= 1e-4 * ref.abs().max().item(), (cfg, err, ref.abs().max().item())
+    assert torch.equal(dw, K.conv_wgrad_nhwc(dy, x, k, stride, dil))
