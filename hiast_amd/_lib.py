@@ -21,7 +21,8 @@ SIGNATURES = {
     "hiast_error_string": (ctypes.c_char_p, [c_int]),
     "hiast_upsample_bilinear_ac_fwd": (c_int, [c_vp, c_vp] + [c_int] * 6 + [c_vp]),
     "hiast_upsample_bilinear_ac_bwd": (c_int, [c_vp, c_vp] + [c_int] * 6 + [c_vp]),
-    "hiast_plabel_pass1": (c_int, [c_vp] + [c_int] * 6 + [c_vp, c_vp, c_vp, c_vp]),
+    "hiast_plabel_pass1_workspace_bytes": (c_sz, [c_int]),
+    "hiast_plabel_pass1": (c_int, [c_vp] + [c_int] * 6 + [c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "hiast_plabel_pass2": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "hiast_plabel_strided_hist_workspace_bytes": (c_sz, [c_i64, c_int]),
     "hiast_plabel_strided_hist": (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
@@ -110,7 +111,7 @@ def load():
             raise HiastLibraryError("libhiast_hip.so does not export %s" % name) from e
         fn.restype = res
         fn.argtypes = args
-    if lib.hiast_version() != 2:
+    if lib.hiast_version() != 3:
         raise HiastLibraryError("libhiast_hip.so ABI version mismatch")
     _lib = lib
     return lib

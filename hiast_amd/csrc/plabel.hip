@@ -13,7 +13,29 @@
 
 namespace hiast {
 
+// Scattered histogram layout of the pass-1 workspace.  On real maps a few classes and the confidences 0.5 .. 1 take nearly
+// all pixels: in the natural [class][bin] layout their ~2000 counters are ~60 lines of 128 B, and integer atomics on
+// one line execute one after the other at the memory side (tools/micro/int_atomics.hip: 3.1 M adds inside 60 lines 0.42 ms,
+// over >= 240 lines 0.12 ms = the chip's rate of 26 G atomics/s).  The workspace stores counter (class c, bin) at word
+// ((bin & 255) * C + c) * 61 + (bin >> 8): neighbouring bins are 256 planes apart, the hot counters lie on several hundred
+// lines.  hist_merge_kernel adds the workspace into the caller's [class][bin] histogram.
+constexpr int HIST_PLANE = (HIAST_NBINS + 255) / 256;                 // 61 words per (low byte, class)
 template <int C>
+__device__ __forceinline__ unsigned hist_slot(unsigned key)
+{
+    const unsigned c = key / HIAST_NBINS, bin = key - c * HIAST_NBINS;
+    return ((bin & 255u) * C + c) * HIST_PLANE + (bin >> 8);
+}
+template <int C>
+__global__ __launch_bounds__(256) void hist_merge_kernel(const uint32_t* __restrict__ ws, uint32_t* __restrict__ hist)
+{
+    const unsigned key = blockIdx.x * 256u + threadIdx.x;
+    if (key >= (unsigned)C * HIAST_NBINS) return;
+    const unsigned v = ws[hist_slot<C>(key)];
+    if (v) hist[key] += v;                       // (one thread per counter; calls on one stream are ordered)
+}
+
+template <int C, bool SCATTER>
 __global__ __launch_bounds__(256) void plabel_pass1_kernel(
     const float* __restrict__ logits, int h, int w, int H, int W, float sh, float sw,
     float* __restrict__ maxprob, uint8_t* __restrict__ argmax, uint32_t* __restrict__ hist)
@@ -85,27 +107,37 @@ __global__ __launch_bounds__(256) void plabel_pass1_kernel(
             const int leader = __ffsll((long long)todo) - 1;
             const unsigned k = __shfl(key, leader, 64);
             const unsigned long long same = __ballot(key == k);
-            if (lane_id() == leader) atomicAdd(&hist[k], (unsigned)__popcll(same));
+            if (lane_id() == leader) atomicAdd(&hist[SCATTER ? hist_slot<C>(k) : k], (unsigned)__popcll(same));
             todo &= ~same;
         }
-        if ((todo >> lane_id()) & 1ull) atomicAdd(&hist[key], 1u);
+        if ((todo >> lane_id()) & 1ull) atomicAdd(&hist[SCATTER ? hist_slot<C>(key) : key], 1u);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < C * TOPB; i += 256) {
         const unsigned v = s_top[i];
-        if (v) atomicAdd(&hist[(unsigned)(i / TOPB) * HIAST_NBINS + (HIAST_NBINS - TOPB) + (unsigned)(i % TOPB)], v);
+        const unsigned k = (unsigned)(i / TOPB) * HIAST_NBINS + (HIAST_NBINS - TOPB) + (unsigned)(i % TOPB);
+        if (v) atomicAdd(&hist[SCATTER ? hist_slot<C>(k) : k], v);
     }
 }
 
 template <int C>
 static int launch_pass1(const float* logits, int B, int h, int w, int H, int W, float* maxprob,
-                        uint8_t* argmax, uint32_t* hist, hipStream_t st)
+                        uint8_t* argmax, uint32_t* hist, uint32_t* ws, hipStream_t st)
 {
     const float sh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.0f;
     const float sw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.0f;
     dim3 grid((W + 255) / 256, h, B);
-    hipLaunchKernelGGL(plabel_pass1_kernel<C>, grid, dim3(256), 0, st, logits, h, w, H, W, sh, sw,
-                       maxprob, argmax, hist);
+    if (ws) {
+        const hipError_t e0 = hipMemsetAsync(ws, 0, (size_t)256 * C * HIST_PLANE * sizeof(uint32_t), st);
+        if (e0 != hipSuccess) return (int)e0;
+        hipLaunchKernelGGL((plabel_pass1_kernel<C, true>), grid, dim3(256), 0, st, logits, h, w, H, W, sh, sw, maxprob,
+                           argmax, ws);
+        HIAST_CHECK_LAUNCH();
+        hipLaunchKernelGGL(hist_merge_kernel<C>, dim3((C * HIAST_NBINS + 255) / 256), dim3(256), 0, st, ws, hist);
+    } else {
+        hipLaunchKernelGGL((plabel_pass1_kernel<C, false>), grid, dim3(256), 0, st, logits, h, w, H, W, sh, sw, maxprob,
+                           argmax, hist);
+    }
     HIAST_CHECK_LAUNCH();
     return 0;
 }
@@ -196,19 +228,26 @@ __global__ __launch_bounds__(256) void plabel_pass2_kernel(
 
 }  // namespace hiast
 
+extern "C" size_t hiast_plabel_pass1_workspace_bytes(int C)
+{
+    return C > 0 && C <= HIAST_MAX_CLASSES ? (size_t)256 * C * hiast::HIST_PLANE * sizeof(uint32_t) : 0;
+}
+
 extern "C" int hiast_plabel_pass1(const float* logits_lr, int B, int C, int h, int w, int H, int W,
-                                  float* maxprob, uint8_t* argmax, uint32_t* hist,
-                                  hiast_stream_t stream)
+                                  float* maxprob, uint8_t* argmax, uint32_t* hist, void* workspace,
+                                  size_t workspace_bytes, hiast_stream_t stream)
 {
     if (!logits_lr || !maxprob || !argmax || !hist) return HIAST_E_ARG;
     if (B <= 0 || C <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return HIAST_E_ARG;
     if (H < h || W < w || B > 65535 || h > 65535) return HIAST_E_RANGE;
+    if (workspace && (workspace_bytes < hiast_plabel_pass1_workspace_bytes(C) || (((uintptr_t)workspace) & 3))) return HIAST_E_WS;
     hipStream_t st = (hipStream_t)stream;
+    uint32_t* ws = (uint32_t*)workspace;
     switch (C) {
-        case 19: return hiast::launch_pass1<19>(logits_lr, B, h, w, H, W, maxprob, argmax, hist, st);
-        case 16: return hiast::launch_pass1<16>(logits_lr, B, h, w, H, W, maxprob, argmax, hist, st);
-        case 9: return hiast::launch_pass1<9>(logits_lr, B, h, w, H, W, maxprob, argmax, hist, st);
-        case 2: return hiast::launch_pass1<2>(logits_lr, B, h, w, H, W, maxprob, argmax, hist, st);
+        case 19: return hiast::launch_pass1<19>(logits_lr, B, h, w, H, W, maxprob, argmax, hist, ws, st);
+        case 16: return hiast::launch_pass1<16>(logits_lr, B, h, w, H, W, maxprob, argmax, hist, ws, st);
+        case 9: return hiast::launch_pass1<9>(logits_lr, B, h, w, H, W, maxprob, argmax, hist, ws, st);
+        case 2: return hiast::launch_pass1<2>(logits_lr, B, h, w, H, W, maxprob, argmax, hist, ws, st);
         default: return HIAST_E_RANGE;   // class counts of the reference's datasets (19 / 9) + tests
     }
 }

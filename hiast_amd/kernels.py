@@ -70,6 +70,9 @@ def upsample_bilinear_ac_bwd(gout, h, w):
 
 
 # ------------------------------------------------------------------------------- K3/K4 pseudo labels
+_pass1_ws = {}
+
+
 def plabel_pass1(logits_lr, H, W, hist=None):
     """-> (maxprob f32 [B,H,W], argmax u8 [B,H,W], hist u32-as-int32 [C,NBINS] (accumulated))"""
     _req(logits_lr, torch.float32, 4, "logits_lr")
@@ -83,8 +86,16 @@ def plabel_pass1(logits_lr, H, W, hist=None):
         _req(hist, torch.int32, 2, "hist")
         assert tuple(hist.shape) == (C, NBINS)
     if B:
-        check(_lib.load().hiast_plabel_pass1(_ptr(logits_lr), B, C, h, w, H, W, _ptr(maxprob), _ptr(argmax),
-                                             _ptr(hist), _stream()), "hiast_plabel_pass1")
+        lib = _lib.load()
+        # scattered counting copy of the histogram (hot counters on different memory lines): one per device and stream,
+        # zeroed by the call; a second launch adds it into hist
+        key = (dev, torch.cuda.current_stream(dev).cuda_stream, C)
+        ws = _pass1_ws.get(key)
+        if ws is None:
+            ws = torch.empty(lib.hiast_plabel_pass1_workspace_bytes(C) // 4, dtype=torch.int32, device=dev)
+            _pass1_ws[key] = ws
+        check(lib.hiast_plabel_pass1(_ptr(logits_lr), B, C, h, w, H, W, _ptr(maxprob), _ptr(argmax), _ptr(hist), _ptr(ws),
+                                     ws.numel() * 4, _stream()), "hiast_plabel_pass1")
     return maxprob, argmax, hist
 
 

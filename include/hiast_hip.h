@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HIAST_ABI_VERSION 2
+#define HIAST_ABI_VERSION 3
 
 #define HIAST_E_ARG   (-1) /* null pointer / non-positive extent */
 #define HIAST_E_RANGE (-2) /* extent outside what the kernels are built for */
@@ -73,10 +73,15 @@ int hiast_upsample_bilinear_ac_bwd(const float* gout, float* gin, int B, int C, 
  * logits_lr [B,C,h,w] (low-res head output; h==H,w==W accepted) ->
  *   maxprob f32 [B,H,W], argmax u8 [B,H,W] (first max on ties),
  *   hist u32 [C,HIAST_NBINS] += count of pixels of class c whose fp16(maxprob) has
- *   bit pattern `bin` (caller zeroes hist; bins accumulate across calls). */
+ *   bit pattern `bin` (caller zeroes hist; bins accumulate across calls).
+ * workspace (optional, hiast_plabel_pass1_workspace_bytes(C) bytes, 4-byte aligned, private to
+ * the call until the stream has passed it): the kernel counts into a scattered copy of the
+ * histogram there (hot counters on different memory lines) and a second launch adds it into
+ * hist; NULL = count straight into hist (same sums, slower on peaked class distributions). */
+size_t hiast_plabel_pass1_workspace_bytes(int C);
 int hiast_plabel_pass1(const float* logits_lr, int B, int C, int h, int w, int H, int W,
-                       float* maxprob, uint8_t* argmax, uint32_t* hist,
-                       hiast_stream_t stream);
+                       float* maxprob, uint8_t* argmax, uint32_t* hist, void* workspace,
+                       size_t workspace_bytes, hiast_stream_t stream);
 
 /* ---- K4: pseudo-label pass 2 -------------------------------------------------------
  * BasePseudoGenerator.select_and_save_confident_label, pseudo_label_generator.py:67-105:

@@ -113,3 +113,36 @@ def test_conv_wgrad_pixel_walk_forms(K, cfg, dt):
     err = (dw - ref).abs().max().item()
     assert err <= 1e-4 * ref.abs().max().item(), (cfg, err, ref.abs().max().item())
     assert torch.equal(dw, K.conv_wgrad_nhwc(dy, x, k, stride, dil))
+
+
+@pytest.mark.parametrize("C", [19, 16, 9, 2])
+def test_plabel_pass1_scattered_workspace_equals_direct_counting(K, C):
+    """K3 with the scattered counting workspace (round 3) vs counting straight into the histogram (workspace = NULL): same
+    maps, same integer histogram, on a peaked class distribution (two dominant classes, spatially smooth confidences: the
+    case the workspace exists for); the histogram accumulates across calls and the workspace is re-zeroed by every call"""
+    import ctypes
+    g = torch.Generator(device="cuda").manual_seed(3400 + C)
+    B, h, w, H, W = 3, 24, 40, 187, 317
+    z = torch.nn.functional.interpolate(torch.randn(B, C, 5, 7, device="cuda", generator=g) * 5.0, size=(h, w), mode="bilinear",
+                                        align_corners=True).contiguous()
+    z[:, 0] += 4.0
+    z[:, C - 1] += 3.0
+    mp, am, hist = K.plabel_pass1(z, H, W)
+    lib = K._lib.load()
+    mp0 = torch.empty_like(mp)
+    am0 = torch.empty_like(am)
+    hist0 = torch.zeros_like(hist)
+    rc = lib.hiast_plabel_pass1(ctypes.c_void_p(z.data_ptr()), B, C, h, w, H, W, ctypes.c_void_p(mp0.data_ptr()),
+                                ctypes.c_void_p(am0.data_ptr()), ctypes.c_void_p(hist0.data_ptr()), None, 0,
+                                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    assert torch.equal(mp, mp0) and torch.equal(am, am0) and torch.equal(hist, hist0)
+    assert int(hist.sum()) == B * H * W
+    _, _, hist2 = K.plabel_pass1(z, H, W, hist.clone())
+    assert torch.equal(hist2, 2 * hist)
+    # a workspace that is too small is refused, not overrun
+    small = torch.empty(16, dtype=torch.int32, device="cuda")
+    rc = lib.hiast_plabel_pass1(ctypes.c_void_p(z.data_ptr()), B, C, h, w, H, W, ctypes.c_void_p(mp0.data_ptr()),
+                                ctypes.c_void_p(am0.data_ptr()), ctypes.c_void_p(hist0.data_ptr()), ctypes.c_void_p(small.data_ptr()),
+                                64, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == -3
