@@ -35,24 +35,23 @@ __global__ __launch_bounds__(256) void hist_merge_kernel(const uint32_t* __restr
     if (v) hist[key] += v;                       // (one thread per counter; calls on one stream are ordered)
 }
 
-template <int C, bool SCATTER>
-__global__ __launch_bounds__(256) void plabel_pass1_kernel(
-    const float* __restrict__ logits, int h, int w, int H, int W, float sh, float sw,
-    float* __restrict__ maxprob, uint8_t* __restrict__ argmax, uint32_t* __restrict__ hist)
+// One work item of pass 1: 256 output columns (tile xt) of one band j of image b; thread t owns one column.
+// MODE 0: counts straight into hist [C][NBINS]; 1: into the scattered workspace; both count the top TOPB bins in LDS
+// (s_cnt = unsigned [C * TOPB], one block = one item).  MODE 2: all bins >= 0.5 (fp16 0x3800 .. 0x3C00) are counted in LDS
+// as packed 16-bit pairs (s_cnt = unsigned [C * UPW]) by a persistent block that works through many items before it
+// flushes; the rest goes to the scattered workspace.
+constexpr int TOPB = 128;
+constexpr int UPLO = 0x3800;                                          // fp16(0.5)
+constexpr int UPW = (HIAST_NBINS - UPLO + 1) / 2;                     // 513 words per class
+template <int C, int MODE>
+__device__ __forceinline__ void pass1_item(const float* __restrict__ logits, int h, int w, int H, int W, float sh, float sw,
+                                           float* __restrict__ maxprob, uint8_t* __restrict__ argmax,
+                                           uint32_t* __restrict__ hist, unsigned* s_cnt, int b, int j, int xt, int t)
 {
-    // The TOP fp16 bins (confidence >= 1 - 128 * 2^-11 ~ 0.94) of every class are counted in LDS first and flushed once
-    // per block: on confident predictions most pixels of the whole batch fall into a handful of (class, bin) counters,
-    // and their global atomics serialise in the L2 (0.99 ms per 8-image batch with every lane adding to global memory).
-    constexpr int TOPB = 128;
-    __shared__ unsigned s_top[C * TOPB];
-    for (int i = threadIdx.x; i < C * TOPB; i += 256) s_top[i] = 0u;
-    __syncthreads();
-    const int b = blockIdx.z;
-    const int j = blockIdx.y;                       // band: source rows (j, j+1)
-    const int X = blockIdx.x * 256 + threadIdx.x;
+    const int X = xt * 256 + t;
     const int Y0 = band_start(sh, j, h, H);
     const int Y1 = band_start(sh, j + 1, h, H);
-    if (Y0 >= Y1) return;                           // block-uniform (nothing was counted)
+    if (Y0 >= Y1) return;                           // uniform over the item (nothing is counted)
     const bool live = X < W;
     const int Xc = live ? X : W - 1;
 
@@ -91,15 +90,22 @@ __global__ __launch_bounds__(256) void plabel_pass1_kernel(
             maxprob[o] = prob;
             argmax[o] = (uint8_t)am;
             const unsigned bin = __half_as_ushort(__float2half_rn(prob));
-            if (bin >= HIAST_NBINS - TOPB && bin < HIAST_NBINS)
-                atomicAdd(&s_top[am * TOPB + (int)(bin - (HIAST_NBINS - TOPB))], 1u);
-            else if (bin < HIAST_NBINS) key = (unsigned)am * HIAST_NBINS + bin;
+            if (MODE == 2) {
+                if (bin >= (unsigned)UPLO && bin < HIAST_NBINS) {
+                    const unsigned i = bin - UPLO;
+                    atomicAdd(&s_cnt[am * UPW + (int)(i >> 1)], (i & 1u) ? 65536u : 1u);
+                } else if (bin < HIAST_NBINS) key = (unsigned)am * HIAST_NBINS + bin;
+            } else {
+                if (bin >= HIAST_NBINS - TOPB && bin < HIAST_NBINS)
+                    atomicAdd(&s_cnt[am * TOPB + (int)(bin - (HIAST_NBINS - TOPB))], 1u);
+                else if (bin < HIAST_NBINS) key = (unsigned)am * HIAST_NBINS + bin;
+            }
         }
-        // Histogram update.  Two wave-aggregated rounds take out the keys many lanes share (flat regions: one saturated
-        // bin per class — 64 same-address atomics would serialise in the L2), the lanes that are left add their own
-        // count: on realistic confidences nearly every lane of a wave holds a different (class, fp16 bin) key, and the
-        // fully aggregated loop then ran 64 ballot / shuffle rounds per wave row (1.85 ms per 8-image batch; the integer
-        // sums are the same in any order).
+        // Histogram update of the keys not counted in LDS.  Two wave-aggregated rounds take out the keys many lanes share
+        // (flat regions: 64 same-address atomics would serialise), the lanes that are left add their own count: on
+        // realistic confidences nearly every lane of a wave holds a different (class, fp16 bin) key, and the fully
+        // aggregated loop then ran 64 ballot / shuffle rounds per wave row (1.85 ms per 8-image batch; the integer sums
+        // are the same in any order).
         unsigned long long todo = __ballot(key != 0xFFFFFFFFu);
 #pragma unroll
         for (int round = 0; round < 2; ++round) {
@@ -107,16 +113,72 @@ __global__ __launch_bounds__(256) void plabel_pass1_kernel(
             const int leader = __ffsll((long long)todo) - 1;
             const unsigned k = __shfl(key, leader, 64);
             const unsigned long long same = __ballot(key == k);
-            if (lane_id() == leader) atomicAdd(&hist[SCATTER ? hist_slot<C>(k) : k], (unsigned)__popcll(same));
+            if (lane_id() == leader) atomicAdd(&hist[MODE ? hist_slot<C>(k) : k], (unsigned)__popcll(same));
             todo &= ~same;
         }
-        if ((todo >> lane_id()) & 1ull) atomicAdd(&hist[SCATTER ? hist_slot<C>(key) : key], 1u);
+        if ((todo >> lane_id()) & 1ull) atomicAdd(&hist[MODE ? hist_slot<C>(key) : key], 1u);
     }
+}
+
+template <int C, bool SCATTER>
+__global__ __launch_bounds__(256) void plabel_pass1_kernel(
+    const float* __restrict__ logits, int h, int w, int H, int W, float sh, float sw,
+    float* __restrict__ maxprob, uint8_t* __restrict__ argmax, uint32_t* __restrict__ hist)
+{
+    // The TOP fp16 bins (confidence >= 1 - 128 * 2^-11 ~ 0.94) of every class are counted in LDS first and flushed once
+    // per block: on confident predictions most pixels of the whole batch fall into a handful of (class, bin) counters
+    // (0.99 ms per 8-image batch with every lane adding to global memory).
+    __shared__ unsigned s_top[C * TOPB];
+    for (int i = threadIdx.x; i < C * TOPB; i += 256) s_top[i] = 0u;
+    __syncthreads();
+    pass1_item<C, SCATTER ? 1 : 0>(logits, h, w, H, W, sh, sw, maxprob, argmax, hist, s_top, blockIdx.z, blockIdx.y, blockIdx.x,
+                                   threadIdx.x);
     __syncthreads();
     for (int i = threadIdx.x; i < C * TOPB; i += 256) {
         const unsigned v = s_top[i];
         const unsigned k = (unsigned)(i / TOPB) * HIAST_NBINS + (HIAST_NBINS - TOPB) + (unsigned)(i % TOPB);
         if (v) atomicAdd(&hist[SCATTER ? hist_slot<C>(k) : k], v);
+    }
+}
+
+// Persistent form (round 3): 1024 threads = four 256-column groups that share ONE LDS histogram of the bins >= 0.5 and work
+// through `chunk` items each between flushes (host: 4 * chunk * pixels per item < 65536, the packed counters cannot
+// overflow).  On real maps two or three classes and the confidences 0.5 .. 1 hold nearly all pixels — about 2000 hot
+// counters; a 2300-pixel item has ~1 pixel per hot counter (aggregating per item saves nothing: 2.9 M global atomics per
+// batch either way, in chains of ~1000 per address), a block that counts 18 000 pixels before it flushes sends each hot
+// counter once: ~0.5 M atomics in chains of <= 256.
+template <int C>
+__global__ __launch_bounds__(1024) void plabel_pass1_persistent_kernel(
+    const float* __restrict__ logits, int h, int w, int H, int W, float sh, float sw, float* __restrict__ maxprob,
+    uint8_t* __restrict__ argmax, uint32_t* __restrict__ ws, int nx, int items, int chunk)
+{
+    __shared__ unsigned s_up[C * UPW];
+    const int tid = threadIdx.x, sub = tid >> 8, t = tid & 255;
+    for (int i = tid; i < C * UPW; i += 1024) s_up[i] = 0u;
+    __syncthreads();
+    const int groups = gridDim.x * 4, g = blockIdx.x * 4 + sub;
+    const int per_group = (items + groups - 1) / groups;              // every group runs the same number of rounds
+    for (int k0 = 0; k0 < per_group; k0 += chunk) {
+        const int k1 = k0 + chunk < per_group ? k0 + chunk : per_group;
+        for (int k = k0; k < k1; ++k) {
+            const int it = k * groups + g;                            // x tile fastest, then band, then image
+            if (it < items) {
+                const int xt = it % nx, r = it / nx;
+                pass1_item<C, 2>(logits, h, w, H, W, sh, sw, maxprob, argmax, ws, s_up, r / h, r % h, xt, t);
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < C * UPW; i += 1024) {
+            const unsigned v = s_up[i];
+            if (v) {
+                const unsigned c = (unsigned)i / UPW, p = (unsigned)i % UPW;
+                const unsigned k = c * HIAST_NBINS + UPLO + 2u * p;
+                if (v & 0xFFFFu) atomicAdd(&ws[hist_slot<C>(k)], v & 0xFFFFu);
+                if (v >> 16) atomicAdd(&ws[hist_slot<C>(k + 1u)], v >> 16);
+                s_up[i] = 0u;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -127,7 +189,21 @@ static int launch_pass1(const float* logits, int B, int h, int w, int H, int W, 
     const float sh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.0f;
     const float sw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.0f;
     dim3 grid((W + 255) / 256, h, B);
-    if (ws) {
+    // a band holds the output rows Y with floor(Y * (h-1)/(H-1)) == j: at most (H-1)/(h-1) + 2 of them; the persistent form
+    // needs 4 * chunk * 256 * rows < 65536 (packed LDS counters)
+    const int rows = h > 1 ? (H - 1) / (h - 1) + 2 : H;
+    const int nx = (W + 255) / 256;
+    const long long items = (long long)nx * h * B;
+    const int chunk = 65535 / (4 * 256 * rows);
+    if (ws && chunk >= 1 && items < (1ll << 30)) {
+        const hipError_t e0 = hipMemsetAsync(ws, 0, (size_t)256 * C * HIST_PLANE * sizeof(uint32_t), st);
+        if (e0 != hipSuccess) return (int)e0;
+        const int blocks = (int)(items / 4 < 256 ? (items + 3) / 4 : 256);
+        hipLaunchKernelGGL(plabel_pass1_persistent_kernel<C>, dim3(blocks), dim3(1024), 0, st, logits, h, w, H, W, sh, sw,
+                           maxprob, argmax, ws, nx, (int)items, chunk);
+        HIAST_CHECK_LAUNCH();
+        hipLaunchKernelGGL(hist_merge_kernel<C>, dim3((C * HIAST_NBINS + 255) / 256), dim3(256), 0, st, ws, hist);
+    } else if (ws) {
         const hipError_t e0 = hipMemsetAsync(ws, 0, (size_t)256 * C * HIST_PLANE * sizeof(uint32_t), st);
         if (e0 != hipSuccess) return (int)e0;
         hipLaunchKernelGGL((plabel_pass1_kernel<C, true>), grid, dim3(256), 0, st, logits, h, w, H, W, sh, sw, maxprob,
