@@ -86,16 +86,22 @@ __global__ __launch_bounds__(256) void aspp2_pack_kernel(const float* __restrict
 // Block = 64 consecutive pixels of one image; a 32-lane half-wave owns one pixel at a time (lane = co), so a
 // tap read is one contiguous Cout*4-byte segment; results go through LDS so that the NCHW store is
 // 64 consecutive pixels per channel.
-__global__ __launch_bounds__(256) void aspp2_shift_add_kernel(const float* __restrict__ T,
+// TT: 0 = T is fp32 (fp32 / bf16 rows, split planes), 2 = fp16: the fp16 forward stores the tap products in the type of its
+// activations (half the bytes of the head's largest tensor, written and read once; the reference's apex-O1 head rounds each
+// dilated convolution's output to fp16 and adds the four in fp16).
+template <int TT>
+__global__ __launch_bounds__(256) void aspp2_shift_add_kernel(const void* __restrict__ Tv,
                                                               const float* __restrict__ bias, float* __restrict__ y,
                                                               int h, int w, int Cout, int NP, Taps2 taps)
 {
+    const float* T = reinterpret_cast<const float*>(Tv);
+    const unsigned short* T16 = reinterpret_cast<const unsigned short*>(Tv);
     __shared__ float s[64][33];
     const int hw = h * w;
     const int b = blockIdx.y;
     const int p0 = blockIdx.x * 64;
     const int co = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const float* Tb = T + (size_t)b * hw * NP;
+    const size_t tb = (size_t)b * hw * NP;
     const float bv = co < Cout ? bias[co] : 0.f;
     for (int i = grp; i < 64; i += 8) {
         const int q = p0 + i;
@@ -108,7 +114,8 @@ __global__ __launch_bounds__(256) void aspp2_shift_add_kernel(const float* __res
             for (int t = 0; t < A2_NTAP; ++t) {
                 const int yy = qy + taps.dy[t], xx = qx + taps.dx[t];
                 const bool in = yy >= 0 && yy < h && xx >= 0 && xx < w;
-                const float v = Tb[(size_t)(in ? yy * w + xx : q) * NP + t * Cout + co];
+                const size_t at = tb + (size_t)(in ? yy * w + xx : q) * NP + t * Cout + co;
+                const float v = TT == 0 ? T[at] : (TT == 1 ? H16<false>::dec(T16[at]) : H16<true>::dec(T16[at]));
                 acc = in ? acc + v : acc;
             }
         }
@@ -392,15 +399,22 @@ extern "C" int hiast_aspp2_fwd(const void* x_nhwc, int dtype, const void* wt, co
     if ((((uintptr_t)x_nhwc) | ((uintptr_t)workspace) | ((uintptr_t)wt)) & 15) return HIAST_E_RANGE;
     hipStream_t st = (hipStream_t)stream;
     float* T = (float*)workspace;
+    // fp16 rows (the reference's apex-O1 type): the tap products are stored as fp16 (HIAST_ASPP_T32=1: fp32, the round-2
+    // form).  bf16 rows keep the fp32 T: 8 significant bits per tap product would double the error of that forward.
+    static const bool t32 = [] { const char* v = getenv("HIAST_ASPP_T32"); return v && atoi(v) != 0; }();
+    const bool t16 = dtype == HIAST_FMT_FP16 && !t32;
     if (dtype == 0)      // fp32 rows, fp32 weights: the register-staged kernel splits on the fly
         e = hiast_gemm_nt_launch(x_nhwc, (const float*)wt, T, M, Cin, NP, 0, st);
     else                 // bf16 rows (1) / split planes (2) / fp16 rows (3), weights packed by hiast_pack_conv_weight: LDS-DMA kernel
         e = hiast_igemm_launch(x_nhwc, wt, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, 0, T, M, Cin, NP, 1, 0, 0,
-                               1, 1, dtype, 1, st, nullptr, nullptr, 0);
+                               1, 1, dtype, t16 ? 0 : 1, st, nullptr, nullptr, 0);
     if (e) return e;
     const hiast::Taps2 taps = hiast::make_taps2(dil);
-    hipLaunchKernelGGL(hiast::aspp2_shift_add_kernel, dim3((h * w + 63) / 64, B), dim3(256), 0, st, T, bias, y, h, w,
-                       Cout, NP, taps);
+    const dim3 grid((h * w + 63) / 64, B);
+    if (!t16)
+        hipLaunchKernelGGL(hiast::aspp2_shift_add_kernel<0>, grid, dim3(256), 0, st, T, bias, y, h, w, Cout, NP, taps);
+    else
+        hipLaunchKernelGGL(hiast::aspp2_shift_add_kernel<2>, grid, dim3(256), 0, st, T, bias, y, h, w, Cout, NP, taps);
     HIAST_CHECK_LAUNCH();
     return 0;
 }

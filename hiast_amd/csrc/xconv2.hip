@@ -268,7 +268,8 @@ static int x2_blocks(int64_t M, int N)
 {
     const int NG = N / X2_COLS;
     const long long npanel = (M + X2_PANEL - 1) / X2_PANEL;
-    long long streams = 256 / NG;                   // one block per CU
+    static const int cus = [] { const char* e = getenv("HIAST_XCONV_CUS"); const int v = e ? atoi(e) : 256; return v >= 8 && v <= 256 ? v : 256; }();
+    long long streams = cus / NG;                   // one block per CU (HIAST_XCONV_CUS: experiment, part of the chip)
     if (streams > npanel) streams = npanel;
     streams = (streams + 7) / 8 * 8;                // the (slot, xcd) numbering wants whole rounds of the 8 XCDs
     return (int)(streams * NG);
