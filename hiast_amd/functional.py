@@ -366,6 +366,8 @@ class _ConvNhwcFn(torch.autograd.Function):
                 dx = K.igemm_bn_act(dy.permute(0, 2, 3, 1), wpt, 1, None, None, False, 1, dil).permute(0, 3, 1, 2)
         own_w = need_w and os.environ.get("HIAST_LIB_WGRAD", "0") != "1" and K.conv_wgrad_preferred(
             weight.shape[1], weight.shape[0], k, stride) and (k == 1 or dy.shape[3] >= 4)
+        small_w = need_w and not own_w and os.environ.get("HIAST_LIB_WGRAD", "0") != "1" and K.conv_wgrad_small_supported(
+            weight.shape[1], weight.shape[0], k, stride)
         # The weight gradient is off the critical path of the backward pass (nothing but the optimiser consumes it)
         # and MFMA-bound, while the BatchNorm backward passes that follow on the main stream are HBM-bound: in a
         # single-process run it goes to a side stream and co-runs with them (wgrad_stream_join() before the optimiser
@@ -380,6 +382,9 @@ class _ConvNhwcFn(torch.autograd.Function):
             if own_w:            # transposed-read GEMM over the pixel index (hiast_conv_wgrad_nhwc)
                 dw = K.conv_wgrad_nhwc(dy.permute(0, 2, 3, 1), x.permute(0, 2, 3, 1), k, stride, dil)
                 need_w = False
+            elif small_w:        # the layers below 256 channels (hiast_conv_wgrad_small_nhwc)
+                dw = K.conv_wgrad_small_nhwc(dy.permute(0, 2, 3, 1), x.permute(0, 2, 3, 1), k, stride, dil)
+                need_w = False
             if need_w or lib_x:
                 wl = torch.empty(weight.shape, dtype=x.dtype, device=weight.device)
                 if lib_x:
@@ -388,7 +393,7 @@ class _ConvNhwcFn(torch.autograd.Function):
                                                                 False, (0, 0), 1, (lib_x, need_w, False))
                 if lib_x:
                     dx = gx
-                if need_w and not own_w:
+                if need_w:
                     # fp32, NCHW-contiguous like the parameter (DDP's gradient-layout contract): one cast+layout kernel
                     dw = gw.to(dtype=weight.dtype, memory_format=torch.contiguous_format)
                     if dw.stride() != weight.stride() and dw.is_contiguous() and weight.is_contiguous():

@@ -1115,6 +1115,44 @@ def conv_wgrad_preferred(Cin, Cout, k, stride):
     return k == 1 or os.environ.get("HIAST_LIB_WGRAD3", "0") != "1"
 
 
+def conv_wgrad_small_supported(Cin, Cout, k, stride):
+    """shapes hiast_conv_wgrad_small_nhwc takes (K9h: the layers below 256 channels; a strided 1x1 runs on the subsampled
+    input); shapes hiast_conv_wgrad_nhwc takes as well stay there"""
+    import os
+
+    def chan(c):
+        return c == 64 or (c >= 128 and c % 128 == 0)
+    if os.environ.get("HIAST_LIB_WGRAD_SMALL", "0") == "1" or conv_wgrad_supported(Cin, Cout, k, stride):
+        return False
+    return chan(Cin) and chan(Cout) and ((k == 1 and stride in (1, 2)) or (k == 3 and stride == 1))
+
+
+def conv_wgrad_small_nhwc(dy, x, k, stride, dil):
+    """dy [B,Ho,Wo,Cout], x [B,H,W,Cin] bf16 / fp16 channels-last rows -> dW fp32 [Cout,Cin,k,k] (K9h)"""
+    _req16(dy, 4, "dy")
+    _req(x, dy.dtype, 4, "x")
+    if stride != 1:
+        assert k == 1
+        x = x[:, ::stride, ::stride, :].contiguous()         # a strided 1x1 sees every stride-th pixel only
+    B, H, W, Cin = x.shape
+    Cout = dy.shape[3]
+    assert tuple(dy.shape[:3]) == (B, H, W)
+    taps = k * k
+    lib = _lib.load()
+    n = lib.hiast_conv_wgrad_small_workspace_bytes(B, H, W, Cin, Cout, taps)
+    if n == 0:
+        raise _lib.HiastLibraryError("hiast_conv_wgrad_small_nhwc: unsupported shape Cin=%d Cout=%d taps=%d" % (Cin, Cout, taps))
+    key = ("small", x.device)
+    ws = _wgrad_ws.get(key)
+    if ws is None or ws.numel() * 4 < n:         # one growing scratch buffer per device (stream-ordered reuse)
+        ws = torch.empty((n + 3) // 4, dtype=torch.float32, device=x.device)
+        _wgrad_ws[key] = ws
+    dw = torch.empty((Cout, Cin, k, k), dtype=torch.float32, device=x.device)
+    check(lib.hiast_conv_wgrad_small_nhwc(_ptr(dy), _ptr(x), _ptr(dw), B, H, W, Cin, Cout, taps, int(dil), fmt_of(dy),
+                                          _ptr(ws), ws.numel() * 4, _stream()), "hiast_conv_wgrad_small_nhwc")
+    return dw
+
+
 def conv_wgrad_nhwc(dy, x, k, stride, dil):
     """dy [B,Ho,Wo,Cout], x [B,H,W,Cin] bf16 / fp16 channels-last rows (same type) -> dW fp32 [Cout,Cin,k,k]"""
     _req16(dy, 4, "dy")

@@ -324,6 +324,15 @@ int hiast_conv_wgrad_nhwc(const void* dy, const void* x, float* dw, int B, int H
                           int stride, int dil, int fmt /* HIAST_FMT_BF16 | HIAST_FMT_FP16: type of dy and x */,
                           void* workspace, size_t workspace_bytes, hiast_stream_t stream);
 
+/* ---- K9h: the same weight gradient for the layers BELOW 256 channels (layer1 / layer2: Cin, Cout in {64, 128, 256, ...,
+ * multiples of 128}; 1x1 and 3x3, stride 1, 'same' padding = dil for 3x3) — autograd of nn.Conv2d in
+ * sseg/models/modules/resnet.py:78-98.  dy [B,H,W,Cout], x [B,H,W,Cin] 16-bit channels-last rows (fmt = HIAST_FMT_BF16 /
+ * _FP16), dw fp32 [Cout][Cin][kh][kw], fp32 accumulation, pixel ranges reduced in a fixed order (bitwise reproducible).
+ * A strided 1x1 is this call on the subsampled input. */
+size_t hiast_conv_wgrad_small_workspace_bytes(int B, int H, int W, int Cin, int Cout, int taps);
+int hiast_conv_wgrad_small_nhwc(const void* dy, const void* x, float* dw, int B, int H, int W, int Cin, int Cout, int taps,
+                                int dil, int fmt, void* workspace, size_t workspace_bytes, hiast_stream_t stream);
+
 /* ---- K10b: BatchNorm2d (+ residual) (+ ReLU), TRAINING mode, on channels-last bf16 activations [M = B*H*W][C] ------
  * Same arithmetic and passes as K10 (resnet.py:78-98 in train(): batch statistics even with frozen affine
  * parameters, utils/utils.py:60-65) in the layout the convolution kernels of K9c produce / consume.

@@ -146,3 +146,37 @@ def test_plabel_pass1_scattered_workspace_equals_direct_counting(K, C):
                                 ctypes.c_void_p(am0.data_ptr()), ctypes.c_void_p(hist0.data_ptr()), ctypes.c_void_p(small.data_ptr()),
                                 64, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == -3
+
+
+SMALL_WGRAD = [(2, 64, 64, 19, 33, 1, 1, 1),      # layer1.0.conv1: both operands 64 wide (TI = 64, half a j tile)
+               (2, 256, 64, 19, 33, 1, 1, 1),     # layer1.1.conv1: dY 64 wide, X in two 128-channel windows
+               (2, 64, 256, 19, 33, 1, 1, 1),     # layer1.x.conv3 / downsample: computed transposed
+               (3, 64, 64, 17, 29, 3, 1, 1),      # layer1.x.conv2: tap pairs side by side in the j tile
+               (2, 512, 128, 13, 21, 1, 1, 1),    # layer2.x.conv1
+               (2, 256, 128, 26, 42, 1, 1, 2),    # layer2.0.conv1: strided 1x1 (subsampled input)
+               (2, 128, 512, 13, 21, 1, 1, 1),    # layer2.x.conv3
+               (2, 256, 512, 26, 42, 1, 1, 2),    # layer2.0.downsample
+               (3, 128, 128, 13, 21, 3, 1, 1),    # layer2.x.conv2
+               (1, 128, 128, 40, 64, 3, 2, 1),    # dilated 3x3, many pixel ranges
+               (8, 64, 64, 64, 128, 3, 1, 1)]     # 65536 pixels: hundreds of ranges, XCD order with a ragged block count
+
+
+@pytest.mark.parametrize("cfg", SMALL_WGRAD)
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_conv_wgrad_small_channels(K, cfg, dt):
+    """K9h (wgrad_small.hip): weight gradient of the layer1 / layer2 convolutions (64 .. 512 channels) vs the fp32 weight
+    gradient of the same 16-bit operands — every tiling form (TI = 64 / 128, 128-channel windows, tap pairs, transposed,
+    strided 1x1 on the subsampled input), both types; bitwise repeatable"""
+    B, Cin, Cout, H, W, k, dil, stride = cfg
+    assert K.conv_wgrad_small_supported(Cin, Cout, k, stride)
+    x = dev(synth.normal_f32(3500, (B, H, W, Cin))).to(dt)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    dy = dev(synth.normal_f32(3501, (B, Ho, Wo, Cout))).to(dt)
+    dw = K.conv_wgrad_small_nhwc(dy, x, k, stride, dil)
+    assert dw.dtype == torch.float32 and tuple(dw.shape) == (Cout, Cin, k, k)
+    pad = dil if k == 3 else 0
+    ref = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2).float(), (Cout, Cin, k, k), dy.permute(0, 3, 1, 2).float(),
+                                      stride=stride, padding=pad, dilation=dil if k == 3 else 1)
+    err = (dw - ref).abs().max().item()
+    assert err <= 1e-4 * ref.abs().max().item(), (cfg, err, ref.abs().max().item())
+    assert torch.equal(dw, K.conv_wgrad_small_nhwc(dy, x, k, stride, dil))
