@@ -111,7 +111,8 @@ class KernelTimer:
             return ("igemm", tuple(x.shape), tuple(wp.shape), int(planes), int(stride), int(dil), res is not None,
                     bool(out_f32), bn is not None, bool(relu))
         def aspp2_key(x, wt, bias, dil, workspace=None, planes=None):
-            return ("aspp2_fwd", tuple(x.shape), int(bias.numel()), 2 if planes == 2 else (0 if x.dtype == torch.float32 else 1))
+            return ("aspp2_fwd", tuple(x.shape), int(bias.numel()), 2 if planes == 2 else (0 if x.dtype == torch.float32 else 1),
+                    str(x.dtype).replace("torch.", ""))
         self.wrap(K, "aspp_fwd", aspp_key)
         self.wrap(K, "aspp2_fwd", aspp2_key)
         self.wrap(K, "igemm_bn_act", ig_key)
@@ -156,7 +157,7 @@ def roofline_of(key, avg_ms, n, steps):
         peak = 2500.0 / 3.0 if mode != 1 else 2500.0
         alg_bytes = B * h * w * Cin * (2 if mode == 1 else 4) + 33 * Cout * Cin * 4 + B * Cout * h * w * 4
         return {"kernel": "hiast_aspp2_fwd (%s tap GEMM on hiast::igemm_bn_act_kernel + aspp2_shift_add_kernel)"
-                          % ("split-bf16" if mode != 1 else "bf16"),
+                          % ("split-bf16" if mode != 1 else {"float16": "fp16", "bfloat16": "bf16"}.get(key[4], key[4])),
                 "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
                 "avg_launch_ms": avg_ms, "launches_per_step": n / steps,
                 "note": "ASPP head forward, %d images: algorithmic %.1f GFLOP (36 taps x %d x %d) and %.0f MB (feature "
