@@ -58,14 +58,6 @@ SIGNATURES = {
     "hiast_igemm_dgrad_bn_stats": (c_int, [c_vp, c_vp, c_vp] + [c_int] * 7 + [c_vp] * 6 + [c_int, c_vp]),
     "hiast_igemm_dgrad_bn_stats_rows": (c_int, [c_i64]),
     "hiast_bn_nhwc_stats_from_partial": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
-    "hiast_bn_nhwc_finalize_partial": (c_int, [c_vp, c_int, c_int, ctypes.c_double, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "hiast_bn_nhwc_finalize_sums": (c_int, [c_vp, c_int, ctypes.c_double, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "hiast_conv_bn3_ok": (c_int, [c_i64, c_int, c_int]),
-    "hiast_conv_bn3_stats_rows": (c_int, [c_i64, c_int, c_int]),
-    "hiast_conv_bn3_stats": (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp]),
-    "hiast_conv_bn3_fwd": (c_int, [c_vp] * 9 + [c_i64, c_int, c_int, c_vp]),
-    "hiast_conv_bn3_bwd_stats": (c_int, [c_vp] * 6 + [c_i64, c_int, c_int, c_vp, c_vp]),
-    "hiast_conv_bn3_bwd_apply": (c_int, [c_vp] * 6 + [ctypes.c_double, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
     "hiast_conv_wgrad_workspace_bytes": (c_sz, [c_int] * 6),
     "hiast_conv_wgrad_nhwc": (c_int, [c_vp, c_vp, c_vp] + [c_int] * 9 + [c_vp, c_sz, c_vp]),
     "hiast_conv_wgrad_small_workspace_bytes": (c_sz, [c_int] * 6),

@@ -513,31 +513,6 @@ extern "C" int hiast_bn_nhwc_stats_from_partial(const float* partial, int nblk, 
     return 0;
 }
 
-// batch statistics alone (no elementwise pass): for callers that apply the normalisation inside another kernel (the
-// conv3 -> bn3 chain of hiast_conv_bn3_*).  From per-block partials in one launch (single rank), or from all-reduced sums.
-extern "C" int hiast_bn_nhwc_finalize_partial(const float* partial, int nblk, int C, double count, float momentum, float eps,
-                                              float* running_mean, float* running_var, float* save_mean,
-                                              float* save_invstd, hiast_stream_t stream)
-{
-    if (!partial || !save_mean || !save_invstd || nblk <= 0 || C <= 0 || !(count > 0)) return HIAST_E_ARG;
-    if (C % 8 != 0) return HIAST_E_RANGE;
-    hipLaunchKernelGGL(hiast::bnh_finalize_prep_kernel, dim3(C / 2), dim3(256), 0, (hipStream_t)stream, partial, nblk, C, count,
-                       momentum, eps, running_mean, running_var, save_mean, save_invstd);
-    HIAST_CHECK_LAUNCH();
-    return 0;
-}
-
-extern "C" int hiast_bn_nhwc_finalize_sums(const double* sums, int C, double count, float momentum, float eps,
-                                           float* running_mean, float* running_var, float* save_mean, float* save_invstd,
-                                           hiast_stream_t stream)
-{
-    if (!sums || !save_mean || !save_invstd || C <= 0 || !(count > 0)) return HIAST_E_ARG;
-    hipLaunchKernelGGL(hiast::bnh_prep_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count,
-                       momentum, eps, running_mean, running_var, save_mean, save_invstd, C);
-    HIAST_CHECK_LAUNCH();
-    return 0;
-}
-
 extern "C" int hiast_bn_nhwc_apply(const void* x, const void* res, void* y, const float* gamma, const float* beta,
                                    float* running_mean, float* running_var, const double* sums, double count,
                                    float momentum, float eps, int relu, float* save_mean, float* save_invstd,

@@ -64,19 +64,7 @@ __device__ __forceinline__ int xc_chan(int g, int b, int r) { return (b >> 1) * 
 //   RELU    o = max(o, 0)
 //   STATS   per-block sums Σy, Σy² of the STORED (bf16-rounded) values -> stats[stream][N][2]
 // F16: the rows are IEEE fp16 (HIAST_FMT_FP16) instead of bf16 — H16<F16> decodes / encodes / multiplies (common.h)
-// MODE (round 3: the student's conv3 -> bn3 chain WITHOUT a stored conv output — the GEMM is recomputed wherever the raw
-// output y = X W^T was read before; 34 GFLOP ride in an HBM-bound launch, 134 MB per pass do not move):
-//   0  as above
-//   1  statistics only: Σy, Σy² of the fp32 accumulators, nothing stored            (flags: STATS)
-//   2  out = relu(bn(y) + R) stored + its ReLU gate as a bit mask Mk[m][N/8]; `var` holds 1/sqrt(var + eps) of the batch
-//      statistics                                                                    (flags: BN RES RELU)
-//   3  BatchNorm-backward sums over g = R (= dout) where the gate bit is set: Σg, Σ g xhat with xhat = (y - mean) invstd;
-//      nothing stored                                                                (flags: BN RES GATE STATS)
-//   4  dy = gamma invstd (g - Σg/n - xhat Σ(g xhat)/n) stored, from `sums` (double [N][2]) and inv_count = 1/n
-//                                                                                    (flags: BN RES GATE)
-// WC: output columns per wave (64: a block owns 512 columns; 32 — MODE 3, whose two sets of running sums do not fit beside 128
-// weight registers — 256 columns: half the weights, accumulators and sums per lane, twice the blocks per panel stream)
-template <int KC, bool BN, bool RES, bool RELU, bool GATE, bool STATS, bool F16 = false, int MODE = 0, int WC = 64>
+template <int KC, bool BN, bool RES, bool RELU, bool GATE, bool STATS, bool F16 = false>
 __global__ __launch_bounds__(512) void xconv_kernel(const unsigned short* __restrict__ X,
                                                     const unsigned short* __restrict__ Wp,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -84,38 +72,32 @@ __global__ __launch_bounds__(512) void xconv_kernel(const unsigned short* __rest
                                                     float eps, const unsigned short* __restrict__ R,
                                                     const unsigned char* __restrict__ Rg,
                                                     unsigned short* __restrict__ Y, int M, int N,
-                                                    float* __restrict__ stats, unsigned char* __restrict__ Mk = nullptr,
-                                                    const double* __restrict__ sums = nullptr, float inv_count = 0.f)
+                                                    float* __restrict__ stats)
 {
-    constexpr bool STORE = MODE != 1 && MODE != 3;
-    constexpr int COLS = WC * 8;                         // output columns per block
-    constexpr int NT = WC / 16;                          // 16-column n-tiles per wave
-    constexpr int NH = NT / 2;                           // 8-channel groups per lane and pixel (1 or 2, 32 channels apart)
     constexpr int SL = KC / 64;                          // 128-byte slabs per row
     constexpr int KS = KC / 32;                          // 32-deep MFMA steps
     constexpr int STAGE = XC_PANEL * KC * 2;             // bytes per panel
     __shared__ __attribute__((aligned(1024))) unsigned char smem[XC_STAGES * STAGE];
-    __shared__ float s_sc[COLS], s_sh[COLS];
-    __shared__ float s_ga[MODE == 4 ? COLS : 1];      // MODE 4: gamma * invstd per column
+    __shared__ float s_sc[XC_COLS], s_sh[XC_COLS];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, px = lane & 15;
     // block -> (column group, panel stream): consecutive block ids go round the 8 XCDs, so the NG blocks that walk
     // the same panels take neighbouring slots of ONE XCD
-    const int NG = N / COLS;
+    const int NG = N / XC_COLS;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int cg = slot % NG;
     const int nstream = (int)gridDim.x / NG;
     const int stream = (slot / NG) * 8 + xcd;
-    const int n0 = cg * COLS + wave * WC;                // this wave's first output column
+    const int n0 = cg * XC_COLS + wave * 64;             // this wave's first output column
     const int npanel = (M + XC_PANEL - 1) / XC_PANEL;
 
     // ---- weights -> registers, in the A-operand layout of v_mfma_f32_16x16x32_bf16 (lane: row px, k = 8 g .. 8 g + 7
     // of a 32-deep step); row px of n-tile b is output channel n0 + xc_chan(px >> 2, b, px & 3)
-    xc_bf16x8 wr[NT][KS];
+    xc_bf16x8 wr[4][KS];
 #pragma unroll
-    for (int b = 0; b < NT; ++b) {
+    for (int b = 0; b < 4; ++b) {
         const unsigned short* wrow = Wp + (size_t)(n0 + xc_chan(px >> 2, b, px & 3)) * KC + g * 8;
 #pragma unroll
         for (int s = 0; s < KS; ++s) wr[b][s] = *reinterpret_cast<const xc_bf16x8*>(wrow + s * 32);
@@ -123,26 +105,15 @@ __global__ __launch_bounds__(512) void xconv_kernel(const unsigned short* __rest
     // pin the fragments down HERE: with their first use inside the panel loop the compiler's wait for these loads
     // lands in the loop as an s_waitcnt vmcnt(0) behind every DMA issue (measured: the prefetch was dead)
 #pragma unroll
-    for (int b = 0; b < NT; ++b)
+    for (int b = 0; b < 4; ++b)
 #pragma unroll
         for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(wr[b][s]));
     if (BN) {
-        for (int c = tid; c < COLS; c += 512) {
-            const int n = cg * COLS + c;
-            if (MODE == 3) {                             // xhat = y * invstd - mean * invstd
-                s_sc[c] = var[n];
-                s_sh[c] = -mean[n] * var[n];
-            } else if (MODE == 4) {                      // dy = a g + P y + Q
-                const float a = (gamma ? gamma[n] : 1.0f) * var[n];
-                const float c1 = (float)(sums[2 * n] * (double)inv_count), c2 = (float)(sums[2 * n + 1] * (double)inv_count);
-                s_ga[c] = a;
-                s_sc[c] = -a * c2 * var[n];
-                s_sh[c] = a * (c2 * mean[n] * var[n] - c1);
-            } else {
-                const float sc = (gamma ? gamma[n] : 1.0f) * (MODE == 2 ? var[n] : 1.0f / sqrtf(var[n] + eps));
-                s_sc[c] = sc;
-                s_sh[c] = fmaf(-mean[n], sc, beta ? beta[n] : 0.0f);
-            }
+        for (int c = tid; c < XC_COLS; c += 512) {
+            const int n = cg * XC_COLS + c;
+            const float sc = (gamma ? gamma[n] : 1.0f) * (1.0f / sqrtf(var[n] + eps));
+            s_sc[c] = sc;
+            s_sh[c] = fmaf(-mean[n], sc, beta ? beta[n] : 0.0f);
         }
         __syncthreads();                                 // (the loop's barriers are bare: they publish no LDS stores)
     }
@@ -162,9 +133,9 @@ __global__ __launch_bounds__(512) void xconv_kernel(const unsigned short* __rest
     };
 
     const unsigned lds_base = (unsigned)(size_t)smem;       // LDS byte address of the stage buffers (for the asm reads)
-    float st1[STATS ? NT * 4 : 1], st2[STATS ? NT * 4 : 1];
+    float st1[STATS ? 16 : 1], st2[STATS ? 16 : 1];
 #pragma unroll
-    for (int q = 0; q < (STATS ? NT * 4 : 1); ++q) { st1[q] = 0.f; st2[q] = 0.f; }
+    for (int q = 0; q < (STATS ? 16 : 1); ++q) { st1[q] = 0.f; st2[q] = 0.f; }
 
     issue(stream, 0);
     issue(stream + nstream, 1);
@@ -176,47 +147,42 @@ __global__ __launch_bounds__(512) void xconv_kernel(const unsigned short* __rest
         // iteration's stores of half 0 (4), residual / gate loads of half 1 and stores of half 1 (4).
         // (First iteration: only the DMA of the second panel is younger.)  No scratch traffic may hide in this count:
         // the variants are built without spills (checked in the build log: private_segment_fixed_size == 0).
-        constexpr int NRES = RES ? (GATE ? 2 * NT : NT) : 0;    // residual (+ gate) loads per 32-row half
+        constexpr int NRES = RES ? (GATE ? 8 : 4) : 0;          // residual (+ gate) loads per 32-row half
         // A bare s_barrier behind the counted wait (round 3): behind __syncthreads() the compiler (ROCm 7.2) emits
         // `s_waitcnt vmcnt(0) lgkmcnt(0)` — every store of the previous panel had to be acknowledged by the memory side and
         // the DMA of the next panel had to land before any wave went on, once per panel (found in the ISA of xconv2.hip;
         // this loop had the same drain, which is what held the residual variants at 4.3 TB/s).  The fragment reads are
         // asm with their own lgkmcnt waits, so nothing else needs the implied wait.
-        constexpr int NST = !STORE ? 0 : (MODE == 2 ? 2 * NT : NT);   // stores per 32-row half (MODE 2: + the mask bytes)
         if (it == 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(SL) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(SL + 2 * NST + NRES) : "memory");  // everyone's has landed;
+        else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(SL + 8 + NRES) : "memory");      // everyone's has landed;
                                                                  // everyone left the stage of panel p - 1
         // residual rows (and gate bytes) of a 32-row half are requested before its MFMAs
-        uint4 rres[RES ? 2 : 1][NH];
-        unsigned rgate[GATE ? 2 : 1][NH];
+        uint4 rres[RES ? 2 : 1][2];
+        unsigned rgate[GATE ? 2 : 1][2];
         auto load_res = [&](int half) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int m = p * XC_PANEL + half * 32 + t * 16 + px;
                 const size_t row = (size_t)(m < M ? m : 0) * N + n0 + g * 8;
                 rres[t][0] = *reinterpret_cast<const uint4*>(R + row);
-                if (NH == 2) rres[t][NH - 1] = *reinterpret_cast<const uint4*>(R + row + 32);
+                rres[t][1] = *reinterpret_cast<const uint4*>(R + row + 32);
                 if (GATE) {
                     const unsigned char* gp = Rg + (size_t)(m < M ? m : 0) * (N >> 3) + ((n0 + g * 8) >> 3);
                     rgate[t][0] = gp[0];
-                    if (NH == 2) rgate[t][NH - 1] = gp[4];
+                    rgate[t][1] = gp[4];
                 }
             }
         };
-        // MODE 3 (backward sums; no stores) requests the rows of a half BEHIND its MFMAs: weights + two sets of 16 sums + the
-        // accumulators leave no room for 20 more live registers in the MFMA loop (124 bytes of scratch otherwise); the other
-        // wave of the SIMD multiplies meanwhile
-        constexpr bool LATE_RES = MODE == 3;
-        if (RES && !LATE_RES) load_res(0);
+        if (RES) load_res(0);
         issue(p + 2 * nstream, (it + 2) % XC_STAGES);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            if (RES && !LATE_RES && half == 1) load_res(1);
-            xc_f32x4 acc[2][NT];
+            if (RES && half == 1) load_res(1);
+            xc_f32x4 acc[2][4];
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int b = 0; b < NT; ++b) acc[a][b] = (xc_f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int b = 0; b < 4; ++b) acc[a][b] = (xc_f32x4){0.f, 0.f, 0.f, 0.f};
             // fragments of step s + 1 are requested before the MFMAs of step s (LDS latency hidden behind 8 MFMAs)
             auto frag = [&](int s, int a) {
                 return xc_lds_read(lds_base + (unsigned)(st * STAGE + (s >> 1) * (XC_PANEL * 128) +
@@ -239,7 +205,7 @@ __global__ __launch_bounds__(512) void xconv_kernel(const unsigned short* __rest
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
-                    for (int b = 0; b < NT; ++b)
+                    for (int b = 0; b < 4; ++b)
                         acc[a][b] = H16<F16>::mfma16(wr[b][s], xa[s & one][a], acc[a][b]);
                 if (s + 1 < KS) {
                     if (!DB) {
@@ -249,64 +215,24 @@ __global__ __launch_bounds__(512) void xconv_kernel(const unsigned short* __rest
                     xc_lds_wait(xa[(s + 1) & one][0], xa[(s + 1) & one][1]);
                 }
             }
-            if (RES && LATE_RES) load_res(half);
             // ---- epilogue of this 32-row half: lane = pixel (a, px), channels n0 + {g*8 .. g*8+7} and + 32
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 const int m = p * XC_PANEL + half * 32 + a * 16 + px;
                 const bool ok = m < M;
                 const size_t row = (size_t)(ok ? m : 0) * N + n0 + g * 8;
-                const uint4 r0 = rres[RES ? a : 0][0], r1 = rres[RES ? a : 0][NH - 1];
+                const uint4 r0 = rres[RES ? a : 0][0], r1 = rres[RES ? a : 0][1];
                 const unsigned gate0 = GATE ? rgate[GATE ? a : 0][0] : 0xFFu;
-                const unsigned gate1 = GATE ? rgate[GATE ? a : 0][NH - 1] : 0xFFu;
-                if (MODE == 1) {                         // statistics of the fp32 accumulators; nothing is stored
-                    if (ok) {
+                const unsigned gate1 = GATE ? rgate[GATE ? a : 0][1] : 0xFFu;
+                float o[16];
 #pragma unroll
-                        for (int b = 0; b < NT; ++b)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int q = (b >> 1) * 8 + (b & 1) * 4 + r;
-                                st1[q] += acc[a][b][r];
-                                st2[q] = fmaf(acc[a][b][r], acc[a][b][r], st2[q]);
-                            }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    continue;
-                }
-                if (MODE == 3) {                         // Σg, Σ g xhat over this lane's pixel: element by element (no copy of
-                    if (ok) {                            // the 16 values: the registers are all taken by weights and sums)
-                        const unsigned wd[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
-#pragma unroll
-                        for (int b = 0; b < NT; ++b) {
-                            const int c = wave * WC + (b >> 1) * 32 + g * 8 + (b & 1) * 4;
-                            const float4 sc = *reinterpret_cast<const float4*>(&s_sc[c]);
-                            const float4 sh = *reinterpret_cast<const float4*>(&s_sh[c]);
-                            const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
-                            const unsigned gate = (b >> 1) ? gate1 : gate0;
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int q = (b >> 1) * 8 + (b & 1) * 4 + r, e = (b & 1) * 4 + r;      // e: channel within the 8
-                                const unsigned w = wd[(b >> 1) * 4 + (e >> 1)];
-                                float gv = (e & 1) ? H16<F16>::hi(w) : H16<F16>::lo(w);
-                                gv = ((gate >> e) & 1u) ? gv : 0.f;
-                                const float xh = fmaf(acc[a][b][r], scv[r], shv[r]);
-                                st1[q] += gv;
-                                st2[q] = fmaf(gv, xh, st2[q]);
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
-                    continue;
-                }
-                float o[NT * 4];
-#pragma unroll
-                for (int b = 0; b < NT; ++b)
+                for (int b = 0; b < 4; ++b)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[(b >> 1) * 8 + (b & 1) * 4 + r] = acc[a][b][r];
                 if (BN) {
 #pragma unroll
-                    for (int hh = 0; hh < NH; ++hh) {
-                        const int c = wave * WC + hh * 32 + g * 8;
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const int c = wave * 64 + hh * 32 + g * 8;
 #pragma unroll
                         for (int q = 0; q < 8; q += 4) {
                             const float4 sc = *reinterpret_cast<const float4*>(&s_sc[c + q]);
@@ -330,35 +256,22 @@ __global__ __launch_bounds__(512) void xconv_kernel(const unsigned short* __rest
                             b0 = ((gate1 >> (2 * q)) & 1u) ? b0 : 0.f;
                             b1 = ((gate1 >> (2 * q + 1)) & 1u) ? b1 : 0.f;
                         }
-                        constexpr int O2 = NH == 2 ? 8 : 0;     // (second 8-channel group: only with 64 columns per wave)
-                        if (MODE == 4) {          // o holds P y + Q; + gamma invstd * g
-                            const int c = wave * WC + g * 8 + 2 * q;
-                            o[2 * q] = fmaf(s_ga[c], a0, o[2 * q]);
-                            o[2 * q + 1] = fmaf(s_ga[c + 1], a1, o[2 * q + 1]);
-                            if (NH == 2) {
-                                o[O2 + 2 * q] = fmaf(s_ga[(c + 32) % COLS], b0, o[O2 + 2 * q]);
-                                o[O2 + 2 * q + 1] = fmaf(s_ga[(c + 33) % COLS], b1, o[O2 + 2 * q + 1]);
-                            }
-                        } else {
-                            o[2 * q] += a0;
-                            o[2 * q + 1] += a1;
-                            if (NH == 2) {
-                                o[O2 + 2 * q] += b0;
-                                o[O2 + 2 * q + 1] += b1;
-                            }
-                        }
+                        o[2 * q] += a0;
+                        o[2 * q + 1] += a1;
+                        o[8 + 2 * q] += b0;
+                        o[8 + 2 * q + 1] += b1;
                     }
                 }
                 if (RELU) {
 #pragma unroll
-                    for (int q = 0; q < NT * 4; ++q) o[q] = o[q] > 0.f ? o[q] : 0.f;
+                    for (int q = 0; q < 16; ++q) o[q] = o[q] > 0.f ? o[q] : 0.f;
                 }
-                unsigned pk[NT * 2];
+                unsigned pk[8];
                 if (STATS && F16) {
                     // fp16 statistics variant: pair by pair, each pair finished before the next is converted (the cvt
                     // temporaries of eight pairs in flight at once pushed this variant 3 registers over the file)
 #pragma unroll
-                    for (int q = 0; q < NT * 2; ++q) {
+                    for (int q = 0; q < 8; ++q) {
                         pk[q] = H16<F16>::pack(o[2 * q], o[2 * q + 1]);
                         if (ok) {
                             const float v0 = H16<F16>::lo(pk[q]), v1 = H16<F16>::hi(pk[q]);
@@ -369,32 +282,19 @@ __global__ __launch_bounds__(512) void xconv_kernel(const unsigned short* __rest
                     }
                 } else {
 #pragma unroll
-                    for (int q = 0; q < NT * 2; ++q) pk[q] = H16<F16>::pack(o[2 * q], o[2 * q + 1]);
+                    for (int q = 0; q < 8; ++q) pk[q] = H16<F16>::pack(o[2 * q], o[2 * q + 1]);
                     if (STATS && ok) {
 #pragma unroll
-                        for (int q = 0; q < NT * 2; ++q) {
+                        for (int q = 0; q < 8; ++q) {
                             const float v0 = H16<F16>::lo(pk[q]), v1 = H16<F16>::hi(pk[q]);
                             st1[2 * q] += v0; st2[2 * q] = fmaf(v0, v0, st2[2 * q]);
                             st1[2 * q + 1] += v1; st2[2 * q + 1] = fmaf(v1, v1, st2[2 * q + 1]);
                         }
                     }
                 }
-                if (MODE == 2 && ok) {
-                    // ReLU gate of the 8 (16) channels of this lane's pixel, one byte per 8: of the STORED value (a positive
-                    // accumulator below half the smallest fp16 subnormal is stored as 0 and must not pass gradient)
-                    unsigned m0 = 0u, m1 = 0u;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        m0 |= (((pk[q >> 1] >> (16 * (q & 1))) & 0x7FFFu) ? 1u : 0u) << q;
-                        if (NH == 2) m1 |= (((pk[NT * 2 - 4 + (q >> 1)] >> (16 * (q & 1))) & 0x7FFFu) ? 1u : 0u) << q;
-                    }
-                    unsigned char* mp = Mk + (size_t)m * (N >> 3) + ((n0 + g * 8) >> 3);
-                    mp[0] = (unsigned char)m0;
-                    if (NH == 2) mp[4] = (unsigned char)m1;
-                }
                 if (ok) {
                     *reinterpret_cast<uint4*>(Y + row) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-                    if (NH == 2) *reinterpret_cast<uint4*>(Y + row + 32) = make_uint4(pk[NT * 2 - 4], pk[NT * 2 - 3], pk[NT * 2 - 2], pk[NT * 2 - 1]);
+                    *reinterpret_cast<uint4*>(Y + row + 32) = make_uint4(pk[4], pk[5], pk[6], pk[7]);
                 }
             }
         }
@@ -402,7 +302,7 @@ __global__ __launch_bounds__(512) void xconv_kernel(const unsigned short* __rest
     if (STATS) {
         // fold the 16 pixel-lanes of each channel group; lane px == 0 of every g then holds the wave's column sums
 #pragma unroll
-        for (int q = 0; q < NT * 4; ++q) {
+        for (int q = 0; q < 16; ++q) {
 #pragma unroll
             for (int o = 1; o < 16; o <<= 1) {
                 st1[q] += __shfl_xor(st1[q], o, 64);
@@ -415,18 +315,16 @@ __global__ __launch_bounds__(512) void xconv_kernel(const unsigned short* __rest
             for (int q = 0; q < 8; ++q) {
                 d[2 * q] = st1[q];
                 d[2 * q + 1] = st2[q];
-                if (NH == 2) {
-                    d[64 + 2 * q] = st1[(NH - 1) * 8 + q];
-                    d[64 + 2 * q + 1] = st2[(NH - 1) * 8 + q];
-                }
+                d[64 + 2 * q] = st1[8 + q];
+                d[64 + 2 * q + 1] = st2[8 + q];
             }
         }
     }
 }
 
-static int xc_blocks(int64_t M, int N, int cols = XC_COLS)
+static int xc_blocks(int64_t M, int N)
 {
-    const int NG = N / cols;
+    const int NG = N / XC_COLS;
     const long long npanel = (M + XC_PANEL - 1) / XC_PANEL;
     static const int cus = [] { const char* e = getenv("HIAST_XCONV_CUS"); const int v = e ? atoi(e) : 256; return v >= 8 && v <= 256 ? v : 256; }();
     long long streams = cus / NG;                   // one block per CU (HIAST_XCONV_CUS: experiment, part of the chip)
@@ -489,107 +387,3 @@ int hiast_xconv_launch(const void* x, const void* wp, const float* gamma, const 
     HIAST_CHECK_LAUNCH();
     return 0;
 }
-
-// ---- the student's conv3 -> bn3 chain on recomputed GEMMs (MODE 1 - 4 of xconv_kernel) -------------------------------------
-// x [M][256] 16-bit rows, wp = hiast_pack_conv_weight(W [N][256]), N % 512 == 0, M >= 4096 (hiast_conv_bn3_ok).
-extern "C" int hiast_conv_bn3_ok(int64_t M, int K, int N)
-{
-    return K == 256 && N % hiast::XC_COLS == 0 && N <= 2048 && M >= 4096 && M * (int64_t)N * 2 < (1ll << 31);
-}
-
-// rows of the per-block partial sums: forward statistics (512 output columns per block) / backward sums (256 per block)
-extern "C" int hiast_conv_bn3_stats_rows(int64_t M, int N, int backward)
-{
-    if (!hiast_conv_bn3_ok(M, 256, N)) return 0;
-    const int cols = backward ? 256 : hiast::XC_COLS;
-    return hiast::xc_blocks(M, N, cols) / (N / cols);
-}
-
-#define XC3_LAUNCH(BNF, RESF, RELUF, GATEF, STATSF, MODEV, ...)                                                         \
-    do {                                                                                                               \
-        const dim3 grid((unsigned)hiast::xc_blocks(M, N));                                                             \
-        if (fmt == HIAST_FMT_FP16)                                                                                     \
-            hipLaunchKernelGGL((hiast::xconv_kernel<256, BNF, RESF, RELUF, GATEF, STATSF, true, MODEV>), grid, dim3(512), 0, \
-                               (hipStream_t)stream, __VA_ARGS__);                                                      \
-        else                                                                                                           \
-            hipLaunchKernelGGL((hiast::xconv_kernel<256, BNF, RESF, RELUF, GATEF, STATSF, false, MODEV>), grid, dim3(512), 0, \
-                               (hipStream_t)stream, __VA_ARGS__);                                                      \
-        HIAST_CHECK_LAUNCH();                                                                                          \
-    } while (0)
-
-#define XC3_LAUNCH32(BNF, RESF, RELUF, GATEF, STATSF, MODEV, ...)                                                       \
-    do {                                                                                                               \
-        const dim3 grid((unsigned)hiast::xc_blocks(M, N, 256));                                                        \
-        if (fmt == HIAST_FMT_FP16)                                                                                     \
-            hipLaunchKernelGGL((hiast::xconv_kernel<256, BNF, RESF, RELUF, GATEF, STATSF, true, MODEV, 32>), grid, dim3(512), 0, \
-                               (hipStream_t)stream, __VA_ARGS__);                                                      \
-        else                                                                                                           \
-            hipLaunchKernelGGL((hiast::xconv_kernel<256, BNF, RESF, RELUF, GATEF, STATSF, false, MODEV, 32>), grid, dim3(512), 0, \
-                               (hipStream_t)stream, __VA_ARGS__);                                                      \
-        HIAST_CHECK_LAUNCH();                                                                                          \
-    } while (0)
-
-static int xc3_check(const void* x, const void* wp, int64_t M, int N, int fmt)
-{
-    if (!x || !wp) return HIAST_E_ARG;
-    if ((fmt != HIAST_FMT_BF16 && fmt != HIAST_FMT_FP16) || !hiast_conv_bn3_ok(M, 256, N)) return HIAST_E_RANGE;
-    if ((((uintptr_t)x) | ((uintptr_t)wp)) & 15) return HIAST_E_RANGE;
-    return 0;
-}
-
-// partial [hiast_conv_bn3_stats_rows][N][2] = per-block (Σy, Σy²) of y = x W^T (fp32 accumulators); y itself is not stored
-extern "C" int hiast_conv_bn3_stats(const void* x, const void* wp, int64_t M, int N, int fmt, float* partial,
-                                    hiast_stream_t stream)
-{
-    int e = xc3_check(x, wp, M, N, fmt);
-    if (e) return e;
-    if (!partial) return HIAST_E_ARG;
-    XC3_LAUNCH(false, false, false, false, true, 1, (const unsigned short*)x, (const unsigned short*)wp, nullptr, nullptr,
-               nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, (int)M, N, partial);
-    return 0;
-}
-
-// out = relu((y - mean) invstd gamma + beta + res) (16-bit rows) and mask [M][N/8] (bit c & 7 of byte c / 8: out > 0)
-extern "C" int hiast_conv_bn3_fwd(const void* x, const void* wp, const float* gamma, const float* beta, const float* mean,
-                                  const float* invstd, const void* res, void* out, uint8_t* mask, int64_t M, int N, int fmt,
-                                  hiast_stream_t stream)
-{
-    int e = xc3_check(x, wp, M, N, fmt);
-    if (e) return e;
-    if (!mean || !invstd || !res || !out || !mask) return HIAST_E_ARG;
-    if ((((uintptr_t)res) | ((uintptr_t)out)) & 15) return HIAST_E_RANGE;
-    XC3_LAUNCH(true, true, true, false, false, 2, (const unsigned short*)x, (const unsigned short*)wp, gamma, beta, mean,
-               invstd, 0.f, (const unsigned short*)res, nullptr, (unsigned short*)out, (int)M, N, nullptr, mask);
-    return 0;
-}
-
-// partial [rows][N][2] = per-block (Σg, Σ g xhat), g = dout where the mask bit is set, xhat = (y - mean) invstd
-extern "C" int hiast_conv_bn3_bwd_stats(const void* x, const void* wp, const float* mean, const float* invstd,
-                                        const void* dout, const uint8_t* mask, int64_t M, int N, int fmt, float* partial,
-                                        hiast_stream_t stream)
-{
-    int e = xc3_check(x, wp, M, N, fmt);
-    if (e) return e;
-    if (!mean || !invstd || !dout || !mask || !partial) return HIAST_E_ARG;
-    if (((uintptr_t)dout) & 15) return HIAST_E_RANGE;
-    XC3_LAUNCH32(true, true, false, true, true, 3, (const unsigned short*)x, (const unsigned short*)wp, nullptr, nullptr, mean,
-               invstd, 0.f, (const unsigned short*)dout, mask, nullptr, (int)M, N, partial);
-    return 0;
-}
-
-// dy = gamma invstd (g - sums[.][0] / count - xhat sums[.][1] / count) (16-bit rows): the gradient w.r.t. y = x W^T
-extern "C" int hiast_conv_bn3_bwd_apply(const void* x, const void* wp, const float* gamma, const float* mean,
-                                        const float* invstd, const double* sums, double count, const void* dout,
-                                        const uint8_t* mask, void* dy, int64_t M, int N, int fmt, hiast_stream_t stream)
-{
-    int e = xc3_check(x, wp, M, N, fmt);
-    if (e) return e;
-    if (!mean || !invstd || !sums || !dout || !mask || !dy || !(count > 0)) return HIAST_E_ARG;
-    if ((((uintptr_t)dout) | ((uintptr_t)dy)) & 15) return HIAST_E_RANGE;
-    XC3_LAUNCH32(true, true, false, true, false, 4, (const unsigned short*)x, (const unsigned short*)wp, gamma, nullptr, mean,
-               invstd, 0.f, (const unsigned short*)dout, mask, (unsigned short*)dy, (int)M, N, nullptr, nullptr, sums,
-               (float)(1.0 / count));
-    return 0;
-}
-#undef XC3_LAUNCH
-#undef XC3_LAUNCH32

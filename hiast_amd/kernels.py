@@ -1094,79 +1094,6 @@ def bn_nhwc_bwd_apply(dy, y, x, gamma, beta, save_mean, save_invstd, sums, count
     return dx, dres, dg, db
 
 
-# ------------------------------------------------------------------------------- K9i conv3 -> bn3 without a stored conv output
-def conv_bn3_ok(M, K, N):
-    import os
-    return os.environ.get("HIAST_NO_CONV_BN3", "0") != "1" and bool(_lib.load().hiast_conv_bn3_ok(int(M), int(K), int(N)))
-
-
-def conv_bn3_stats(x, wp, N):
-    """x [M,256] 16-bit rows, wp packed [N,256] -> per-block (Σy, Σy²) of y = x W^T: fp32 [rows, N, 2]; y is not stored"""
-    _req16(x, 2, "x")
-    M = x.shape[0]
-    lib = _lib.load()
-    rows = lib.hiast_conv_bn3_stats_rows(M, N, 0)
-    if rows == 0:
-        raise _lib.HiastLibraryError("hiast_conv_bn3: unsupported shape M=%d N=%d" % (M, N))
-    part = torch.empty((rows, N, 2), dtype=torch.float32, device=x.device)
-    check(lib.hiast_conv_bn3_stats(_ptr(x), _ptr(wp), M, N, fmt_of(x), _ptr(part), _stream()), "hiast_conv_bn3_stats")
-    return part
-
-
-def bn_finalize(C, count, momentum, eps, running_mean, running_var, partial=None, sums=None):
-    """batch mean / invstd (+ running-statistics update) from per-block partials [nblk,C,2] or double sums [C,2]"""
-    dev = (partial if partial is not None else sums).device
-    sm = torch.empty(C, dtype=torch.float32, device=dev)
-    si = torch.empty(C, dtype=torch.float32, device=dev)
-    lib = _lib.load()
-    if partial is not None:
-        _req(partial, torch.float32, 3, "partial")
-        check(lib.hiast_bn_nhwc_finalize_partial(_ptr(partial), partial.shape[0], C, float(count), float(momentum), float(eps),
-                                                 _ptr(running_mean), _ptr(running_var), _ptr(sm), _ptr(si), _stream()),
-              "hiast_bn_nhwc_finalize_partial")
-    else:
-        _req(sums, torch.float64, 2, "sums")
-        check(lib.hiast_bn_nhwc_finalize_sums(_ptr(sums), C, float(count), float(momentum), float(eps), _ptr(running_mean),
-                                              _ptr(running_var), _ptr(sm), _ptr(si), _stream()), "hiast_bn_nhwc_finalize_sums")
-    return sm, si
-
-
-def conv_bn3_fwd(x, wp, gamma, beta, mean, invstd, res):
-    """-> (out [M,N] = relu(bn(x W^T) + res) 16-bit rows, mask u8 [M, N/8])"""
-    _req16(x, 2, "x")
-    _req(res, x.dtype, 2, "res")
-    M, N = res.shape
-    out = torch.empty_like(res)
-    mask = torch.empty((M, N // 8), dtype=torch.uint8, device=x.device)
-    check(_lib.load().hiast_conv_bn3_fwd(_ptr(x), _ptr(wp), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(invstd), _ptr(res),
-                                         _ptr(out), _ptr(mask), M, N, fmt_of(x), _stream()), "hiast_conv_bn3_fwd")
-    return out, mask
-
-
-def conv_bn3_bwd_stats(x, wp, mean, invstd, dout, mask):
-    """-> per-block (Σg, Σ g xhat): fp32 [rows, N, 2]"""
-    _req16(x, 2, "x")
-    _req(dout, x.dtype, 2, "dout")
-    M, N = dout.shape
-    lib = _lib.load()
-    rows = lib.hiast_conv_bn3_stats_rows(M, N, 1)
-    part = torch.empty((rows, N, 2), dtype=torch.float32, device=x.device)
-    check(lib.hiast_conv_bn3_bwd_stats(_ptr(x), _ptr(wp), _ptr(mean), _ptr(invstd), _ptr(dout), _ptr(mask), M, N, fmt_of(x),
-                                       _ptr(part), _stream()), "hiast_conv_bn3_bwd_stats")
-    return part
-
-
-def conv_bn3_bwd_apply(x, wp, gamma, mean, invstd, sums, count, dout, mask):
-    """-> dy [M,N] 16-bit rows: the gradient w.r.t. y = x W^T"""
-    _req(sums, torch.float64, 2, "sums")
-    M, N = dout.shape
-    dy = torch.empty_like(dout)
-    check(_lib.load().hiast_conv_bn3_bwd_apply(_ptr(x), _ptr(wp), _ptr(gamma), _ptr(mean), _ptr(invstd), _ptr(sums), float(count),
-                                               _ptr(dout), _ptr(mask), _ptr(dy), M, N, fmt_of(x), _stream()),
-          "hiast_conv_bn3_bwd_apply")
-    return dy
-
-
 # ------------------------------------------------------------------------------- K9d conv weight gradient (NHWC bf16)
 _wgrad_ws = {}
 

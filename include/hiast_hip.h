@@ -343,39 +343,6 @@ size_t hiast_bn_nhwc_workspace_bytes(int C);
 int hiast_bn_nhwc_stats(const void* x, int64_t M, int C, double* sums, void* workspace, size_t workspace_bytes, int fmt,
                         hiast_stream_t stream);
 int hiast_bn_nhwc_stats_from_partial(const float* partial, int nblk, int C, double* sums, hiast_stream_t stream);
-
-/* Batch statistics alone (mean, 1/sqrt(var + eps), running-statistics update as nn.BatchNorm2d.forward in train()), for
- * callers that normalise inside another kernel (hiast_conv_bn3_*): from per-block partial sums [nblk][C][2] in one launch
- * (single rank) or from (all-reduced) double sums [C][2]. */
-int hiast_bn_nhwc_finalize_partial(const float* partial, int nblk, int C, double count, float momentum, float eps,
-                                   float* running_mean, float* running_var, float* save_mean, float* save_invstd,
-                                   hiast_stream_t stream);
-int hiast_bn_nhwc_finalize_sums(const double* sums, int C, double count, float momentum, float eps, float* running_mean,
-                                float* running_var, float* save_mean, float* save_invstd, hiast_stream_t stream);
-
-/* ---- K9i: conv3 -> bn3 (-> + identity -> ReLU) of a bottleneck in train() WITHOUT a stored convolution output
- * (sseg/models/modules/resnet.py:88-98: out = relu(bn3(conv3(x)) + identity), and its autograd).  The 1x1 GEMM
- * y = x W^T (x [M][256] 16-bit channels-last rows, W [N][256] packed by hiast_pack_conv_weight, N % 512 == 0,
- * M >= 4096: hiast_conv_bn3_ok) is recomputed by every pass that needs y; none of them writes it:
- *   _stats      per-block (Σy, Σy²) -> partial [hiast_conv_bn3_stats_rows(M, N, 0)][N][2]
- *   _fwd        out = relu((y - mean) invstd gamma + beta + res) as 16-bit rows + mask u8 [M][N/8] (bit c & 7 of byte
- *               c / 8 = out[m][c] > 0)
- *   _bwd_stats  per-block (Σg, Σ g xhat), g = dout where the mask bit is set, xhat = (y - mean) invstd
- *               -> partial [hiast_conv_bn3_stats_rows(M, N, 1)][N][2]
- *   _bwd_apply  dy = gamma invstd (g - sums[c][0] / count - xhat sums[c][1] / count): the gradient w.r.t. y (16-bit rows),
- *               input of the convolution's own data / weight gradient; dgamma = sums[.][1], dbeta = sums[.][0].
- * fmt = HIAST_FMT_BF16 / HIAST_FMT_FP16. */
-int hiast_conv_bn3_ok(int64_t M, int K, int N);
-int hiast_conv_bn3_stats_rows(int64_t M, int N, int backward);
-int hiast_conv_bn3_stats(const void* x, const void* wp, int64_t M, int N, int fmt, float* partial, hiast_stream_t stream);
-int hiast_conv_bn3_fwd(const void* x, const void* wp, const float* gamma, const float* beta, const float* mean,
-                       const float* invstd, const void* res, void* out, uint8_t* mask, int64_t M, int N, int fmt,
-                       hiast_stream_t stream);
-int hiast_conv_bn3_bwd_stats(const void* x, const void* wp, const float* mean, const float* invstd, const void* dout,
-                             const uint8_t* mask, int64_t M, int N, int fmt, float* partial, hiast_stream_t stream);
-int hiast_conv_bn3_bwd_apply(const void* x, const void* wp, const float* gamma, const float* mean, const float* invstd,
-                             const double* sums, double count, const void* dout, const uint8_t* mask, void* dy, int64_t M,
-                             int N, int fmt, hiast_stream_t stream);
 /* single-rank forward straight from the per-block partial sums (no all-reduce point): statistics + apply */
 int hiast_bn_nhwc_apply_partial(const void* x, const void* res, void* y, const float* gamma, const float* beta,
                                 float* running_mean, float* running_var, const float* partial, int nblk, double count,

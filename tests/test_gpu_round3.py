@@ -180,55 +180,3 @@ def test_conv_wgrad_small_channels(K, cfg, dt):
     err = (dw - ref).abs().max().item()
     assert err <= 1e-4 * ref.abs().max().item(), (cfg, err, ref.abs().max().item())
     assert torch.equal(dw, K.conv_wgrad_small_nhwc(dy, x, k, stride, dil))
-
-
-@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("MN", [(8192, 1024), (4096 + 37, 512), (65536, 1024)])
-def test_conv_bn3_chain_on_recomputed_gemms(K, dt, MN):
-    """K9i (hiast_conv_bn3_*): statistics / forward / backward sums / backward apply of conv3 -> bn3 -> (+ identity) -> ReLU,
-    each recomputing y = x W^T instead of reading a stored copy, against float64 on the same 16-bit operands; ragged M
-    (a tail panel), many panels per block (M = 65536)"""
-    M, N = MN
-    Kc = 256
-    x = dev(synth.normal_f32(3600, (M, Kc))).to(dt)
-    w = dev(synth.normal_f32(3601, (N, Kc, 1, 1), (2.0 / Kc) ** 0.5))
-    res = dev(synth.normal_f32(3602, (M, N))).to(dt)
-    dout = dev(synth.normal_f32(3603, (M, N))).to(dt)
-    gamma = dev(synth.normal_f32(3604, (N,), 0.3)) + 1.0
-    beta = dev(synth.normal_f32(3605, (N,), 0.2))
-    rm, rv = torch.zeros(N, device="cuda"), torch.ones(N, device="cuda")
-    assert K.conv_bn3_ok(M, Kc, N)
-    wp = K.pack_conv_weight(w, K.fmt_of(x))
-    wq = w.view(N, Kc).to(dt).double()
-    y = x.double() @ wq.t()                                        # float64 on the operands the kernel multiplies
-    # statistics
-    part = K.conv_bn3_stats(x, wp, N)
-    sums = part.double().sum(0)
-    assert torch.allclose(sums[:, 0], y.sum(0), rtol=1e-5, atol=1e-3 * float(y.abs().max()))
-    assert torch.allclose(sums[:, 1], (y * y).sum(0), rtol=1e-5)
-    sm, si = K.bn_finalize(N, M, 0.1, 1e-5, rm, rv, partial=part)
-    mean, var = y.mean(0), y.var(0, unbiased=False)
-    assert torch.allclose(sm.double(), mean, atol=1e-5 * float(y.abs().max())) and torch.allclose(si.double(), (var + 1e-5).rsqrt(), rtol=1e-5)
-    assert torch.allclose(rm.double(), 0.1 * mean, atol=1e-6) and torch.allclose(rv.double(), 0.9 + 0.1 * y.var(0, unbiased=True), rtol=1e-5)
-    # forward
-    out, mask = K.conv_bn3_fwd(x, wp, gamma, beta, sm, si, res)
-    xhat = (y - sm.double()) * si.double()
-    pre = xhat * gamma.double() + beta.double() + res.double()
-    ref = pre.clamp_min(0)
-    ulp = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
-    assert bool(((out.double() - ref).abs() <= ulp * ref.abs() + 1e-5 * float(pre.abs().max())).all())
-    bits = ((mask.view(M, N // 8, 1) >> torch.arange(8, device="cuda", dtype=torch.uint8)) & 1).view(M, N).bool()
-    assert torch.equal(bits, out > 0)
-    assert float((bits != (pre > 0)).double().mean()) < 1e-4       # (differs only where |pre| is at rounding level)
-    # backward sums: g = dout where the gate is open
-    g = dout.double() * bits.double()
-    bpart = K.conv_bn3_bwd_stats(x, wp, sm, si, dout, mask)
-    bsums = K.bn_nhwc_stats_from_partial(bpart)
-    assert torch.allclose(bsums[:, 0], g.sum(0), rtol=1e-5, atol=1e-3 * float(g.abs().max()))
-    assert torch.allclose(bsums[:, 1], (g * xhat).sum(0), rtol=1e-4, atol=1e-3 * float((g * xhat).abs().max()))
-    # backward apply
-    dy = K.conv_bn3_bwd_apply(x, wp, gamma, sm, si, bsums, M, dout, mask)
-    dref = gamma.double() * si.double() * (g - bsums[:, 0] / M - xhat * bsums[:, 1] / M)
-    assert bool(((dy.double() - dref).abs() <= ulp * dref.abs() + 2e-5 * float(dref.abs().max())).all())
-    # nothing is written behind the last row (tail panel)
-    assert torch.equal(K.conv_bn3_bwd_apply(x, wp, gamma, sm, si, bsums, M, dout, mask), dy)
