@@ -61,7 +61,7 @@ SIGNATURES = {
     "hiast_conv_wgrad_workspace_bytes": (c_sz, [c_int] * 6),
     "hiast_conv_wgrad_nhwc": (c_int, [c_vp, c_vp, c_vp] + [c_int] * 9 + [c_vp, c_sz, c_vp]),
     "hiast_conv_wgrad_small_workspace_bytes": (c_sz, [c_int] * 6),
-    "hiast_conv_wgrad_small_nhwc": (c_int, [c_vp, c_vp, c_vp] + [c_int] * 8 + [c_vp, c_sz, c_vp]),
+    "hiast_conv_wgrad_small_nhwc": (c_int, [c_vp, c_vp, c_vp] + [c_int] * 9 + [c_vp, c_sz, c_vp]),
     "hiast_pack_conv_weight": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "hiast_bn_nhwc_workspace_bytes": (c_sz, [c_int]),
     "hiast_bn_nhwc_stats": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_sz, c_int, c_vp]),

@@ -31,7 +31,8 @@ struct WSArgs {
     const unsigned short* J;      // j operand [M][CJ] (X when taps = 9)
     float* P;                     // partial tiles [split][it][jt][TI][128]
     int M, CI, CJ;
-    int H, W, dil;                // 3x3: map geometry (stride 1, 'same' padding)
+    int H, W, dil;                // 3x3: OUTPUT map geometry ('same' padding = dil)
+    int stride, Hin, Win;         // 3x3: input map (stride 1: the same map)
     int m_per_split, ni, nj;
 };
 
@@ -82,18 +83,19 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WSArgs g)
     const int oy = TAPS == 9 ? (jtap / 3 - 1) * g.dil : 0, ox = TAPS == 9 ? (jtap % 3 - 1) * g.dil : 0;
     const long long jshift = (long long)(oy * g.W + ox) * g.CJ + jc8;       // elements from X[m][0] to this thread's chunk
     constexpr int NU = KS / 16;                          // 16-byte chunks per thread and tile (j tile; i tile for TI = 128)
-    int wy[NU], wx[NU];
+    int wy[NU], wx[NU], wi[NU];
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-        wy[u] = 0; wx[u] = 0;
+        wy[u] = 0; wx[u] = 0; wi[u] = 0;
         if (TAPS == 9) {
             const int m = m_begin + (tid >> 4) + 16 * u;
             const int r = m % (g.H * g.W);
-            wy[u] = r / g.W + oy;                                            // input row / column incl. the tap offset
-            wx[u] = r % g.W + ox;
+            wy[u] = r / g.W + (g.stride == 1 ? oy : 0);                      // stride 1: input row / column incl. the tap offset;
+            wx[u] = r % g.W + (g.stride == 1 ? ox : 0);                      // otherwise the OUTPUT row / column
+            wi[u] = m / (g.H * g.W);
         }
     }
-    const int wx_end = g.W + ox, wy_end = g.H + oy;
+    const int wx_end = g.W + (g.stride == 1 ? ox : 0), wy_end = g.H + (g.stride == 1 ? oy : 0);
     // (two register sets — the rows of step t + 2 requested while step t is multiplied — bought nothing at TI = 64 and cost the
     // second block per CU at TI = 128: 194 VGPRs, 36.8 -> 60.8 us on the layer2 3x3)
     uint4 ri[1][NU], rj[1][NU];
@@ -117,13 +119,20 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WSArgs g)
         for (int u = 0; u < NU; ++u) {
             const int m = mrow + (tid >> 4) + 16 * u;
             bool ok = jlive && m < m_end;
+            long long at = (long long)m * g.CJ + jshift;                     // (1x1, and 3x3 stride 1: input pixel = m + tap shift)
             if (TAPS == 9) {
-                ok = ok && (unsigned)wy[u] < (unsigned)g.H && (unsigned)wx[u] < (unsigned)g.W;
+                if (g.stride == 1) {
+                    ok = ok && (unsigned)wy[u] < (unsigned)g.H && (unsigned)wx[u] < (unsigned)g.W;
+                } else {                                                     // strided: input pixel from the output position
+                    const int iy = wy[u] * g.stride + oy, ix = wx[u] * g.stride + ox;
+                    ok = ok && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
+                    at = ((long long)(wi[u] * g.Hin + iy) * g.Win + ix) * g.CJ + jc8;
+                }
                 wx[u] += KS;                                                 // the next k-step: KS output pixels on
                 while (wx[u] >= wx_end) { wx[u] -= g.W; wy[u] += 1; }
-                while (wy[u] >= wy_end) wy[u] -= g.H;
+                while (wy[u] >= wy_end) { wy[u] -= g.H; wi[u] += 1; }
             }
-            rj[SET][u] = ok ? *reinterpret_cast<const uint4*>(g.J + ((long long)m * g.CJ + jshift)) : make_uint4(0, 0, 0, 0);
+            rj[SET][u] = ok ? *reinterpret_cast<const uint4*>(g.J + at) : make_uint4(0, 0, 0, 0);
         }
     };
     auto lds_store = [&](int buf) {
@@ -232,7 +241,7 @@ struct WSPlan {
     size_t bytes;
 };
 
-static WSPlan ws_plan(int B, int H, int W, int Cin, int Cout, int taps)
+static WSPlan ws_plan(int B, int H, int W, int Cin, int Cout, int taps)   // H, W: OUTPUT map
 {
     WSPlan p = {};
     auto chan = [](int c) { return c == 64 || (c >= 128 && c <= 2048 && c % 128 == 0); };
@@ -271,9 +280,15 @@ extern "C" size_t hiast_conv_wgrad_small_workspace_bytes(int B, int H, int W, in
 }
 
 extern "C" int hiast_conv_wgrad_small_nhwc(const void* dy, const void* x, float* dw, int B, int H, int W, int Cin, int Cout,
-                                           int taps, int dil, int fmt, void* workspace, size_t workspace_bytes,
+                                           int taps, int stride, int dil, int fmt, void* workspace, size_t workspace_bytes,
                                            hiast_stream_t stream)
 {
+    // H, W: the INPUT map; a strided 3x3 ('same' padding = dil) is walked inside the kernel, a strided 1x1 is this call on
+    // the subsampled input (stride must be 1 for taps = 1)
+    if (stride <= 0 || (taps == 1 && stride != 1)) return HIAST_E_RANGE;
+    const int Hin = H, Win = W;
+    H = (H - 1) / stride + 1;
+    W = (W - 1) / stride + 1;
     if (fmt != HIAST_FMT_BF16 && fmt != HIAST_FMT_FP16) return HIAST_E_RANGE;
     if (!dy || !x || !dw || !workspace) return HIAST_E_ARG;
     if (B <= 0 || H <= 0 || W <= 0 || dil <= 0) return HIAST_E_ARG;
@@ -289,6 +304,8 @@ extern "C" int hiast_conv_wgrad_small_nhwc(const void* dy, const void* x, float*
     a.CI = p.transposed ? Cin : Cout;
     a.CJ = p.transposed ? Cout : Cin;
     a.H = H; a.W = W; a.dil = dil;
+    a.stride = stride; a.Hin = Hin; a.Win = Win;
+    if ((long long)B * Hin * Win * Cin * 2 >= (1ll << 40)) return HIAST_E_RANGE;
     a.m_per_split = p.mps; a.ni = p.ni; a.nj = p.nj;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)(p.ni * p.nj), (unsigned)p.nsplit);

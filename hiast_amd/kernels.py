@@ -1124,22 +1124,22 @@ def conv_wgrad_small_supported(Cin, Cout, k, stride):
         return c == 64 or (c >= 128 and c % 128 == 0)
     if os.environ.get("HIAST_LIB_WGRAD_SMALL", "0") == "1" or conv_wgrad_supported(Cin, Cout, k, stride):
         return False
-    return chan(Cin) and chan(Cout) and ((k == 1 and stride in (1, 2)) or (k == 3 and stride == 1))
+    return chan(Cin) and chan(Cout) and ((k == 1 and stride in (1, 2)) or k == 3)
 
 
 def conv_wgrad_small_nhwc(dy, x, k, stride, dil):
     """dy [B,Ho,Wo,Cout], x [B,H,W,Cin] bf16 / fp16 channels-last rows -> dW fp32 [Cout,Cin,k,k] (K9h)"""
     _req16(dy, 4, "dy")
     _req(x, dy.dtype, 4, "x")
-    if stride != 1:
-        assert k == 1
+    if stride != 1 and k == 1:
         x = x[:, ::stride, ::stride, :].contiguous()         # a strided 1x1 sees every stride-th pixel only
+        stride = 1
     B, H, W, Cin = x.shape
-    Cout = dy.shape[3]
-    assert tuple(dy.shape[:3]) == (B, H, W)
+    Bo, Ho, Wo, Cout = dy.shape
+    assert (Bo, Ho, Wo) == (B, (H - 1) // stride + 1, (W - 1) // stride + 1)
     taps = k * k
     lib = _lib.load()
-    n = lib.hiast_conv_wgrad_small_workspace_bytes(B, H, W, Cin, Cout, taps)
+    n = lib.hiast_conv_wgrad_small_workspace_bytes(B, Ho, Wo, Cin, Cout, taps)
     if n == 0:
         raise _lib.HiastLibraryError("hiast_conv_wgrad_small_nhwc: unsupported shape Cin=%d Cout=%d taps=%d" % (Cin, Cout, taps))
     key = ("small", x.device)
@@ -1148,7 +1148,7 @@ def conv_wgrad_small_nhwc(dy, x, k, stride, dil):
         ws = torch.empty((n + 3) // 4, dtype=torch.float32, device=x.device)
         _wgrad_ws[key] = ws
     dw = torch.empty((Cout, Cin, k, k), dtype=torch.float32, device=x.device)
-    check(lib.hiast_conv_wgrad_small_nhwc(_ptr(dy), _ptr(x), _ptr(dw), B, H, W, Cin, Cout, taps, int(dil), fmt_of(dy),
+    check(lib.hiast_conv_wgrad_small_nhwc(_ptr(dy), _ptr(x), _ptr(dw), B, H, W, Cin, Cout, taps, int(stride), int(dil), fmt_of(dy),
                                           _ptr(ws), ws.numel() * 4, _stream()), "hiast_conv_wgrad_small_nhwc")
     return dw
 

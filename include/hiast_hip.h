@@ -325,13 +325,14 @@ int hiast_conv_wgrad_nhwc(const void* dy, const void* x, float* dw, int B, int H
                           void* workspace, size_t workspace_bytes, hiast_stream_t stream);
 
 /* ---- K9h: the same weight gradient for the layers BELOW 256 channels (layer1 / layer2: Cin, Cout in {64, 128, 256, ...,
- * multiples of 128}; 1x1 and 3x3, stride 1, 'same' padding = dil for 3x3) — autograd of nn.Conv2d in
- * sseg/models/modules/resnet.py:78-98.  dy [B,H,W,Cout], x [B,H,W,Cin] 16-bit channels-last rows (fmt = HIAST_FMT_BF16 /
+ * multiples of 128}; 1x1 (stride 1) and 3x3 (any stride, 'same' padding = dil)) — autograd of nn.Conv2d in
+ * sseg/models/modules/resnet.py:78-98.  x [B,H,W,Cin], dy [B,Ho,Wo,Cout] (Ho = (H-1)/stride + 1) 16-bit channels-last rows;
+ * hiast_conv_wgrad_small_workspace_bytes takes the OUTPUT map size (fmt = HIAST_FMT_BF16 /
  * _FP16), dw fp32 [Cout][Cin][kh][kw], fp32 accumulation, pixel ranges reduced in a fixed order (bitwise reproducible).
  * A strided 1x1 is this call on the subsampled input. */
 size_t hiast_conv_wgrad_small_workspace_bytes(int B, int H, int W, int Cin, int Cout, int taps);
 int hiast_conv_wgrad_small_nhwc(const void* dy, const void* x, float* dw, int B, int H, int W, int Cin, int Cout, int taps,
-                                int dil, int fmt, void* workspace, size_t workspace_bytes, hiast_stream_t stream);
+                                int stride, int dil, int fmt, void* workspace, size_t workspace_bytes, hiast_stream_t stream);
 
 /* ---- K10b: BatchNorm2d (+ residual) (+ ReLU), TRAINING mode, on channels-last bf16 activations [M = B*H*W][C] ------
  * Same arithmetic and passes as K10 (resnet.py:78-98 in train(): batch statistics even with frozen affine

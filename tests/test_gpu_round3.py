@@ -158,7 +158,9 @@ SMALL_WGRAD = [(2, 64, 64, 19, 33, 1, 1, 1),      # layer1.0.conv1: both operand
                (2, 256, 512, 26, 42, 1, 1, 2),    # layer2.0.downsample
                (3, 128, 128, 13, 21, 3, 1, 1),    # layer2.x.conv2
                (1, 128, 128, 40, 64, 3, 2, 1),    # dilated 3x3, many pixel ranges
-               (8, 64, 64, 64, 128, 3, 1, 1)]     # 65536 pixels: hundreds of ranges, XCD order with a ragged block count
+               (8, 64, 64, 64, 128, 3, 1, 1),     # 65536 pixels: hundreds of ranges, XCD order with a ragged block count
+               (2, 128, 128, 27, 45, 3, 1, 2),    # layer2.0.conv2: strided 3x3 (input pixel from the output position)
+               (3, 64, 64, 16, 20, 3, 2, 2)]      # strided + dilated, tap pairs, several images
 
 
 @pytest.mark.parametrize("cfg", SMALL_WGRAD)
