@@ -75,6 +75,7 @@ SIGNATURES = {
     "hiast_pack_conv_weight_multi": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
     "hiast_split_planes": (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
     "hiast_stem_tail": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "hiast_stem_eval": (c_int, [c_vp] * 6 + [c_f32, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "hiast_ema_update": (c_int, [c_vp, c_vp, c_vp, c_int, c_f32, c_f32, c_vp]),
     "hiast_normalize_u8": (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_vp, c_vp]),
     "hiast_maxpool3x3s2_nhwc_fwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),

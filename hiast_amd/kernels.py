@@ -800,6 +800,34 @@ def stem_tail(x, bn, fmt):
     return out
 
 
+def stem_eval_supported(conv, bn, pool):
+    """the module triple hiast_stem_eval replaces: Conv2d(3, 64, 7, 2, 3, bias=False) -> BatchNorm2d(64) (eval) -> ReLU ->
+    MaxPool2d(3, 2, 1)"""
+    import os
+    return (os.environ.get("HIAST_NO_STEM_FUSED", "0") != "1"
+            and (conv.in_channels, conv.out_channels, conv.kernel_size, conv.stride, conv.padding, conv.dilation, conv.groups)
+            == (3, 64, (7, 7), (2, 2), (3, 3), (1, 1), 1) and conv.bias is None and bn.num_features == 64 and not bn.training
+            and (pool.kernel_size, pool.stride, pool.padding, pool.dilation, pool.ceil_mode) == (3, 2, 1, 1, False))
+
+
+def stem_eval(x, weight, bn, fmt):
+    """K9j: conv 7x7 s2 -> bn (eval) -> ReLU -> MaxPool2d(3, 2, 1) in one kernel.
+    x fp32 [B,3,H,W] -> [B,Hp,Wp,planes*64] in operand format `fmt` (FMT_BF16 | FMT_SPLIT_BF16 | FMT_FP16)"""
+    x = x.contiguous()                    # NCHW (a channels-last or sliced batch is copied: 6 MB per image)
+    _req(x, torch.float32, 4, "x")
+    _req(weight, torch.float32, 4, "stem weight")
+    assert tuple(weight.shape) == (64, 3, 7, 7) and x.shape[1] == 3
+    fmt = int(fmt)
+    B, _, H, W = x.shape
+    Hc, Wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    Hp, Wp = (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1
+    out = torch.empty((B, Hp, Wp, (2 if fmt == FMT_SPLIT_BF16 else 1) * 64), dtype=fmt_dtype(fmt), device=x.device)
+    g, b, mu, var, eps = _bn_params(bn)
+    check(_lib.load().hiast_stem_eval(_ptr(x), _ptr(weight), g, b, mu, var, eps, _ptr(out), fmt, B, H, W, _stream()),
+          "hiast_stem_eval")
+    return out
+
+
 # ------------------------------------------------------------------------------- K9c LDS-DMA implicit GEMM on split planes
 # A "split-plane" activation is an opaque bf16 tensor [B,H,W,2*C] holding hi = bf16(v) and lo = bf16(v - hi) of an
 # fp32-class value (layout inside the last axis: include/hiast_hip.h, K9c); plain bf16 activations are [B,H,W,C].

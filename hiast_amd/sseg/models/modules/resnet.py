@@ -189,6 +189,14 @@ class ResNet(nn.Module):
         """PL: operand format (K.FMT_*) -> trunk feature as a 16-bit channels-last tensor [B,h,w,planes*2048]"""
         from hiast_amd import kernels as K
         self.prepack(PL)
+        if K.stem_eval_supported(self.conv1, self.bn1, self.maxpool) and x.dtype == torch.float32 and x.shape[1] == 3:
+            # conv1 -> bn1 -> ReLU -> maxpool -> operand format of the trunk kernels in ONE kernel (K9j): the full-resolution
+            # stem output is never stored
+            o = K.stem_eval(x, self.conv1.weight.detach(), self.bn1, PL)
+            for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
+                for blk in stage:
+                    o = blk.forward_eval_planes(o, PL)
+            return o
         x = x.contiguous(memory_format=torch.channels_last)
         o = self.conv1(x)                 # library 7x7 stem (bf16 output under autocast)
         o = o.contiguous(memory_format=torch.channels_last)

@@ -304,6 +304,14 @@ int hiast_split_planes(float* x, void* planes, int64_t M, int C, int inverse, hi
 int hiast_stem_tail(const void* x, int dtype /* 0 fp32 | 1 bf16 | 2 fp16 */, const float* gamma, const float* beta,
                     const float* mean, const float* var, float eps, void* out, int fmt /* HIAST_FMT_* of out */, int B, int H,
                     int W, int C, hiast_stream_t stream);
+/* K9j hiast_stem_eval: the whole stem of an inference forward in ONE kernel — conv 7x7 / stride 2 / padding 3 (3 -> 64, no bias)
+ * -> bn1 (eval) -> ReLU -> MaxPool2d(3, stride 2, padding 1) (ResNet.forward, sseg/models/modules/resnet.py:180-184), written in
+ * the operand format of the trunk kernels; the full-resolution convolution output is never stored.
+ * x: fp32 [B,3,H,W] contiguous (NCHW), w: fp32 [64,3,7,7] (nn.Conv2d layout), gamma / beta may be NULL (1 / 0);
+ * out: [B,Hp,Wp,planes*64] in format fmt (HIAST_FMT_BF16 | _SPLIT_BF16 | _FP16), Hc = (H-1)/2+1, Hp = (Hc-1)/2+1 (same for W).
+ * Arithmetic: fmt's 16-bit operands (split planes: hi*hi + lo*hi + hi*lo) with fp32 accumulation. */
+int hiast_stem_eval(const float* x, const float* w, const float* gamma, const float* beta, const float* mean, const float* var,
+                    float eps, void* out, int fmt, int B, int H, int W, hiast_stream_t stream);
 /* hiast_pack_conv_weight for a list of weights in ONE launch (a trunk's 104 convolutions after every optimiser / EMA
  * update).  table: device array of records (mode = the `transpose` argument above; N, K multiples of 64, taps <= 9);
  * one block per 64 x 64 (n, k) tile of one weight: chunk_tensor[b] = record index, chunk_start[b] = index of the tile

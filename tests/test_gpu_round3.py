@@ -182,3 +182,65 @@ def test_conv_wgrad_small_channels(K, cfg, dt):
     err = (dw - ref).abs().max().item()
     assert err <= 1e-4 * ref.abs().max().item(), (cfg, err, ref.abs().max().item())
     assert torch.equal(dw, K.conv_wgrad_small_nhwc(dy, x, k, stride, dil))
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 67, 101), (2, 9, 14), (3, 130, 258), (1, 512, 1024)])
+@pytest.mark.parametrize("fmt", [1, 2, 3])
+def test_stem_eval_fused(K, shape, fmt):
+    """K9j (stem.hip): conv 7x7 s2 -> bn (eval) -> ReLU -> MaxPool2d(3, 2, 1) in one kernel vs float64 torch on the operand
+    values the kernel multiplies (16-bit formats: x and W rounded to the type; split planes: the fp32 values), every output
+    format, odd sizes (ragged tiles, pooling windows over the map's border), image sizes below one tile"""
+    B, H, W = shape
+    x = dev(synth.normal_f32(3700, (B, 3, H, W)))
+    w = dev(synth.normal_f32(3701, (64, 3, 7, 7), 0.15))
+    bn = torch.nn.BatchNorm2d(64).cuda().eval()
+    with torch.no_grad():
+        bn.weight.copy_(dev(synth.normal_f32(3702, (64,), 0.3)) + 1.0)
+        bn.bias.copy_(dev(synth.normal_f32(3703, (64,), 0.3)))
+        bn.running_mean.copy_(dev(synth.normal_f32(3704, (64,), 0.5)))
+        bn.running_var.copy_(dev(synth.normal_f32(3705, (64,), 0.2)).abs() + 0.5)
+    out = K.stem_eval(x, w, bn, fmt)
+    dt = {1: torch.bfloat16, 3: torch.float16}.get(fmt)
+    xq = x.to(dt).double() if dt is not None else x.double()
+    wq = w.to(dt).double() if dt is not None else w.double()
+    y = torch.nn.functional.conv2d(xq, wq, None, 2, 3)
+    y = torch.nn.functional.batch_norm(y, bn.running_mean.double(), bn.running_var.double(), bn.weight.double(), bn.bias.double(),
+                                       False, 0.0, bn.eps).clamp_min(0)
+    ref = torch.nn.functional.max_pool2d(y, 3, 2, 1).permute(0, 2, 3, 1)
+    Hp, Wp = ref.shape[1], ref.shape[2]
+    assert tuple(out.shape) == (B, Hp, Wp, 64 * (2 if fmt == 2 else 1))
+    got = (K.merge_planes(out.view(-1, 128)).view(B, Hp, Wp, 64) if fmt == 2 else out.float()).double()
+    ulp = {1: 2.0 ** -8, 2: 0.0, 3: 2.0 ** -11}[fmt]
+    tol = ulp * ref.abs() + 3e-5 * float(ref.abs().max())
+    assert bool(((got - ref).abs() <= tol).all()), (shape, fmt, float((got - ref).abs().max()), float(ref.abs().max()))
+
+
+def test_stem_eval_in_the_eval_forward_matches_the_module_path(K, monkeypatch):
+    """ResNet.forward_eval_planes with the fused stem vs the same forward with HIAST_NO_STEM_FUSED=1 (library convolution +
+    hiast_stem_tail): the trunk feature agrees to the rounding of the 16-bit stem output / 1e-4 in the fp32-class format"""
+    from hiast_amd.sseg.models.modules.resnet import build_resnet101
+    from hiast_amd.tools import synth_data
+    torch.manual_seed(5)
+    x = dev(synth.normal_f32(3710, (2, 3, 64, 96)))
+    m = synth_data.calibrate_bn(build_resnet101(False, 8).cuda(), x).eval()    # (running statistics of the data: fp16 range)
+    with torch.no_grad():
+        a = m(x)
+        monkeypatch.setenv("HIAST_NO_STEM_FUSED", "1")
+        b = m(x)
+        monkeypatch.setenv("HIAST_NO_FAST_EVAL", "1")
+        c = m(x)                                                   # module path: the library's fp32 convolutions
+        monkeypatch.delenv("HIAST_NO_STEM_FUSED")
+        monkeypatch.delenv("HIAST_NO_FAST_EVAL")
+        s = float(c.abs().max())
+        # (33 blocks amplify a 1e-5 difference at the stem a few hundred times: the yardstick is how far the tail path is
+        # from the library's fp32 forward)
+        ea, eb = float((a - c).abs().max()), float((b - c).abs().max())
+        assert ea <= 2.0 * eb + 1e-4 * s and ea <= 2e-2 * s, (ea / s, eb / s)
+        with torch.autocast("cuda", dtype=torch.float16):
+            a16 = m(x).float()
+            monkeypatch.setenv("HIAST_NO_STEM_FUSED", "1")
+            b16 = m(x).float()
+        assert bool(torch.isfinite(a16).all()) and bool(torch.isfinite(b16).all())
+        # the fused stem skips one fp16 rounding (the convolution output): at least as close to the fp32 forward
+        ea, eb = float((a16 - c).abs().max()), float((b16 - c).abs().max())
+        assert ea <= 1.5 * eb + 1e-3 * s, (ea / s, eb / s)
