@@ -1,10 +1,13 @@
+"""fused inference stem (K9j, hiast_stem_eval) against library convolution + hiast_stem_tail: agreement on a calibrated random-init
+ResNet-101 and kernel time at B = 8, 512x1024: python tools/ab_stem.py  (library via HIAST_LIB)"""
 import os, sys, torch
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import synth
 from hiast_amd import kernels as K
 from hiast_amd.tools import synth_data
 from hiast_amd.sseg.models.modules.resnet import build_resnet101
-sys.path.insert(0, "/root/repo/tools")
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 from ab_igemm import timeit
 torch.manual_seed(5)
 x = torch.from_numpy(synth.normal_f32(3710, (2, 3, 64, 96))).cuda()
