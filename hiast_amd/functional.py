@@ -180,13 +180,13 @@ def _sync_world(bn):
     return 1
 
 
-def _stat_all_reduce(t):
+def _stat_all_reduce(t, async_op=False):
     """SyncBN exchange: sum of the per-rank statistics, on the communicator reserved for it (utils/comm.py: these
     [C,2] reduces sit between two kernels of the main stream and must not queue behind DDP's 32 MB gradient buckets or
-    the pseudo-label histogram on the default communicator)"""
+    the pseudo-label histogram on the default communicator).  async_op: -> the work handle (the caller waits)"""
     import torch.distributed as dist
     from hiast_amd.utils import comm
-    dist.all_reduce(t, group=comm.stat_group())
+    return dist.all_reduce(t, group=comm.stat_group(), async_op=async_op)
 
 
 class _BnActFn(torch.autograd.Function):
@@ -272,6 +272,7 @@ class _BnActNhwcFn(torch.autograd.Function):
         ctx.stat_box = None
         if stat_box is not None and ctx.gate == 2:
             stat_box["bn"] = (x.detach(), sm, si, gamma, beta)
+            stat_box["world"] = world
             ctx.stat_box = stat_box
         return y
 
@@ -282,12 +283,17 @@ class _BnActNhwcFn(torch.autograd.Function):
             dy = dy.to(x.dtype)
         dy = dy.contiguous(memory_format=torch.channels_last)
         fused = ctx.stat_box.pop("bwd_partial", None) if ctx.stat_box is not None else None
-        if fused is not None:          # per-block sums from the epilogue of the consuming convolution's data gradient
-            sums = K.bn_nhwc_stats_from_partial(fused)
+        early = ctx.stat_box.pop("bwd_sums", None) if ctx.stat_box is not None else None
+        if early is not None:          # SyncBN: the consuming convolution's backward has reduced its epilogue sums and started
+            sums, work = early         # the all-reduce BEFORE its weight gradient: the exchange ran beside that kernel
+            work.wait()
         else:
-            sums = K.bn_nhwc_bwd_stats(dy, y, x, gamma, beta, sm, si, ctx.gate)
-        if ctx.world > 1:
-            _stat_all_reduce(sums)
+            if fused is not None:      # per-block sums from the epilogue of the consuming convolution's data gradient
+                sums = K.bn_nhwc_stats_from_partial(fused)
+            else:
+                sums = K.bn_nhwc_bwd_stats(dy, y, x, gamma, beta, sm, si, ctx.gate)
+            if ctx.world > 1:
+                _stat_all_reduce(sums)
         want_p = gamma is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3])
         handoff = ctx.box is not None and ctx.needs_input_grad[1]
         dx, dres, dg, db = K.bn_nhwc_bwd_apply(dy, y, x, gamma, beta, sm, si, sums, ctx.count, ctx.gate,
@@ -356,7 +362,14 @@ class _ConvNhwcFn(torch.autograd.Function):
                 bx, sm, si, gamma, beta = ctx.in_bn["bn"]
                 dxv, bpartial = K.igemm_dgrad_bn_stats(dy.permute(0, 2, 3, 1), wpt, dil, bx.permute(0, 2, 3, 1), gamma, beta,
                                                        sm, si)
-                ctx.in_bn["bwd_partial"] = bpartial
+                if ctx.in_bn.get("world", 1) > 1 and os.environ.get("HIAST_NO_ASYNC_STAT", "0") != "1":
+                    # SyncBN: reduce the per-block sums now and start their all-reduce; the weight gradient below (50 - 300 us,
+                    # on the main stream under DDP) runs while the [C,2] exchange (a latency, ~30 us on 8 devices) is in
+                    # flight — the BatchNorm's backward then finds the reduced sums instead of waiting for the exchange
+                    bsums = K.bn_nhwc_stats_from_partial(bpartial)
+                    ctx.in_bn["bwd_sums"] = (bsums, _stat_all_reduce(bsums, async_op=True))
+                else:
+                    ctx.in_bn["bwd_partial"] = bpartial
                 dx = dxv.permute(0, 3, 1, 2)
             elif gated is not None:    # + dy_block * (y_block > 0): the identity branch's gradient, in the epilogue
                 dx = K.igemm_bn_act(dy.permute(0, 2, 3, 1), wpt, 1, None, gated[0].permute(0, 2, 3, 1), False, 1, dil,
