@@ -60,6 +60,8 @@ SIGNATURES = {
     "hiast_bn_nhwc_stats_from_partial": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
     "hiast_conv_wgrad_workspace_bytes": (c_sz, [c_int] * 6),
     "hiast_conv_wgrad_nhwc": (c_int, [c_vp, c_vp, c_vp] + [c_int] * 9 + [c_vp, c_sz, c_vp]),
+    "hiast_conv_wgrad_group_workspace_bytes": (c_sz, [c_vp, c_int]),
+    "hiast_conv_wgrad_group_nhwc": (c_int, [c_vp, c_int, c_int, c_vp, c_sz, c_vp]),
     "hiast_conv_wgrad_small_workspace_bytes": (c_sz, [c_int] * 6),
     "hiast_conv_wgrad_small_nhwc": (c_int, [c_vp, c_vp, c_vp] + [c_int] * 9 + [c_vp, c_sz, c_vp]),
     "hiast_pack_conv_weight": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
@@ -85,6 +87,14 @@ SIGNATURES = {
     "hiast_adam_step": (c_int, [c_vp, c_vp, c_vp, c_int, ctypes.c_double, ctypes.c_double, c_f32, c_f32, c_vp, c_vp]),
     "hiast_confusion_hist": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp]),
 }
+
+
+
+class WgradJob(ctypes.Structure):
+    """hiast_wgrad_job of include/hiast_hip.h"""
+    _fields_ = [("dy", c_vp), ("x", c_vp), ("dw", c_vp)] + [(n, ctypes.c_int32) for n in
+                                                             ("B", "H", "W", "Cin", "Cout", "taps", "stride", "dil")]
+
 
 NBINS = 15361
 PROB_FX_SHIFT = 30
@@ -114,7 +124,7 @@ def load():
             raise HiastLibraryError("libhiast_hip.so does not export %s" % name) from e
         fn.restype = res
         fn.argtypes = args
-    if lib.hiast_version() != 3:
+    if lib.hiast_version() != 4:
         raise HiastLibraryError("libhiast_hip.so ABI version mismatch")
     _lib = lib
     return lib

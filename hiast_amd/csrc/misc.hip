@@ -85,7 +85,9 @@ __global__ __launch_bounds__(256) void multi_copy_kernel(const hiast_copy_rec* _
 // the bias corrections that count implies — and adam_kernel reads it; the host never waits for found_inf (GradScaler's
 // own `if not found_inf.item(): optimizer.step()` drains the launch queue once per iteration).  The host keeps counting
 // ATTEMPTED steps per tensor (record field `step`); the device counts the skipped ones; a tensor's applied-step count is
-// the difference, so tensors that join later or sit out a step (grad None) keep their own counts, as in torch.
+// the difference.  The skipped count is ONE number for all tensors: the host (utils.FusedAdam.step) folds it into the
+// per-tensor counts whenever the set of participating tensors changes (a tensor joins later or sits out a step with grad
+// None), so between two folds every counted tensor took part in every step and keeps its own count, as in torch.
 __global__ void adam_prepare_kernel(hiast_adam_ctl* __restrict__ ctl, const float* __restrict__ grad_scale,
                                     const float* __restrict__ found_inf)
 {
@@ -109,7 +111,8 @@ __global__ __launch_bounds__(256) void adam_kernel(const hiast_adam_rec* __restr
     if (ctl) {                                // device-side control block: skipped step / loss scale / skipped-step count
         if (ctl->skip != 0.f) return;
         inv_scale = ctl->inv_scale;
-        const double t = (double)(r.step - ctl->skipped);            // applied steps of THIS tensor, this one included
+        double t = (double)(r.step - ctl->skipped);                  // applied steps of THIS tensor, this one included
+        t = t < 1.0 ? 1.0 : t;                // (the host folds the counts when the set of tensors changes; never 1 - beta^0)
         bc1 = (float)(1.0 - pow(beta1d, t));  // torch: 1 - beta1 ** step and sqrt(1 - beta2 ** step), formed in double
         bc2_sqrt = (float)sqrt(1.0 - pow(beta2d, t));
     }

@@ -82,31 +82,30 @@ constexpr int WG_PCS = WG_ROWS / 8;               // DMA pieces (4 rows x 256 B)
 
 // F16: dY and X rows are IEEE fp16 (HIAST_FMT_FP16) instead of bf16; the kernel never decodes a value, only the MFMA differs
 // S1 (3x3 only): stride 1 and Wo >= 20 — the tap shift is a constant number of pixels and rides in the buffer descriptor
-template <int TAPS, bool F16 = false, bool S1 = false>
-__global__ __launch_bounds__(512) void wgrad_tn_kernel(const unsigned short* __restrict__ dY,
-                                                       const unsigned short* __restrict__ X, float* __restrict__ P,
-                                                       int M, int N, int K, WGeo geo, int m_per_split)
+// XCD-aware block order: the dispatcher deals consecutive workgroup ids round-robin over the 8 XCDs (private L2
+// each).  The logical order is pixel range OUTER / (n tile, k tile, tap) INNER, and XCD k takes the k-th contiguous
+// share of it: the blocks that re-read one pixel range's dY and X rows (all taps, all tiles) sit on ONE XCD at the
+// same time, so those rows leave HBM once instead of once per XCD they were dealt to.
+__device__ __forceinline__ int wg_logical_block(int lid, int total)
 {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[WG_NST * WG_STAGE];
+    const int base = total >> 3, rem = total & 7;
+    const int xcd = lid & 7, slot = lid >> 3;
+    return xcd * base + (xcd < rem ? xcd : rem) + slot;
+}
+
+// One block = one (256 n) x (256 k) x tap tile `t` of dW over the pixel range of `split`: partial tile -> P[split][n][tap][k]
+template <int TAPS, bool F16, bool S1>
+__device__ __forceinline__ void wgrad_tn_body(unsigned char* smem, const unsigned short* __restrict__ dY,
+                                              const unsigned short* __restrict__ X, float* __restrict__ P, int M, int N,
+                                              int K, const WGeo& geo, int m_per_split, int t, int split)
+{
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;             // wave tile: n rows [128*wm, +128), k cols [64*wn, +64)
     const int kt_tiles = K / 256;
-    // XCD-aware block order: the dispatcher deals consecutive workgroup ids round-robin over the 8 XCDs (private L2
-    // each).  The logical order is pixel range OUTER / (n tile, k tile, tap) INNER, and XCD k takes the k-th contiguous
-    // share of it: the blocks that re-read one pixel range's dY and X rows (all taps, all tiles) sit on ONE XCD at the
-    // same time, so those rows leave HBM once instead of once per XCD they were dealt to.
-    int lid = blockIdx.x + gridDim.x * blockIdx.y;
-    {
-        const int total = gridDim.x * gridDim.y, base = total >> 3, rem = total & 7;
-        const int xcd = lid & 7, slot = lid >> 3;
-        lid = xcd * base + (xcd < rem ? xcd : rem) + slot;
-    }
-    int t = lid % (int)gridDim.x;                         // (n tile, k tile, tap)
-    const int tap = t % TAPS; t /= TAPS;
+    const int tap = t % TAPS; t /= TAPS;                  // t: (n tile, k tile, tap)
     const int k0 = (t % kt_tiles) * 256, n0 = (t / kt_tiles) * 256;
-    const int split = lid / (int)gridDim.x;
-    const int m_begin = split * m_per_split;              // a multiple of 64
+    const int m_begin = split * m_per_split;              // a multiple of 32
     const int m_end = (m_begin + m_per_split < M) ? m_begin + m_per_split : M;
     const int nk = (m_end - m_begin + WG_ROWS - 1) / WG_ROWS;
     const int oy = TAPS == 1 ? 0 : (tap / 3 - 1) * geo.dil, ox = TAPS == 1 ? 0 : (tap % 3 - 1) * geo.dil;
@@ -298,6 +297,59 @@ __global__ __launch_bounds__(512) void wgrad_tn_kernel(const unsigned short* __r
         }
 }
 
+template <int TAPS, bool F16 = false, bool S1 = false>
+__global__ __launch_bounds__(512) void wgrad_tn_kernel(const unsigned short* __restrict__ dY,
+                                                       const unsigned short* __restrict__ X, float* __restrict__ P,
+                                                       int M, int N, int K, WGeo geo, int m_per_split)
+{
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[WG_NST * WG_STAGE];
+    const int lid = wg_logical_block(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+    wgrad_tn_body<TAPS, F16, S1>(smem, dY, X, P, M, N, K, geo, m_per_split, lid % (int)gridDim.x, lid / (int)gridDim.x);
+}
+
+// ---- grouped launch: the weight gradients of SEVERAL convolutions (the three of one bottleneck) in one grid ----------
+// A weight-gradient launch fills the chip with one 256 x 256 tile per CU, whatever the layer: a layer3 1x1 has 4 tiles, so
+// 64 pixel ranges each write a 256 KiB fp32 partial tile (64 MB written and read again by the reduction, against 168 MB of
+// operands), a layer3 3x3 has 9 tiles x 28 ranges (64 MB of partials against 67 MB of operands).  The three convolutions
+// of a bottleneck TOGETHER have 17 tiles: 15 pixel ranges x 17 tiles fill the chip once with 64 MB of partials for all
+// three (was 192 MB), every block runs 137 k-steps instead of 32 ... 73, and the HBM-bound 1x1 tiles run beside the
+// L2-fed 3x3 tiles on the same XCD.  (The operands of the three products exist at different times of a backward pass;
+// the host defers the launch to the end of the block's backward: functional._WGroupFn.)
+constexpr int WG_MAXJOBS = 4;
+struct WJob {
+    const unsigned short* dY;
+    const unsigned short* X;
+    float* P;               // partials of this job: [nsplit][N][taps][K]
+    float* dw;              // result, torch layout [N][K][kh][kw]
+    int M, N, K, taps, s1, m_per_split, tile_begin, f4_begin;
+    WGeo geo;
+};
+struct WGroup {
+    WJob j[WG_MAXJOBS];
+    int njobs, tiles, nsplit;
+};
+
+template <bool F16>
+__global__ __launch_bounds__(512) void wgrad_group_kernel(const WGroup g)
+{
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[WG_NST * WG_STAGE];
+    const int lid = wg_logical_block(blockIdx.x, gridDim.x);
+    const int split = lid / g.tiles;
+    int t = lid - split * g.tiles, ji = 0;
+#pragma unroll
+    for (int q = 1; q < WG_MAXJOBS; ++q)
+        if (q < g.njobs && t >= g.j[q].tile_begin) ji = q;
+    ji = __builtin_amdgcn_readfirstlane(ji);
+    const WJob& jb = g.j[ji];
+    t -= jb.tile_begin;
+    if (jb.taps == 1)
+        wgrad_tn_body<1, F16, false>(smem, jb.dY, jb.X, jb.P, jb.M, jb.N, jb.K, jb.geo, jb.m_per_split, t, split);
+    else if (jb.s1)
+        wgrad_tn_body<9, F16, true>(smem, jb.dY, jb.X, jb.P, jb.M, jb.N, jb.K, jb.geo, jb.m_per_split, t, split);
+    else
+        wgrad_tn_body<9, F16, false>(smem, jb.dY, jb.X, jb.P, jb.M, jb.N, jb.K, jb.geo, jb.m_per_split, t, split);
+}
+
 // dW[n][k][tap] (torch [N][K][kh][kw]) = Σ_s P[s][n][tap][k], ascending s (fixed order: bitwise reproducible).
 // thread = (n, tap, 4 consecutive k): the partials are read as they lie — 16 bytes per lane, eight splits in flight
 // (the first form, one float per thread and four loads in flight, streamed the 67 MB of a layer3 1x1 at 1.8 TB/s:
@@ -330,6 +382,48 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
     float* d = dw + ((size_t)n * K + k) * taps + t;
+    if (taps == 1) {
+        *reinterpret_cast<float4*>(d) = acc;
+    } else {
+        d[0] = acc.x; d[taps] = acc.y; d[2 * taps] = acc.z; d[3 * taps] = acc.w;
+    }
+}
+
+// the same reduction for every job of a grouped launch in ONE grid (f4_begin: first float4 index of a job's [n][tap][k])
+__global__ __launch_bounds__(256) void wgrad_group_reduce_kernel(const WGroup g)
+{
+    long long idx4 = (long long)blockIdx.x * 256 + threadIdx.x;
+    int ji = 0;
+#pragma unroll
+    for (int q = 1; q < WG_MAXJOBS; ++q)
+        if (q < g.njobs && idx4 >= g.j[q].f4_begin) ji = q;
+    const WJob& jb = g.j[ji];
+    idx4 -= jb.f4_begin;
+    const int N = jb.N, K = jb.K, taps = jb.taps, nsplit = g.nsplit;
+    const size_t per = (size_t)N * taps * K;
+    if (idx4 * 4 >= (long long)per) return;
+    const long long idx = idx4 * 4;
+    const int k = (int)(idx % K);
+    const long long nt = idx / K;
+    const int t = (int)(nt % taps), n = (int)(nt / taps);
+    const float4* p = reinterpret_cast<const float4*>(jb.P + idx);
+    const size_t per4 = per / 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int s = 0;
+    for (; s + 8 <= nsplit; s += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(s + u) * per4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {           // the additions keep their order
+            acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
+        }
+    }
+    for (; s < nsplit; ++s) {
+        const float4 v = p[(size_t)s * per4];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    float* d = jb.dw + ((size_t)n * K + k) * taps + t;
     if (taps == 1) {
         *reinterpret_cast<float4*>(d) = acc;
     } else {
@@ -395,6 +489,90 @@ extern "C" int hiast_conv_wgrad_nhwc(const void* dy, const void* x, float* dw, i
     const long long total = (long long)Cout * Cin * taps / 4;           // float4 per thread (Cin % 256 == 0)
     hipLaunchKernelGGL(hiast::wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                        (const float*)workspace, dw, Cout, Cin, taps, nsplit);
+    HIAST_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- grouped launch (see wgrad_group_kernel) ---------------------------------------------------------------------------
+static int wgrad_group_plan(const hiast_wgrad_job* jobs, int njobs, hiast::WGroup& g, size_t& ws_bytes)
+{
+    if (!jobs || njobs < 1 || njobs > hiast::WG_MAXJOBS) return HIAST_E_ARG;
+    int tiles = 0;
+    long long f4 = 0, mmin = -1;
+    for (int i = 0; i < njobs; ++i) {
+        const hiast_wgrad_job& q = jobs[i];
+        if (q.B <= 0 || q.H <= 0 || q.W <= 0 || q.stride <= 0 || q.dil <= 0) return HIAST_E_ARG;
+        if (q.Cin % 256 != 0 || q.Cout % 256 != 0 || (q.taps != 1 && q.taps != 9) || (q.taps == 1 && q.stride != 1))
+            return HIAST_E_RANGE;
+        const int Ho = q.taps == 1 ? q.H : (q.H - 1) / q.stride + 1, Wo = q.taps == 1 ? q.W : (q.W - 1) / q.stride + 1;
+        const long long M = (long long)q.B * Ho * Wo;
+        if ((size_t)M * q.Cout * 2 >= (1ull << 31) || (size_t)q.B * q.H * q.W * q.Cin * 2 >= (1ull << 31) || M >= (1ll << 24))
+            return HIAST_E_RANGE;
+        if (q.taps == 9 && (Wo < 4 || (long long)q.B * q.H * q.W + 64 >= (1ll << 23))) return HIAST_E_RANGE;
+        hiast::WJob& j = g.j[i];
+        j.dY = (const unsigned short*)q.dy;
+        j.X = (const unsigned short*)q.x;
+        j.dw = q.dw;
+        j.M = (int)M; j.N = q.Cout; j.K = q.Cin; j.taps = q.taps;
+        j.s1 = (q.taps == 9 && q.stride == 1 && Wo >= 20) ? 1 : 0;
+        j.geo = {q.H, q.W, Ho, Wo, q.stride, q.dil};
+        j.tile_begin = tiles;
+        j.f4_begin = (int)f4;
+        tiles += (q.Cout / 256) * (q.Cin / 256) * q.taps;
+        f4 += (long long)q.Cout * q.Cin * q.taps / 4;
+        if (f4 >= (1ll << 31)) return HIAST_E_RANGE;
+        mmin = (mmin < 0 || M < mmin) ? M : mmin;
+    }
+    // ONE round of <= 256 blocks (see wgrad_nsplit), at least 16 k-steps per block
+    long long ns = 256 / tiles;
+    const long long smax = mmin / 512 > 0 ? mmin / 512 : 1;
+    ns = ns < 1 ? 1 : (ns > smax ? smax : ns);
+    ns = ns > 64 ? 64 : ns;
+    g.njobs = njobs; g.tiles = tiles; g.nsplit = (int)ns;
+    size_t off = 0;
+    for (int i = 0; i < njobs; ++i) {
+        hiast::WJob& j = g.j[i];
+        int mps = (int)((j.M + ns - 1) / ns);
+        j.m_per_split = ((mps + hiast::WG_ROWS - 1) / hiast::WG_ROWS) * hiast::WG_ROWS;
+        j.P = (float*)off;                               // offset for now; the launch adds the workspace base
+        off += (size_t)ns * j.N * j.taps * j.K * sizeof(float);
+    }
+    ws_bytes = off;
+    return 0;
+}
+
+extern "C" size_t hiast_conv_wgrad_group_workspace_bytes(const hiast_wgrad_job* jobs, int njobs)
+{
+    hiast::WGroup g;
+    size_t n = 0;
+    return wgrad_group_plan(jobs, njobs, g, n) == 0 ? n : 0;
+}
+
+extern "C" int hiast_conv_wgrad_group_nhwc(const hiast_wgrad_job* jobs, int njobs, int fmt, void* workspace,
+                                           size_t workspace_bytes, hiast_stream_t stream)
+{
+    if (fmt != HIAST_FMT_BF16 && fmt != HIAST_FMT_FP16) return HIAST_E_RANGE;
+    if (!workspace) return HIAST_E_ARG;
+    hiast::WGroup g;
+    size_t need = 0;
+    const int e = wgrad_group_plan(jobs, njobs, g, need);
+    if (e) return e;
+    if (workspace_bytes < need) return HIAST_E_WS;
+    uintptr_t al = (uintptr_t)workspace;
+    for (int i = 0; i < njobs; ++i) {
+        if (!jobs[i].dy || !jobs[i].x || !jobs[i].dw) return HIAST_E_ARG;
+        al |= (uintptr_t)jobs[i].dy | (uintptr_t)jobs[i].x | (uintptr_t)jobs[i].dw;
+        g.j[i].P = (float*)((unsigned char*)workspace + (size_t)g.j[i].P);
+    }
+    if (al & 15) return HIAST_E_RANGE;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned blocks = (unsigned)(g.tiles * g.nsplit);
+    if (fmt == HIAST_FMT_FP16) hipLaunchKernelGGL(hiast::wgrad_group_kernel<true>, dim3(blocks), dim3(512), 0, st, g);
+    else hipLaunchKernelGGL(hiast::wgrad_group_kernel<false>, dim3(blocks), dim3(512), 0, st, g);
+    HIAST_CHECK_LAUNCH();
+    const hiast::WJob& last = g.j[njobs - 1];
+    const long long total4 = (long long)last.f4_begin + (long long)last.N * last.K * last.taps / 4;
+    hipLaunchKernelGGL(hiast::wgrad_group_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, g);
     HIAST_CHECK_LAUNCH();
     return 0;
 }

@@ -180,6 +180,11 @@ def _sync_world(bn):
     return 1
 
 
+# read ONCE at import: the ranks of a job must issue the collectives of the statistics group at matching points, a switch
+# that is looked up per call could differ between them (or change between a forward and its backward)
+_NO_ASYNC_STAT = os.environ.get("HIAST_NO_ASYNC_STAT", "0") == "1"
+
+
 def _stat_all_reduce(t, async_op=False):
     """SyncBN exchange: sum of the per-rank statistics, on the communicator reserved for it (utils/comm.py: these
     [C,2] reduces sit between two kernels of the main stream and must not queue behind DDP's 32 MB gradient buckets or
@@ -270,6 +275,13 @@ class _BnActNhwcFn(torch.autograd.Function):
         # statistics hand-off (see _ConvNhwcFn): the data-gradient launch of the ONE convolution that consumes y can emit
         # this layer's backward sums (Σg, Σ g*xhat) from its epilogue; it needs x and the batch statistics for that
         ctx.stat_box = None
+        if stat_box is not None:
+            # leftovers of a previous iteration whose backward through THIS layer was pruned (its input needed no gradient)
+            # while the consuming convolution's backward had already started the exchange: finish it, drop the sums
+            left = stat_box.pop("bwd_sums", None)
+            if left is not None:
+                left[1].wait()
+            stat_box.pop("bwd_partial", None)
         if stat_box is not None and ctx.gate == 2:
             stat_box["bn"] = (x.detach(), sm, si, gamma, beta)
             stat_box["world"] = world
@@ -313,8 +325,9 @@ class _ConvNhwcFn(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
-    def forward(ctx, x, weight, stride, dil, want_stats, box, packed, in_bn=None):
+    def forward(ctx, x, weight, stride, dil, want_stats, box, packed, in_bn=None, wgroup=None):
         xv = x.permute(0, 2, 3, 1)
+        ctx.wgroup = wgroup                   # (group dict, slot): the weight gradient is deferred to _WGroupFn.backward
         # in_bn: x = relu(bn(x0)) of a BatchNorm that registered itself there (and has no other consumer): the data
         # gradient of this convolution then also delivers that BatchNorm's backward sums (hiast_igemm_dgrad_bn_stats)
         ctx.in_bn = in_bn if (in_bn is not None and "bn" in in_bn and stride == 1 and ctx.needs_input_grad[0]
@@ -344,7 +357,7 @@ class _ConvNhwcFn(torch.autograd.Function):
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dy, _dpartial=None):
         if dy is None:
-            return None, None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None, None
         x, weight = ctx.saved_tensors
         stride, dil = ctx.geo
         if dy.dtype != x.dtype:
@@ -362,7 +375,7 @@ class _ConvNhwcFn(torch.autograd.Function):
                 bx, sm, si, gamma, beta = ctx.in_bn["bn"]
                 dxv, bpartial = K.igemm_dgrad_bn_stats(dy.permute(0, 2, 3, 1), wpt, dil, bx.permute(0, 2, 3, 1), gamma, beta,
                                                        sm, si)
-                if ctx.in_bn.get("world", 1) > 1 and os.environ.get("HIAST_NO_ASYNC_STAT", "0") != "1":
+                if ctx.in_bn.get("world", 1) > 1 and not _NO_ASYNC_STAT:
                     # SyncBN: reduce the per-block sums now and start their all-reduce; the weight gradient below (50 - 300 us,
                     # on the main stream under DDP) runs while the [C,2] exchange (a latency, ~30 us on 8 devices) is in
                     # flight — the BatchNorm's backward then finds the reduced sums instead of waiting for the exchange
@@ -385,6 +398,13 @@ class _ConvNhwcFn(torch.autograd.Function):
         # and MFMA-bound, while the BatchNorm backward passes that follow on the main stream are HBM-bound: in a
         # single-process run it goes to a side stream and co-runs with them (wgrad_stream_join() before the optimiser
         # step).  Under DDP the reducer reads gradients as soon as autograd delivers them, so it stays on the main stream.
+        if need_w and own_w and ctx.wgroup is not None:
+            # grouped weight gradient (hiast_conv_wgrad_group_nhwc): hand the operands to the bottleneck's _WGroupFn node,
+            # whose backward runs when the last of the block's convolutions has delivered its pair, and return a
+            # zero-stride placeholder of the weight's shape (no memory, no kernel) for autograd to pass on to it
+            grp, slot = ctx.wgroup
+            grp["jobs"][slot] = (dy.permute(0, 2, 3, 1), x.permute(0, 2, 3, 1), k, stride, dil)
+            return dx, _wgrad_token(weight), None, None, None, None, None, None, None
         side = wgrad_side_stream(x.device) if (need_w and not lib_x) else None
         main = torch.cuda.current_stream()
         if side is not None:
@@ -414,7 +434,95 @@ class _ConvNhwcFn(torch.autograd.Function):
                                                                 # (DDP compares strides with its bucket view literally)
         if side is not None and dw is not None:
             dw.record_stream(main)
-        return dx, dw, None, None, None, None, None, None
+        return dx, dw, None, None, None, None, None, None, None
+
+
+_wgrad_tokens = {}
+
+
+def _wgrad_token(weight):
+    """a zero-stride tensor of the weight's shape / dtype / device: what a grouped convolution's backward returns in place of
+    its weight gradient (autograd checks the metadata and hands it to _WGroupFn.backward, which ignores the values)"""
+    key = (weight.device, weight.dtype)
+    z = _wgrad_tokens.get(key)
+    if z is None:
+        z = _wgrad_tokens[key] = torch.zeros((), dtype=weight.dtype, device=weight.device)
+    return z.expand(weight.shape)
+
+
+class _WGroupFn(torch.autograd.Function):
+    """The weights of ONE bottleneck pass through this node on their way to its convolutions (identity forward).  Its
+    backward runs once all of them have run theirs — the operands (dY, X) of the three products are then all there — and
+    computes the weight gradients in one grouped launch (K.conv_wgrad_group: the chip is filled once, with one fp32
+    partial tile per CU, for all three instead of once per convolution; reference: autograd of the three nn.Conv2d of
+    Bottleneck.forward, sseg/models/modules/resnet.py:78-98).  The gradients reach the parameters (and DDP's reducer
+    hooks) complete, from this node."""
+
+    @staticmethod
+    def forward(ctx, grp, *ws):
+        ctx.grp = grp
+        ctx.set_materialize_grads(False)
+        return tuple(w.view_as(w) for w in ws)
+
+    @staticmethod
+    def backward(ctx, *tokens):
+        grp = ctx.grp
+        jobs = grp["jobs"]
+        live = [i for i, j in enumerate(jobs) if j is not None and tokens[i] is not None]
+        # a convolution that did not take the grouped path after all (a shape its backward sends elsewhere) has returned
+        # its real weight gradient: passed through
+        out = [tokens[i] if jobs[i] is None else None for i in range(len(jobs))]
+        if live:
+            dev = jobs[live[0]][1].device
+            side = wgrad_side_stream(dev)
+            main = torch.cuda.current_stream()
+            if side is not None:
+                side.wait_stream(main)
+                for i in live:
+                    jobs[i][0].record_stream(side)
+                    jobs[i][1].record_stream(side)
+            with torch.cuda.stream(side if side is not None else main):
+                dws = K.conv_wgrad_group([jobs[i] for i in live]) if len(live) > 1 else [K.conv_wgrad_nhwc(*jobs[live[0]])]
+            for i, dw in zip(live, dws):
+                if side is not None:
+                    dw.record_stream(main)
+                out[i] = dw
+        for i in range(len(jobs)):
+            jobs[i] = None                                  # drop the operand references
+        return (None, *out)
+
+
+def wgroup_weights(convs, x):
+    """-> (group dict, [weight views]) when the weight gradients of `convs` (the convolutions of one bottleneck) can be
+    computed by one grouped launch on the training path of x, else (None, None)"""
+    if (len(convs) < 2 or len(convs) > 4 or os.environ.get("HIAST_NO_WGROUP", "0") == "1"
+            or os.environ.get("HIAST_LIB_WGRAD", "0") == "1" or not torch.is_grad_enabled()):
+        return None, None
+    for c in convs:
+        k = c.kernel_size[0]
+        if (not c.weight.requires_grad or not conv_nhwc_ok(x, c) or c.stride[0] != 1
+                or not K.conv_wgrad_preferred(c.in_channels, c.out_channels, k, 1)):
+            return None, None
+    # A grouped launch is ONE round of (tiles x pixel ranges) <= 256 blocks: worth it when that fills the chip.  layer3:
+    # 4 + 9 + 4 tiles x 15 ranges = 255 blocks (190 us against 239 us one by one); layer4: 16 + 36 + 16 tiles x 3 ranges
+    # = 204 blocks leave a fifth of the CUs idle (698 against 622 us) — there only the 1x1 pair is grouped (32 tiles x 8
+    # ranges: 265 against 300 us) and the 3x3 keeps its own launch (36 tiles x 7 ranges).
+    tiles = [(c.in_channels // 256) * (c.out_channels // 256) * c.kernel_size[0] ** 2 for c in convs]
+    fill = lambda idx: sum(tiles[i] for i in idx) * (256 // sum(tiles[i] for i in idx)) / 256.0 if sum(
+        tiles[i] for i in idx) <= 256 else 0.0
+    member = list(range(len(convs)))
+    if fill(member) < 0.9:
+        member = [i for i in member if convs[i].kernel_size[0] == 1]
+        if len(member) < 2 or fill(member) < 0.9:
+            return None, None
+    grp = {"jobs": [None] * len(member)}
+    views = _WGroupFn.apply(grp, *[convs[i].weight for i in member])
+    wv = [None] * len(convs)
+    slot = [None] * len(convs)
+    for s_, i in enumerate(member):
+        wv[i], slot[i] = views[s_], s_
+    grp["slot"] = slot
+    return grp, wv
 
 
 _wgrad_streams = {}
@@ -648,10 +756,11 @@ class _SubsampleClFn(torch.autograd.Function):
         return g, None
 
 
-def conv_nhwc(x, conv, want_stats=False, box=None, in_bn=None):
+def conv_nhwc(x, conv, want_stats=False, box=None, in_bn=None, wgroup=None):
     """-> y, or (y, partial) with want_stats (see igemm_bn_act); box: identity-branch hand-off of a bottleneck;
     in_bn: statistics hand-off of the BatchNorm whose output x is (bn_act(..., stat_box=in_bn))"""
     w = conv.weight
+    wv = w if wgroup is None else wgroup[2]      # wgroup = (group dict, slot, this weight as it comes out of _WGroupFn)
     fmt = K.fmt_of(x)
     fwd = conv.__dict__.get("_hiast_packed", {}).get(fmt)
     adj = conv.__dict__.get("_hiast_packed_adj", {}).get(fmt)
@@ -664,7 +773,8 @@ def conv_nhwc(x, conv, want_stats=False, box=None, in_bn=None):
         # DDP copy the bucket view); autograd scatters the data gradient back into the skipped pixels
         x = _SubsampleClFn.apply(x, stride)
         stride = 1
-    return _ConvNhwcFn.apply(x, w, stride, conv.dilation[0], bool(want_stats), box, packed, in_bn)
+    return _ConvNhwcFn.apply(x, wv, stride, conv.dilation[0], bool(want_stats), box, packed, in_bn,
+                             None if wgroup is None else (wgroup[0], wgroup[1]))
 
 
 _nbt_batched = [False]      # set by ResNet.forward while it has already advanced every num_batches_tracked at once

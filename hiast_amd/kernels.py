@@ -89,8 +89,12 @@ def plabel_pass1(logits_lr, H, W, hist=None):
         lib = _lib.load()
         # scattered counting copy of the histogram (hot counters on different memory lines): one per device and stream,
         # zeroed by the call; a second launch adds it into hist
-        key = (dev, torch.cuda.current_stream(dev).cuda_stream, C)
+        # (keyed by the device INDEX — torch.device("cuda") and ("cuda", 0) are different keys — and the stream handle; the
+        # table holds at most a few streams per device, so a recycled handle at worst reuses a buffer of the right size)
+        key = (logits_lr.get_device(), torch.cuda.current_stream(dev).cuda_stream, C)
         ws = _pass1_ws.get(key)
+        if len(_pass1_ws) > 16 and ws is None:
+            _pass1_ws.clear()
         if ws is None:
             ws = torch.empty(lib.hiast_plabel_pass1_workspace_bytes(C) // 4, dtype=torch.int32, device=dev)
             _pass1_ws[key] = ws
@@ -1170,9 +1174,12 @@ def conv_wgrad_small_nhwc(dy, x, k, stride, dil):
     n = lib.hiast_conv_wgrad_small_workspace_bytes(B, Ho, Wo, Cin, Cout, taps)
     if n == 0:
         raise _lib.HiastLibraryError("hiast_conv_wgrad_small_nhwc: unsupported shape Cin=%d Cout=%d taps=%d" % (Cin, Cout, taps))
-    key = ("small", x.device)
+    # one growing scratch buffer per (device, stream): launches of ONE stream reuse it in stream order; the weight gradients
+    # of a backward pass run on two streams (main for the layers whose data gradient is the library's, the side stream for
+    # the rest) and two launches that shared the partials would overwrite each other's
+    key = ("small", x.device, torch.cuda.current_stream(x.device).cuda_stream)
     ws = _wgrad_ws.get(key)
-    if ws is None or ws.numel() * 4 < n:         # one growing scratch buffer per device (stream-ordered reuse)
+    if ws is None or ws.numel() * 4 < n:
         ws = torch.empty((n + 3) // 4, dtype=torch.float32, device=x.device)
         _wgrad_ws[key] = ws
     dw = torch.empty((Cout, Cin, k, k), dtype=torch.float32, device=x.device)
@@ -1193,12 +1200,49 @@ def conv_wgrad_nhwc(dy, x, k, stride, dil):
     n = lib.hiast_conv_wgrad_workspace_bytes(B, Ho, Wo, Cin, Cout, taps)
     if n == 0:
         raise _lib.HiastLibraryError("hiast_conv_wgrad_nhwc: unsupported shape Cin=%d Cout=%d taps=%d" % (Cin, Cout, taps))
-    key = x.device
+    key = ("big", x.device, torch.cuda.current_stream(x.device).cuda_stream)     # per stream: see conv_wgrad_small_nhwc
     ws = _wgrad_ws.get(key)
-    if ws is None or ws.numel() * 4 < n:         # one growing scratch buffer per device (stream-ordered reuse)
+    if ws is None or ws.numel() * 4 < n:
         ws = torch.empty((n + 3) // 4, dtype=torch.float32, device=x.device)
         _wgrad_ws[key] = ws
     dw = torch.empty((Cout, Cin, k, k), dtype=torch.float32, device=x.device)
     check(lib.hiast_conv_wgrad_nhwc(_ptr(dy), _ptr(x), _ptr(dw), B, H, W, Cin, Cout, taps, int(stride), int(dil), fmt_of(dy),
                                     _ptr(ws), ws.numel() * 4, _stream()), "hiast_conv_wgrad_nhwc")
     return dw
+
+
+def conv_wgrad_group(jobs):
+    """the weight gradients of up to 4 convolutions in ONE launch + ONE reduction (hiast_conv_wgrad_group_nhwc): jobs =
+    [(dy [B,Ho,Wo,Cout], x [B,H,W,Cin], k, stride, dil), ...], 16-bit channels-last rows of one type, every shape one that
+    conv_wgrad_supported() takes -> [dW fp32 [Cout,Cin,k,k], ...].  The jobs share the pixel-range split: the chip is
+    filled once for all of them (one fp32 partial tile per CU) instead of once per convolution."""
+    import ctypes
+    lib = _lib.load()
+    n = len(jobs)
+    arr = (_lib.WgradJob * n)()
+    outs = []
+    fmt = None
+    for i, (dy, x, k, stride, dil) in enumerate(jobs):
+        _req16(dy, 4, "dy")
+        _req(x, dy.dtype, 4, "x")
+        B, H, W, Cin = x.shape
+        Bo, Ho, Wo, Cout = dy.shape
+        assert Bo == B and (Ho, Wo) == ((H, W) if k == 1 else ((H - 1) // stride + 1, (W - 1) // stride + 1))
+        assert fmt is None or fmt == fmt_of(dy), "one operand type per grouped launch"
+        fmt = fmt_of(dy)
+        dw = torch.empty((Cout, Cin, k, k), dtype=torch.float32, device=x.device)
+        outs.append(dw)
+        arr[i] = _lib.WgradJob(_ptr(dy), _ptr(x), _ptr(dw), B, H, W, Cin, Cout, k * k, int(stride), int(dil))
+    need = lib.hiast_conv_wgrad_group_workspace_bytes(ctypes.addressof(arr), n)
+    if need == 0:
+        raise _lib.HiastLibraryError("hiast_conv_wgrad_group_nhwc: unsupported shapes %s" %
+                                     [(tuple(j[0].shape), tuple(j[1].shape), j[2]) for j in jobs])
+    dev = jobs[0][1].device
+    key = ("group", dev, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _wgrad_ws.get(key)
+    if ws is None or ws.numel() * 4 < need:
+        ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
+        _wgrad_ws[key] = ws
+    check(lib.hiast_conv_wgrad_group_nhwc(ctypes.addressof(arr), n, fmt, _ptr(ws), ws.numel() * 4, _stream()),
+          "hiast_conv_wgrad_group_nhwc")
+    return outs

@@ -33,12 +33,12 @@ def conv(m, x):
     return m(x)
 
 
-def conv_bn_act(cv, bn, x, res=None, relu=True, conv_box=None, bn_box=None, in_bn=None, stat_box=None):
+def conv_bn_act(cv, bn, x, res=None, relu=True, conv_box=None, bn_box=None, in_bn=None, stat_box=None, wgroup=None):
     """relu?(bn(conv(x)) [+ res]).  On the channels-last bf16 training path the convolution's epilogue also
     delivers the per-block sums the BatchNorm needs (one pass over the activation less); stat_box / in_bn: the same for
     the BACKWARD sums — this BatchNorm registers itself in stat_box, the next conv_bn_act gets that dict as in_bn."""
     if x.is_cuda and x.dtype in HF.H16 and bn.training and HF.conv_nhwc_ok(x, cv):
-        y, partial = HF.conv_nhwc(x, cv, want_stats=True, box=conv_box, in_bn=in_bn)
+        y, partial = HF.conv_nhwc(x, cv, want_stats=True, box=conv_box, in_bn=in_bn, wgroup=wgroup)
         return HF.bn_act(y, bn, res, relu, partial=partial, box=bn_box, stat_box=stat_box)
     return bn_act(bn, conv(cv, x), res, relu)
 
@@ -89,9 +89,15 @@ class Bottleneck(nn.Module):
         # `box` is the hand-off between the two autograd nodes of this call
         box = {} if (self.downsample is None and os.environ.get("HIAST_NO_IDT_HANDOFF", "0") != "1") else None
         sb1, sb2 = {}, {}       # bn1 -> conv2's data gradient, bn2 -> conv3's: backward statistics from the dgrad epilogue
-        o = conv_bn_act(self.conv1, self.bn1, x, conv_box=box, stat_box=sb1)
-        o = conv_bn_act(self.conv2, self.bn2, o, in_bn=sb1, stat_box=sb2)
-        return conv_bn_act(self.conv3, self.bn3, o, res=idt, bn_box=box, in_bn=sb2)        # += identity, ReLU
+        # layer3 / layer4 on the 16-bit training path: the three weight gradients of the block are ONE grouped launch at the
+        # end of its backward (HF._WGroupFn) instead of three launches that each fill the chip with partial tiles
+        grp, wv = (None, None)
+        if x.is_cuda and x.dtype in HF.H16 and self.bn1.training:
+            grp, wv = HF.wgroup_weights((self.conv1, self.conv2, self.conv3), x)
+        g = (lambda i: (grp, grp["slot"][i], wv[i]) if wv[i] is not None else None) if grp is not None else (lambda i: None)
+        o = conv_bn_act(self.conv1, self.bn1, x, conv_box=box, stat_box=sb1, wgroup=g(0))
+        o = conv_bn_act(self.conv2, self.bn2, o, in_bn=sb1, stat_box=sb2, wgroup=g(1))
+        return conv_bn_act(self.conv3, self.bn3, o, res=idt, bn_box=box, in_bn=sb2, wgroup=g(2))        # += identity, ReLU
 
     def forward_eval_planes(self, x, fmt):
         """inference on channels-last 16-bit activations [B,H,W,planes*C] in operand format `fmt` (K.FMT_SPLIT_BF16: split

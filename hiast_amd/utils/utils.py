@@ -173,6 +173,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._plan = None
         self._ctl = None        # device control block (element 0: number of steps SKIPPED on an overflow so far)
         self._attempts = {}     # id(param) -> steps attempted since the counts were last folded into state['step']
+        self._part = None       # ids of the parameters that took part in the previous step
 
     def _skipped(self):
         return 0 if self._ctl is None else int(self._ctl[0].item())       # (synchronises)
@@ -229,6 +230,13 @@ class FusedAdam(torch.optim.Optimizer):
         dev = next((p.device for items in by_hyper.values() for p, _, _ in items), None)
         if dev is None:
             return loss
+        # The device counts skipped (overflow) steps ONCE for all tensors, so between two folds every counted tensor must
+        # have taken part in every step: when the set of participating parameters changes (a tensor sits out a step, or
+        # comes back), the counts are folded first (one synchronisation, only on such a change).
+        part = frozenset(id(p) for items in by_hyper.values() for p, _, _ in items)
+        if self._part is not None and part != self._part and self._attempts:
+            self._fold_steps()
+        self._part = part
         if self._ctl is None:
             self._ctl = torch.zeros(8, dtype=torch.float32, device=dev)
         K.adam_prepare(self._ctl, grad_scale, found_inf)      # ONE decision per step, shared by every launch below

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HIAST_ABI_VERSION 3
+#define HIAST_ABI_VERSION 4
 
 #define HIAST_E_ARG   (-1) /* null pointer / non-positive extent */
 #define HIAST_E_RANGE (-2) /* extent outside what the kernels are built for */
@@ -331,6 +331,17 @@ size_t hiast_conv_wgrad_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout
 int hiast_conv_wgrad_nhwc(const void* dy, const void* x, float* dw, int B, int H, int W, int Cin, int Cout, int taps,
                           int stride, int dil, int fmt /* HIAST_FMT_BF16 | HIAST_FMT_FP16: type of dy and x */,
                           void* workspace, size_t workspace_bytes, hiast_stream_t stream);
+
+/* Grouped form (round 4): the weight gradients of up to 4 convolutions — the three of one bottleneck, whose backward
+ * (resnet.py:78-98 under autograd) produces their operands one after the other — in ONE launch + ONE reduction.  Each job
+ * is a hiast_conv_wgrad_nhwc problem (same shape limits); the jobs share the pixel-range split, so the chip is filled
+ * once (one 256 x 256 fp32 partial tile per CU) for all of them instead of once per convolution: a layer3 bottleneck
+ * writes 64 MB of partials instead of 192 MB and needs 2 launches instead of 6.  `jobs` is a HOST array (read during the
+ * call); results are bitwise reproducible (fixed-order reduction) but differ from the one-by-one form in summation order. */
+typedef struct { const void* dy; const void* x; float* dw; int32_t B, H, W, Cin, Cout, taps, stride, dil; } hiast_wgrad_job;
+size_t hiast_conv_wgrad_group_workspace_bytes(const hiast_wgrad_job* jobs, int njobs);
+int hiast_conv_wgrad_group_nhwc(const hiast_wgrad_job* jobs, int njobs, int fmt, void* workspace, size_t workspace_bytes,
+                                hiast_stream_t stream);
 
 /* ---- K9h: the same weight gradient for the layers BELOW 256 channels (layer1 / layer2: Cin, Cout in {64, 128, 256, ...,
  * multiples of 128}; 1x1 (stride 1) and 3x3 (any stride, 'same' padding = dil)) — autograd of nn.Conv2d in

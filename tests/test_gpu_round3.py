@@ -244,3 +244,4 @@ def test_stem_eval_in_the_eval_forward_matches_the_module_path(K, monkeypatch):
         # the fused stem skips one fp16 rounding (the convolution output): at least as close to the fp32 forward
         ea, eb = float((a16 - c).abs().max()), float((b16 - c).abs().max())
         assert ea <= 1.5 * eb + 1e-3 * s, (ea / s, eb / s)
+

@@ -24,3 +24,19 @@ for name, ci, co, k, dl in (("l3.c1", 1024, 256, 1, 1), ("l3.c2", 256, 256, 3, 2
     gf = 2.0 * B * H * W * ci * co * k * k / 1e9
     row += " | %s %6.1f us %4.0f TF" % (name, t * 1e3, gf / t)
 print(row, flush=True)
+
+# round 4: the three weight gradients of one bottleneck one by one (6 launches) against the grouped launch (2 launches)
+for name, cin, mid, dl in (("layer3 block", 1024, 256, 2), ("layer4 block", 2048, 512, 4)):
+    x1 = torch.randn(B, H, W, cin, device=dev).to(dt)
+    d1 = torch.randn(B, H, W, mid, device=dev).to(dt)
+    x2 = torch.randn(B, H, W, mid, device=dev).to(dt)
+    d2 = torch.randn(B, H, W, mid, device=dev).to(dt)
+    x3 = torch.randn(B, H, W, mid, device=dev).to(dt)
+    d3 = torch.randn(B, H, W, cin, device=dev).to(dt)
+    jobs = [(d3, x3, 1, 1, 1), (d2, x2, 3, 1, dl), (d1, x1, 1, 1, 1)]
+    t_one = timeit(lambda: [K.conv_wgrad_nhwc(*j) for j in jobs], n=30)
+    t_grp = timeit(lambda: K.conv_wgrad_group(jobs), n=30)
+    t_13 = timeit(lambda: K.conv_wgrad_group([jobs[0], jobs[2]]), n=30)
+    gf = 2.0 * B * H * W * (2 * cin * mid + 9 * mid * mid) / 1e9
+    print("%s: one by one %.1f us (%.0f TF) | grouped %.1f us (%.0f TF) | grouped 1x1 pair only %.1f us" %
+          (name, t_one * 1e3, gf / t_one, t_grp * 1e3, gf / t_grp, t_13 * 1e3), flush=True)
