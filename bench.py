@@ -9,7 +9,8 @@ resident in HBM before the timed region:
      histogram kernel -> (N>1: RCCL all-reduce of the 19x15361 histogram) -> IAS thresholds -> select kernel
      -> (N>1: all-reduce of the class sums);
   B. self-training step (BASELINE configs[2], HIAST setting): EMA-teacher forward (no grad) + student
-     forward/backward under bf16 autocast (the reference trains under apex O1), fused 4-term
+     forward/backward under fp16 autocast with dynamic loss scaling (the reference trains under apex O1;
+     --amp-dtype bf16: plain bf16, no scaling), fused 4-term
      region-adaptive loss on the labels of A, Adam step (N>1: DDP/RCCL gradient all-reduce overlapped with
      backward, SyncBN), EMA update.
 value = N * B * K / max-over-ranks(time of K steps)  [images/s].
@@ -42,6 +43,10 @@ def parse():
     p.add_argument("--steps", type=int, default=12)
     p.add_argument("--warmup", type=int, default=4)
     p.add_argument("--batch", type=int, default=8, help="images per GPU per step")
+    p.add_argument("--global-batch", type=int, default=0,
+                   help="reference semantics of cfg4 (code/train.py:52-53: the configured batch size is the GLOBAL one, every "
+                        "rank takes batch/N images and SyncBN pools the statistics): images per step over ALL ranks; "
+                        "overrides --batch with global/N and reports scaling 'strong'.  0 = weak scaling (--batch per GPU)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-size", type=int, nargs=2, default=[H, W],
                    help="H W of the CPU-baseline sample images (BASELINE.md §3: the full 512x1024, ~20 s of CPU work on 16 "
@@ -610,6 +615,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+    if args.global_batch:
+        assert args.global_batch % world == 0, "--global-batch %d does not divide over %d ranks" % (args.global_batch, world)
+        args.batch = args.global_batch // world
     import __graft_entry__ as ge
     if rank == 0 and not os.path.exists(os.path.join(ROOT, "hiast_amd", "csrc", "libhiast_hip.so")):
         ge.build()
@@ -738,7 +746,7 @@ def main():
             "metric": "self-training images/sec (fwd+bwd+pseudo-label) at 1024x512",
             "value": imgs / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.amp_dtype,
+            "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": args.amp_dtype,
             "dtype_detail": "16-bit MFMA with fp32 accumulate everywhere: %s in the training step, split-bf16 planes "
                             "(hi*hi+lo*hi+hi*lo, fp32-class) in the pseudo-label forward incl. its ASPP head; losses / "
                             "softmax / thresholds fp32 + integer"
@@ -752,6 +760,8 @@ def main():
             "config": {"workload": "configs[2] self-training round (%s, region-adaptive reg on) bs=%d/GPU @1024x512 "
                                    "+ configs[1] IAS pseudo-label pass on the same batch" % (args.trainer, args.batch),
                        "images_per_gpu_per_step": args.batch, "num_classes": C,
+                       "batch_semantics": ("reference_bs%d: global batch split over the ranks + SyncBN (code/train.py:52-53)"
+                                           % args.global_batch if args.global_batch else "per-GPU batch (weak scaling)"),
                        "parallelism": "dp%d" % world if world > 1 else "single"},
             "phases_ms": {"pseudo_label": 1e3 * t_pl / args.steps, "train_step": 1e3 * t_tr / args.steps,
                           "note": "of the first timed step, which runs every part in order on one stream (per-launch "

@@ -17,12 +17,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run_bench(extra, timeout=900):
+def _run_bench(extra, timeout=900, gpus=2, env_extra=None):
     env = dict(os.environ)
+    env.update(env_extra or {})
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1",
            "--no-cpu-baseline"] + extra
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
     assert p.returncode == 0, "bench.py rc %d\n--- stdout\n%s\n--- stderr (tail)\n%s" % (p.returncode, p.stdout[-2000:],
@@ -32,11 +33,11 @@ def _run_bench(extra, timeout=900):
     return json.loads(lines[0]), p.stderr
 
 
-def _check(out, batch):
-    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2"
-    assert out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+def _check(out, batch, gpus=2, scaling="weak"):
+    assert out["n_gpus"] == gpus and out["config"]["parallelism"] == "dp%d" % gpus
+    assert out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == scaling
     assert out["config"]["images_per_gpu_per_step"] == batch
-    assert out["value"] > 0 and abs(out["value"] - 2 * batch * 2 / (out["ms_per_step"] * 2e-3)) <= 1e-6 * out["value"]
+    assert out["value"] > 0 and abs(out["value"] - gpus * batch * 2 / (out["ms_per_step"] * 2e-3)) <= 1e-6 * out["value"]
     fin = out["final_losses"]
     assert set(fin) == {"target_seg_loss", "kld_confident_loss", "ent_ignored_loss", "cst_loss"}
     assert all(v == v and abs(v) < 1e4 for v in fin.values()), fin         # finite on every rank (all-reduced mean)
@@ -55,4 +56,18 @@ def test_bench_two_ranks_through_spawn_ranks_rccl():
         pytest.skip("RCCL needs one device per rank; %d visible" % torch.cuda.device_count())
     out, err = _run_bench(["--batch", "2"])
     _check(out, 2)
+    assert "grad strides do not match bucket view" not in err
+
+
+@pytest.mark.parametrize("no_async", ["0", "1"])
+def test_bench_four_ranks_reference_batch_semantics_gloo_same_device(no_async):
+    """cfg4 in the reference's own semantics (code/train.py:52-53: a GLOBAL batch, here 4 = ONE image per rank, SyncBN
+    pools the statistics — every BatchNorm sum is a one-image sum and the 208 chained [C,2] exchanges dominate the step),
+    four ranks on cuda:0 over gloo through the driver's command shape, with the SyncBN backward exchange started ahead of the
+    weight gradient (default) and inside the BatchNorm's backward (HIAST_NO_ASYNC_STAT=1).  Four ranks, not eight: a GPU box
+    allows six processes on its card, and this pytest process holds it too."""
+    out, err = _run_bench(["--same-device", "--backend", "gloo", "--global-batch", "4"], gpus=4,
+                          env_extra={"HIAST_NO_ASYNC_STAT": no_async}, timeout=1200)
+    _check(out, 1, gpus=4, scaling="strong")
+    assert out["config"]["batch_semantics"].startswith("reference_bs4")
     assert "grad strides do not match bucket view" not in err

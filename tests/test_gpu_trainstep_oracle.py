@@ -254,3 +254,110 @@ def test_training_step_vs_cpu_autograd_oracle(tmp_path_factory, monkeypatch, mod
         assert min(cos[k] for k in trunk) >= lo, min(((k, cos[k]) for k in trunk), key=lambda kv: kv[1])
         last = "seg_model.backbone.layer4.%d.conv3.weight" % (DEPTHS[depth][3] - 1)
         assert cos[last] >= (0.95 if mode == "O1_bf16" else 0.99), (last, cos[last])     # measured: 0.977-0.987 / 0.996-0.998
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Round 4: arithmetic error apart from gate flips.  The bounds above (trunk cosines >= 0.85 in fp16) are loose because a
+# gradient through ReLUs amplifies a forward rounding e to ~sqrt(e): flipped gates.  Here the gates are taken OUT of the
+# comparison: the device step exports the gates it used (every ReLU's output > 0, the stem pooling's window positions) and
+# the float64 oracle is evaluated AROUND THOSE gates (oracle/deeplab_ref.backbone(relu_masks=, pool_codes=): ReLU -> multiply
+# by the mask, pooling -> gather).  What is left between the two is arithmetic only — 16-bit storage of activations and
+# gradients, fp32 accumulation — which is linear in e: every gradient tensor has to agree tightly.  A mis-scaled epilogue, a
+# dropped tap, a wrong statistic in one layer shows up here at full size.
+def _capture_gates(monkeypatch, net):
+    """wrap the trunk's fused BN(+residual)+ReLU calls and the stem pooling: -> (relu masks by BatchNorm name, pool codes)"""
+    from hiast_amd import kernels as K
+    from hiast_amd.sseg.models.modules import resnet
+    names = {id(m): n for n, m in net.seg_model.named_modules()}
+    masks, pool = {}, {}
+    real_cba, real_ba, real_pool = resnet.conv_bn_act, resnet.bn_act, K.maxpool3x3s2_cl_fwd
+
+    def cba(cv, bn, x, res=None, relu=True, **kw):
+        y = real_cba(cv, bn, x, res=res, relu=relu, **kw)
+        if relu and torch.is_grad_enabled():
+            masks[names[id(bn)]] = (y.detach() > 0).cpu()
+        return y
+
+    def ba(bn, x, res=None, relu=True):
+        y = real_ba(bn, x, res, relu)
+        if relu and torch.is_grad_enabled():
+            masks[names[id(bn)]] = (y.detach() > 0).cpu()
+        return y
+
+    def mp(x):
+        y, idx = real_pool(x)      # (called inside an autograd.Function: the student's forward is the only caller)
+        pool["codes"] = idx.permute(0, 3, 1, 2).cpu()          # [B,Ho,Wo,C] -> [B,C,Ho,Wo]
+        return y, idx
+    monkeypatch.setattr(resnet, "conv_bn_act", cba)
+    monkeypatch.setattr(resnet, "bn_act", ba)
+    monkeypatch.setattr(K, "maxpool3x3s2_cl_fwd", mp)
+    return masks, pool
+
+
+def _oracle_step_given_gates(sd, masks, codes):
+    """_oracle_step in float64 around the given gates -> (losses, gradients)"""
+    from oracle import deeplab_ref, losses_ref
+    dtype = torch.float64
+    weak, strong, plbl = _inputs()
+    sub = {k[len("seg_model."):]: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
+    with torch.no_grad():
+        zt = deeplab_ref.deeplab_v2(torch.from_numpy(weak).to(dtype), sub, train=False)[0]
+    params = {k: v.detach().clone().requires_grad_(v.dim() == 4 or "aspp" in k) for k, v in sub.items()}
+    zs = deeplab_ref.deeplab_v2(torch.from_numpy(strong).to(dtype), params, train=True, relu_masks=masks, pool_codes=codes)[0]
+    L = losses_ref.st_losses(zs, zt, torch.from_numpy(plbl.astype(np.int64)), (H, W), "ignored", dtype=dtype, **WEIGHTS)
+    sum(L.values()).backward()
+    return ({k: float(v.detach()) for k, v in L.items()},
+            {"seg_model." + k: p.grad.double().numpy() for k, p in params.items() if p.grad is not None})
+
+
+@pytest.mark.parametrize("depth", list(DEPTHS))
+@pytest.mark.parametrize("mode", ["O1_fp16", "O1_bf16"])
+def test_training_step_arithmetic_given_the_device_gates(tmp_path_factory, monkeypatch, mode, depth):
+    orc = _oracle(depth, tmp_path_factory, monkeypatch)
+    tr = _trainer(orc["root"], *MODES[mode])
+    masks, pool = _capture_gates(monkeypatch, tr.model.module)
+    losses, grads, _stats, scale = _device_step(tr)
+    n_relu = 1 + 3 * sum(DEPTHS[depth])
+    assert len(masks) == n_relu and "codes" in pool, (len(masks), n_relu)
+    sd = torch.load(os.path.join(orc["root"], "init.pth"))
+    want, og = _oracle_step_given_gates(sd, masks, pool["codes"])
+    _, free, _ = orc["f64"]     # the free-running float64 oracle (its own gates), for the record
+    lines = ["training step vs float64 oracle AROUND THE DEVICE'S GATES, mode %s, trunk %s %s, B=%d 3x%dx%d, loss scale %g"
+             % (mode, depth, DEPTHS[depth], B, H, W, scale),
+             "columns: cos(device, gated oracle) | max-rel | rel-L2 || cos(device, free oracle) for comparison"]
+    for k, v in want.items():
+        lines.append("loss %-22s device %.7f gated oracle %.7f rel %.2e" % (k, losses[k], v, abs(losses[k] - v) / max(1.0, abs(v))))
+    cos, rel, l2, fcos = {}, {}, {}, {}
+    order = [k for k in tr.model.module.state_dict() if k in og]
+    assert set(order) == set(grads)
+    for k in order:
+        cos[k], fcos[k] = _cos(grads[k], og[k]), _cos(grads[k], free[k])
+        rel[k] = float(np.abs(grads[k] - og[k]).max() / (np.abs(og[k]).max() + 1e-30))
+        l2[k] = float(np.linalg.norm(grads[k] - og[k]) / (np.linalg.norm(og[k]) + 1e-30))
+        lines.append("grad %-52s cos %.8f  max-rel %.2e  rel-L2 %.2e || free cos %.6f"
+                     % (k[len("seg_model."):], cos[k], rel[k], l2[k], fcos[k]))
+    trunk = [k for k in order if "aspp" not in k]
+    lines.append("summary: cos min %.8f (%s) mean %.8f; max-rel max %.2e median %.2e; rel-L2 max %.2e | free-running oracle: cos min "
+                 "%.6f mean %.6f" % (min(cos.values()), min(cos, key=cos.get)[len("seg_model."):], float(np.mean(list(cos.values()))),
+                                    max(rel.values()), float(np.median(list(rel.values()))), max(l2.values()),
+                                    min(fcos[k] for k in trunk), float(np.mean([fcos[k] for k in trunk]))))
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "r04_trainstep_gated_oracle_%s_%s.txt" % (depth, mode)), "w") as f:
+            f.write("\n".join(lines) + "\n")
+    except OSError:
+        pass
+    print("\n".join(lines[:6] + lines[-1:]))
+    for k, v in want.items():
+        assert abs(losses[k] - v) <= 3e-2 * max(1.0, abs(v)), (k, losses[k], v)
+    # measured on MI355X (profiles/r04_trainstep_gated_oracle_*): see GATED_BOUNDS
+    lo_cos, hi_rel = GATED_BOUNDS[depth][mode]
+    worst = min(cos.items(), key=lambda kv: kv[1])
+    assert worst[1] >= lo_cos, worst
+    worst = max(rel.items(), key=lambda kv: kv[1])
+    assert worst[1] <= hi_rel, worst
+
+
+# (cos floor, max-rel ceiling) per gradient tensor, every one of the 112 / 36: set from the first measurements with a margin
+GATED_BOUNDS = {"r26": {"O1_fp16": (0.9999, 2e-2), "O1_bf16": (0.999, 6e-2)},
+                "r101": {"O1_fp16": (0.9999, 2e-2), "O1_bf16": (0.999, 6e-2)}}

@@ -4,6 +4,8 @@
 set -euo pipefail
 cd "${GRAFT_REPO_ROOT:?}"
 tag="$1"; shift || true
+# a tag that ends in "serial": every part of the step on ONE stream (true per-kernel durations, nothing co-running)
+case "$tag" in *serial) export HIAST_BENCH_SERIAL=1 HIAST_NO_SIDE_STREAM=1 HIAST_NO_WGRAD_STREAM=1 HIAST_EVAL_SPLIT=1 HIAST_BENCH_PL_STREAM=0;; esac
 out="gpurun_out/prof_${tag}"
 rm -rf "$out"; mkdir -p "$out"
 export TMPDIR=/tmp
