@@ -358,6 +358,14 @@ def test_training_step_arithmetic_given_the_device_gates(tmp_path_factory, monke
     assert worst[1] <= hi_rel, worst
 
 
-# (cos floor, max-rel ceiling) per gradient tensor, every one of the 112 / 36: set from the first measurements with a margin
-GATED_BOUNDS = {"r26": {"O1_fp16": (0.9999, 2e-2), "O1_bf16": (0.999, 6e-2)},
-                "r101": {"O1_fp16": (0.9999, 2e-2), "O1_bf16": (0.999, 6e-2)}}
+# (cos floor, max-rel ceiling) for EVERY gradient tensor (112 / 36 of them), measured on MI355X (profiles/r04_trainstep_gated_
+# oracle_*) with a margin.  fp16: cos 0.99962-0.99987, rel-L2 1.6e-2 ... 2.8e-2 on the trunk (free-running oracle: cos 0.943), head
+# 3e-3; bf16: cos 0.976-0.99, rel-L2 0.21-0.22 — 8.0x the fp16 figure, the ratio of the two unit roundoffs: what is left IS
+# rounding, linear in e as arithmetic error must be (the free-running comparison goes with sqrt(e): 0.943 / 0.62).  It does not
+# grow with depth (1.6e-2 at layer4.2.conv3, right under the head; 2.2e-2 at layer1.0): the gradient is STORED in 16 bits
+# between the kernels and each BatchNorm backward subtracts the channel means from it (g - mean(g) - xhat * mean(g * xhat)),
+# which amplifies the relative rounding of g by |g| / |g - mean(g)|; the same holds for the reference's apex-O1 step.  A
+# mis-scaled epilogue, a dropped tap or a wrong statistic in ONE layer is an O(1) error in every tensor upstream of it:
+# far outside these bounds, and invisible to the free-running bound of 0.85.
+GATED_BOUNDS = {"r26": {"O1_fp16": (0.9993, 6e-2), "O1_bf16": (0.96, 0.4)},
+                "r101": {"O1_fp16": (0.9993, 6e-2), "O1_bf16": (0.96, 0.4)}}
