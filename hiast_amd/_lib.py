@@ -78,6 +78,10 @@ SIGNATURES = {
     "hiast_split_planes": (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
     "hiast_stem_tail": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "hiast_stem_eval": (c_int, [c_vp] * 6 + [c_f32, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "hiast_stem_train_blocks": (c_int, [c_int] * 3),
+    "hiast_stem_train_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "hiast_stem_wgrad_workspace_bytes": (c_sz, [c_int] * 3),
+    "hiast_stem_wgrad": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_sz, c_vp]),
     "hiast_ema_update": (c_int, [c_vp, c_vp, c_vp, c_int, c_f32, c_f32, c_vp]),
     "hiast_normalize_u8": (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_vp, c_vp]),
     "hiast_maxpool3x3s2_nhwc_fwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),

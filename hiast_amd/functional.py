@@ -525,6 +525,52 @@ def wgroup_weights(convs, x):
     return grp, wv
 
 
+class _StemConvFn(torch.autograd.Function):
+    """the 7x7 stride-2 stem convolution of the mixed-precision training forward on the hand-written kernels (K9k:
+    hiast_stem_train_fwd / hiast_stem_wgrad): reads the fp32 NCHW batch as it is (no channels-last copy, no cast), writes
+    16-bit channels-last rows and the per-block sums for the batch-statistics BatchNorm behind it; backward = the weight
+    gradient only (the image needs none).  Reference: `self.conv1(x)` in ResNet.forward, resnet.py:177-180, under apex O1."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, x, weight, fmt):
+        x = x.contiguous()
+        y, partial = K.stem_train_fwd(x, weight.detach(), fmt)
+        ctx.save_for_backward(x)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(partial)
+        return y.permute(0, 3, 1, 2), partial
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy, _dpartial=None):
+        if dy is None or not ctx.needs_input_grad[1]:
+            return None, None, None
+        x, = ctx.saved_tensors
+        dyv = dy.permute(0, 2, 3, 1)
+        if not dyv.is_contiguous():
+            dyv = dyv.contiguous()
+        side = wgrad_side_stream(x.device)
+        main = torch.cuda.current_stream()
+        if side is not None:
+            side.wait_stream(main)
+            dyv.record_stream(side)
+            x.record_stream(side)
+        with torch.cuda.stream(side if side is not None else main):
+            dw = K.stem_wgrad(x, dyv)
+        if side is not None:
+            dw.record_stream(main)
+        return None, dw, None
+
+
+def stem_conv_train(x, conv):
+    """-> (y logical [B,64,Hc,Wc] 16-bit with channels-last memory, partial) of the trunk's stem convolution under 16-bit
+    autocast (K9k)"""
+    dt = torch.get_autocast_dtype("cuda")
+    return _StemConvFn.apply(x.float() if x.dtype != torch.float32 else x, conv.weight,
+                             K.FMT_FP16 if dt == torch.float16 else K.FMT_BF16)
+
+
 _wgrad_streams = {}
 _wgrad_overlap = [False]
 _eval_streams = {}

@@ -832,6 +832,58 @@ def stem_eval(x, weight, bn, fmt):
     return out
 
 
+def stem_train_supported(conv):
+    """the module hiast_stem_train_fwd / hiast_stem_wgrad replace: Conv2d(3, 64, 7, 2, 3, bias=False)"""
+    import os
+    return (os.environ.get("HIAST_LIB_STEM", "0") != "1"
+            and (conv.in_channels, conv.out_channels, conv.kernel_size, conv.stride, conv.padding, conv.dilation, conv.groups)
+            == (3, 64, (7, 7), (2, 2), (3, 3), (1, 1), 1) and conv.bias is None)
+
+
+def stem_train_fwd(x, weight, fmt):
+    """K9k: the stem convolution of the training forward.  x fp32 [B,3,H,W] (NCHW), weight fp32 [64,3,7,7] ->
+    (y [B,Hc,Wc,64] 16-bit channels-last rows in format fmt, partial fp32 [blocks,64,2]: Σy, Σy² of the stored values)"""
+    _req(x, torch.float32, 4, "x")
+    _req(weight, torch.float32, 4, "stem weight")
+    assert tuple(weight.shape) == (64, 3, 7, 7) and x.shape[1] == 3
+    fmt = int(fmt)
+    B, _, H, W = x.shape
+    Hc, Wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    lib = _lib.load()
+    nblk = lib.hiast_stem_train_blocks(B, H, W)
+    if nblk <= 0:
+        raise _lib.HiastLibraryError("hiast_stem_train_fwd: unsupported geometry B=%d H=%d W=%d" % (B, H, W))
+    y = torch.empty((B, Hc, Wc, 64), dtype=fmt_dtype(fmt), device=x.device)
+    partial = torch.empty((nblk, 64, 2), dtype=torch.float32, device=x.device)
+    check(lib.hiast_stem_train_fwd(_ptr(x), _ptr(weight), _ptr(y), _ptr(partial), fmt, B, H, W, _stream()),
+          "hiast_stem_train_fwd")
+    return y, partial
+
+
+_stem_ws = {}
+
+
+def stem_wgrad(x, dy):
+    """K9k: dW fp32 [64,3,7,7] of the stem convolution from x fp32 [B,3,H,W] (NCHW) and dy [B,Hc,Wc,64] 16-bit rows"""
+    _req(x, torch.float32, 4, "x")
+    _req16(dy, 4, "dy")
+    B, _, H, W = x.shape
+    assert tuple(dy.shape) == (B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 64)
+    lib = _lib.load()
+    need = lib.hiast_stem_wgrad_workspace_bytes(B, H, W)
+    if need == 0:
+        raise _lib.HiastLibraryError("hiast_stem_wgrad: unsupported geometry B=%d H=%d W=%d" % (B, H, W))
+    key = (x.device, torch.cuda.current_stream(x.device).cuda_stream)
+    ws = _stem_ws.get(key)
+    if ws is None or ws.numel() * 4 < need:
+        ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
+        _stem_ws[key] = ws
+    dw = torch.empty((64, 3, 7, 7), dtype=torch.float32, device=x.device)
+    check(lib.hiast_stem_wgrad(_ptr(x), _ptr(dy), _ptr(dw), fmt_of(dy), B, H, W, _ptr(ws), ws.numel() * 4, _stream()),
+          "hiast_stem_wgrad")
+    return dw
+
+
 # ------------------------------------------------------------------------------- K9c LDS-DMA implicit GEMM on split planes
 # A "split-plane" activation is an opaque bf16 tensor [B,H,W,2*C] holding hi = bf16(v) and lo = bf16(v - hi) of an
 # fp32-class value (layout inside the last axis: include/hiast_hip.h, K9c); plain bf16 activations are [B,H,W,C].

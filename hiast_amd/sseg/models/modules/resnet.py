@@ -240,6 +240,7 @@ class ResNet(nn.Module):
         return p.permute(0, 3, 1, 2)
 
     def forward(self, x, is_return_low=False):
+        stem_partial = None
         if not is_return_low:
             PL = self.fast_eval_planes(x)
             if PL:
@@ -249,8 +250,13 @@ class ResNet(nn.Module):
             # mixed-precision step: the whole trunk runs channels-last (library stem -> 16-bit NHWC activations)
             if self.training and torch.is_grad_enabled():
                 self.prepack(3 if torch.get_autocast_dtype("cuda") == torch.float16 else 1, adjoint=True)
-            x = x.contiguous(memory_format=torch.channels_last)
-            x = self.conv1(x).contiguous(memory_format=torch.channels_last)
+            from hiast_amd import kernels as K
+            if self.bn1.training and K.stem_train_supported(self.conv1):
+                # K9k: own stem convolution straight from the fp32 NCHW batch, + the sums bn1 needs (HIAST_LIB_STEM=1: library)
+                x, stem_partial = HF.stem_conv_train(x, self.conv1)
+            else:
+                x = x.contiguous(memory_format=torch.channels_last)
+                x = self.conv1(x).contiguous(memory_format=torch.channels_last)
         else:
             x = self.conv1(x)
         batched = False
@@ -268,7 +274,8 @@ class ResNet(nn.Module):
         prev = HF._nbt_batched[0]
         HF._nbt_batched[0] = batched or prev
         try:
-            x = HF.maxpool(bn_act(self.bn1, x), self.maxpool)
+            x = HF.maxpool(bn_act(self.bn1, x) if stem_partial is None else HF.bn_act(x, self.bn1, partial=stem_partial),
+                           self.maxpool)
             low = self.layer1(x)
             x = self.layer4(self.layer3(self.layer2(low)))
         finally:

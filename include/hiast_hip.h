@@ -312,6 +312,21 @@ int hiast_stem_tail(const void* x, int dtype /* 0 fp32 | 1 bf16 | 2 fp16 */, con
  * Arithmetic: fmt's 16-bit operands (split planes: hi*hi + lo*hi + hi*lo) with fp32 accumulation. */
 int hiast_stem_eval(const float* x, const float* w, const float* gamma, const float* beta, const float* mean, const float* var,
                     float eps, void* out, int fmt, int B, int H, int W, hiast_stream_t stream);
+
+/* ---- K9k (round 4): the stem convolution of the TRAINING forward and its weight gradient -----------------------------------
+ * `x = self.conv1(x)` of ResNet.forward in model.train() under apex O1 (sseg/models/modules/resnet.py:177-180: a half-
+ * precision library convolution) and the autograd weight gradient of that nn.Conv2d (the image needs no data gradient).
+ * x fp32 [B,3,H,W] NCHW contiguous, w fp32 [64,3,7,7] -> y [B,Hc,Wc,64] channels-last rows in format fmt (HIAST_FMT_BF16 |
+ * HIAST_FMT_FP16; operands rounded to that type, fp32 accumulation), Hc = (H-1)/2+1, Wc = (W-1)/2+1, and partial fp32
+ * [hiast_stem_train_blocks(B,H,W)][64][2]: per-block sums Σy, Σy² of the STORED values for the batch-statistics BatchNorm that
+ * follows (hiast_bn_nhwc_apply_partial).  hiast_stem_wgrad: dw fp32 [64,3,7,7] from dy (rows like y) and the same x;
+ * per-block partials in `workspace` (hiast_stem_wgrad_workspace_bytes), added in a fixed order: bitwise reproducible. */
+int hiast_stem_train_blocks(int B, int H, int W);
+int hiast_stem_train_fwd(const float* x, const float* w, void* y, float* partial, int fmt, int B, int H, int W,
+                         hiast_stream_t stream);
+size_t hiast_stem_wgrad_workspace_bytes(int B, int H, int W);
+int hiast_stem_wgrad(const float* x, const void* dy, float* dw, int fmt, int B, int H, int W, void* workspace,
+                     size_t workspace_bytes, hiast_stream_t stream);
 /* hiast_pack_conv_weight for a list of weights in ONE launch (a trunk's 104 convolutions after every optimiser / EMA
  * update).  table: device array of records (mode = the `transpose` argument above; N, K multiples of 64, taps <= 9);
  * one block per 64 x 64 (n, k) tile of one weight: chunk_tensor[b] = record index, chunk_start[b] = index of the tile

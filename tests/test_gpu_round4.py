@@ -96,3 +96,72 @@ def test_layer4_block_groups_only_its_1x1_pair(monkeypatch):
     assert torch.equal(res["group"][0], res["single"][0])
     for a, b in zip(res["group"][1], res["single"][1]):
         assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
+
+
+# ------------------------------------------------------------------------------------------------ the training stem (K9k)
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 64, 128), (1, 70, 90), (3, 33, 47), (2, 128, 256)])
+def test_stem_train_fwd_and_wgrad_vs_fp32_on_the_rounded_operands(dt, shape):
+    """hiast_stem_train_fwd / hiast_stem_wgrad (conv 7x7 s2 p3, 3 -> 64, of the mixed-precision training forward) against
+    torch's fp32 convolution / weight gradient of the SAME 16-bit-rounded operands: outputs within one rounding of the
+    16-bit type, the per-block sums equal to the sums of the stored values, dW to fp32 summation order; ragged tiles
+    (sizes that are no multiples of the 8 x 16 tile), several images, bitwise repeatable"""
+    import torch.nn.functional as F
+    from hiast_amd import kernels as K
+    B, H, W = shape
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(77)
+    x = torch.randn(B, 3, H, W, generator=g).to(dev)
+    w = (torch.randn(64, 3, 7, 7, generator=g) * 0.1).to(dev)
+    fmt = K.FMT_FP16 if dt == torch.float16 else K.FMT_BF16
+    y, partial = K.stem_train_fwd(x, w, fmt)
+    Hc, Wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    assert tuple(y.shape) == (B, Hc, Wc, 64) and y.dtype == dt
+    xr, wr = x.to(dt).float(), w.to(dt).float()
+    ref = F.conv2d(xr, wr, None, 2, 3).permute(0, 2, 3, 1)
+    eps = 2.0 ** -10 if dt == torch.float16 else 2.0 ** -7
+    err = (y.float() - ref).abs()
+    assert (err <= eps * ref.abs() + 1e-5 * ref.abs().max()).all(), float(err.max())
+    sums = partial.double().sum(0)
+    yd = y.double().reshape(-1, 64)
+    assert torch.allclose(sums[:, 0], yd.sum(0), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(sums[:, 1], (yd * yd).sum(0), rtol=1e-5, atol=1e-3)
+    # weight gradient
+    dy = torch.randn(B, Hc, Wc, 64, generator=g).to(dt).to(dev)
+    dw = K.stem_wgrad(x, dy)
+    refw = torch.nn.grad.conv2d_weight(xr, (64, 3, 7, 7), dy.float().permute(0, 3, 1, 2), stride=2, padding=3)
+    assert dw.dtype == torch.float32 and tuple(dw.shape) == (64, 3, 7, 7)
+    assert (dw - refw).abs().max().item() <= 1e-4 * refw.abs().max().item()
+    assert torch.equal(dw, K.stem_wgrad(x, dy))
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_training_forward_with_own_stem_matches_the_library_stem(dt, monkeypatch):
+    """ResNet.forward in train mode under 16-bit autocast: the K9k stem (conv + statistics from its epilogue) against the
+    library convolution + statistics pass (HIAST_LIB_STEM=1) — trunk output and conv1's weight gradient"""
+    from hiast_amd.sseg.models.modules.resnet import ResNet
+    torch.manual_seed(3)
+    dev = torch.device("cuda:0")
+    net = ResNet(layers=(1, 1, 1, 1), strides=(1, 2, 1, 1), dilations=((1, 1), (1, 1), (1, 2), (2, 4))).to(dev).train()
+    x = torch.randn(2, 3, 96, 160, device=dev)
+    out = {}
+    for lib in ("1", "0"):
+        monkeypatch.setenv("HIAST_LIB_STEM", lib)
+        net.zero_grad()
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.reset_running_stats()
+        with torch.autocast("cuda", dtype=dt):
+            y = net(x)
+        y.float().square().mean().backward()
+        torch.cuda.synchronize()
+        out[lib] = (y.detach().float(), net.conv1.weight.grad.clone(), net.bn1.running_mean.clone(), net.bn1.running_var.clone())
+    tol = 2e-2 if dt == torch.float16 else 1e-1
+    a, b = out["0"], out["1"]
+    assert (a[0] - b[0]).abs().max().item() <= tol * b[0].abs().max().item()
+    cos = torch.nn.functional.cosine_similarity(a[1].flatten(), b[1].flatten(), dim=0).item()
+    # two 16-bit paths whose convolution outputs differ in the last bit: the gates of four blocks and of the pooling decorrelate
+    # (the sqrt(e) law of test_gpu_trainstep_oracle.py; measured 0.989 / fp16).  The exact checks of the two kernels are above,
+    # and test_training_step_arithmetic_given_the_device_gates bounds conv1's gradient in the assembled step.
+    assert cos >= (0.97 if dt == torch.float16 else 0.9), cos
+    assert torch.allclose(a[2], b[2], rtol=1e-3, atol=1e-4) and torch.allclose(a[3], b[3], rtol=1e-3, atol=1e-4)
