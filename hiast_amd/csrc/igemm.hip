@@ -228,7 +228,15 @@ static int igemm_launch_mode(const void* x, const void* wp, const float* gamma, 
     if ((((uintptr_t)x) | ((uintptr_t)wp) | ((uintptr_t)y) | ((uintptr_t)res)) & 15) return HIAST_E_RANGE;
     hiast::IGeo geo = {0, 0, 0, 0, 1, 1};
     size_t in_pix = (size_t)M;
-    if (taps != 1) {
+    if (taps != 1 && stride == -2) {
+        // transposed stride-2 3x3 (hiast_igemm_dgrad_s2): H x W is the OUTPUT map (the strided convolution's input), the
+        // operand rows are its output gradient on ((H-1)/2+1) x ((W-1)/2+1)
+        if (H <= 0 || W <= 0 || dil != 1 || planes != 1 || out_f32) return HIAST_E_ARG;
+        const int Hs = (H - 1) / 2 + 1, Ws = (W - 1) / 2 + 1;
+        if (M % ((int64_t)H * W) != 0) return HIAST_E_ARG;
+        geo = {Hs, Ws, H, W, -2, 1};
+        in_pix = (size_t)(M / ((int64_t)H * W)) * Hs * Ws;
+    } else if (taps != 1) {
         if (H <= 0 || W <= 0 || stride <= 0 || dil <= 0) return HIAST_E_ARG;
         const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
         if (M % ((int64_t)Ho * Wo) != 0) return HIAST_E_ARG;
@@ -280,6 +288,18 @@ extern "C" int hiast_igemm_dgrad_bn_stats(const void* dy, const void* wpt, void*
     if ((((uintptr_t)save_mean) | ((uintptr_t)save_invstd) | ((uintptr_t)gamma) | ((uintptr_t)beta)) & 15) return HIAST_E_RANGE;
     return igemm_launch_mode(dy, wpt, gamma, beta, save_mean, save_invstd, 0.0f, bn_x, 0, da, (int64_t)B * H * W, Cin, Cout,
                              taps, H, W, 1, dil, fmt, 0, (hipStream_t)stream, partial, nullptr, 0, 2);
+}
+
+// Data gradient of a 3x3 / stride-2 / padding-1 trunk convolution (layer2.0.conv2; autograd of that nn.Conv2d in
+// Bottleneck.forward, resnet.py:78-98): dx [B,H,W,Cin] = transposed convolution of dy [B,(H-1)/2+1,(W-1)/2+1,Cout] with the
+// adjoint-packed weight wpt (hiast_pack_conv_weight transpose) — the tile kernel with the parity test of the UPS variant.
+extern "C" int hiast_igemm_dgrad_s2(const void* dy, const void* wpt, void* dx, int B, int H, int W, int Cin, int Cout, int fmt,
+                                    hiast_stream_t stream)
+{
+    if (fmt != HIAST_FMT_BF16 && fmt != HIAST_FMT_FP16) return HIAST_E_RANGE;
+    if (B <= 0 || H <= 0 || W <= 0) return HIAST_E_ARG;
+    return igemm_launch_mode(dy, wpt, nullptr, nullptr, nullptr, nullptr, 0.0f, nullptr, 0, dx, (int64_t)B * H * W, Cout, Cin, 9,
+                             H, W, -2, 1, fmt, 0, (hipStream_t)stream, nullptr, nullptr, 0, 0);
 }
 
 extern "C" int hiast_igemm_dgrad_bn_stats_rows(int64_t M) { return M <= 0 ? 0 : (int)((M + hiast::IG_BM - 1) / hiast::IG_BM); }

@@ -166,7 +166,13 @@ __device__ __forceinline__ size_t ig_elem(size_t m, int c, int C)
 // BatchNorm backward then skips its statistics pass (one read of dA and x per layer).
 // F16 (PL = 1 only): the rows are IEEE fp16 instead of bf16 (HIAST_FMT_FP16: the reference's apex-O1 type) — same slabs,
 // same DMA / LDS images, v_mfma_f32_16x16x32_f16; decode / encode through H16<F16> (common.h).
-template <int PL, bool OUTF32, int BN, int TAPS, bool RES, bool RELU, int GATE = 0, int STATS = 0, bool F16 = false>
+// UPS (3x3, plain launches only): the TRANSPOSED stride-2 convolution — the data gradient of a 3x3 / stride-2 / padding-1
+// convolution (layer2.0.conv2 of the trunk).  The output map (geo.Ho x geo.Wo) is the convolution's INPUT map, the operand
+// (geo.H x geo.W) its output gradient: tap (ty, tx) of output pixel (y, x) reads source pixel ((y + ty - 1) / 2, (x + tx - 1) / 2)
+// when both are even and nothing otherwise (the weights are packed in adjoint form as for a stride-1 data gradient).  The
+// parity test joins the in-image test of the DMA address; three of four taps fetch zeros (which the DMA writes for free).
+template <int PL, bool OUTF32, int BN, int TAPS, bool RES, bool RELU, int GATE = 0, int STATS = 0, bool F16 = false,
+          bool UPS = false>
 __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
     const unsigned short* __restrict__ X, const unsigned short* __restrict__ Wp, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ var, float eps,
@@ -176,6 +182,7 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
 {
     static_assert(GATE == 0 || (PL == 1 && RES && !RELU && !OUTF32), "gated residual: bf16 data-gradient launches only");
     static_assert(!F16 || PL == 1, "fp16 rows are a one-plane format");
+    static_assert(!UPS || (TAPS == 9 && PL == 1 && !RES && !RELU && GATE == 0 && STATS == 0 && !OUTF32), "transposed stride 2: plain 3x3");
     using HT = H16<F16>;
     constexpr int WN = BN / 64, WM = 8 / WN;
     static_assert(!STATS || (PL == 1 && !OUTF32 && !RES && !RELU && GATE == 0), "statistics epilogue: plain bf16 launches only");
@@ -234,8 +241,8 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
             const int hw = geo.Ho * geo.Wo;
             an[g] = mc / hw;
             const int r = mc - an[g] * hw;
-            ay[g] = (r / geo.Wo) * geo.stride;
-            ax[g] = (r - (r / geo.Wo) * geo.Wo) * geo.stride;
+            ay[g] = (r / geo.Wo) * (UPS ? 1 : geo.stride);
+            ax[g] = (r - (r / geo.Wo) * geo.Wo) * (UPS ? 1 : geo.stride);
         }
     }
     int bvoff[BG];
@@ -258,8 +265,13 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
         if (TAPS == 1) {
             voff = (aok[g] & on) ? an[g] * (KS * 128) + achunk[g] : OOB;
         } else {
-            const int yy = ay[g] + (tap / 3 - 1) * geo.dil, xx = ax[g] + (tap % 3 - 1) * geo.dil;
-            const bool ok = aok[g] & on & ((unsigned)yy < (unsigned)geo.H) & ((unsigned)xx < (unsigned)geo.W);
+            int yy = ay[g] + (tap / 3 - 1) * geo.dil, xx = ax[g] + (tap % 3 - 1) * geo.dil;
+            bool par = true;
+            if (UPS) {                                       // (-1 is odd: rejected before the shift)
+                par = ((yy | xx) & 1) == 0;
+                yy >>= 1; xx >>= 1;
+            }
+            const bool ok = aok[g] & on & par & ((unsigned)yy < (unsigned)geo.H) & ((unsigned)xx < (unsigned)geo.W);
             const int pix = (an[g] * geo.H + yy) * geo.W + xx;
             voff = ok ? pix * (KS * 128) + achunk[g] : OOB;
         }
@@ -664,6 +676,21 @@ static int launch_igemm_t(const void* x, const void* wp, const float* gamma, con
     }
     dim3 grid((unsigned)((M + hiast::IG_BM - 1) / hiast::IG_BM), (N + BN - 1) / BN);
     const int gate = !res_gate ? 0 : (gate_mask ? 2 : 1);
+    if (geo.stride < 0) {                                   // transposed stride-2 3x3 (UPS): plain 16-bit launches only
+        if constexpr (PL == 1 && !OUTF32) {
+            if (taps != 9 || !plain || N % BN != 0) return HIAST_E_RANGE;
+#define LU(BNV)                                                                                                        \
+    hipLaunchKernelGGL((hiast::igemm_bn_act_kernel<PL, OUTF32, BNV, 9, false, false, 0, 0, F16, true>), grid, dim3(512), 0, st, \
+                       (const unsigned short*)x, (const unsigned short*)wp, gamma, beta, mean, var, eps,                \
+                       (const unsigned short*)res, y, (int)M, K, N, geo, stats, (const unsigned short*)res_gate)
+            if (BN == 256) LU(256); else if (BN == 128) LU(128); else LU(64);
+#undef LU
+            HIAST_CHECK_LAUNCH();
+            return 0;
+        } else {
+            return HIAST_E_RANGE;
+        }
+    }
 #define L(BNV, T, RES, RELU, G)                                                                                      \
     hipLaunchKernelGGL((hiast::igemm_bn_act_kernel<PL, OUTF32, BNV, T, RES, RELU, G, 0, F16>), grid, dim3(512), 0, st,    \
                        (const unsigned short*)x, (const unsigned short*)wp, gamma, beta, mean, var, eps,              \

@@ -180,6 +180,8 @@ def _sync_world(bn):
     return 1
 
 
+_OWN_S2_DGRAD = os.environ.get("HIAST_LIB_DGRAD_S2", "0") != "1"      # (=1: the library's data gradient for the strided 3x3)
+
 # read ONCE at import: the ranks of a job must issue the collectives of the statistics group at matching points, a switch
 # that is looked up per call could differ between them (or change between a forward and its backward)
 _NO_ASYNC_STAT = os.environ.get("HIAST_NO_ASYNC_STAT", "0") == "1"
@@ -338,7 +340,8 @@ class _ConvNhwcFn(torch.autograd.Function):
         if box is not None and stride == 1 and ctx.needs_input_grad[0]:
             box["armed"] = True                    # this conv's backward will take over the identity-branch gradient
             ctx.box = box
-        need_adj = stride == 1 and ctx.needs_input_grad[0]
+        # (the adjoint weight serves the stride-1 data gradients and the transposed form of the 3x3 / stride-2 one)
+        need_adj = ctx.needs_input_grad[0] and (stride == 1 or (stride == 2 and weight.shape[2] == 3 and dil == 1 and _OWN_S2_DGRAD))
         if packed is not None and packed[0] is not None and (not need_adj or packed[1] is not None):
             wp, ctx.wpt = packed                   # kernel-format copies kept current by ResNet.prepack (one launch)
         elif need_adj:                             # forward + adjoint (data-gradient) weight in one pack launch
@@ -367,7 +370,11 @@ class _ConvNhwcFn(torch.autograd.Function):
         pad = dil if k == 3 else 0
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         dx = dw = None
-        lib_x = need_x and stride != 1
+        own_s2 = need_x and stride == 2 and k == 3 and dil == 1 and _OWN_S2_DGRAD
+        lib_x = need_x and stride != 1 and not own_s2
+        if own_s2:              # hiast_igemm_dgrad_s2: the transposed form of the tile kernel (was the library's, round 3)
+            wpt = ctx.wpt if ctx.wpt is not None else K.pack_conv_weight(weight, K.fmt_of(x), transpose=True)
+            dx = K.igemm_dgrad_s2(dy.permute(0, 2, 3, 1), wpt, x.shape[2], x.shape[3]).permute(0, 3, 1, 2)
         if need_x and stride == 1:
             wpt = ctx.wpt if ctx.wpt is not None else K.pack_conv_weight(weight, K.fmt_of(x), transpose=True)
             gated = ctx.box.pop("gated", None) if ctx.box is not None else None

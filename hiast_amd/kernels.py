@@ -1059,6 +1059,20 @@ def igemm_dgrad_bn_stats(dy, wpt, dil, bn_x, gamma, beta, save_mean, save_invstd
     return da, partial
 
 
+def igemm_dgrad_s2(dy, wpt, H, W):
+    """data gradient of a 3x3 / stride-2 / padding-1 trunk convolution: dy [B,(H-1)//2+1,(W-1)//2+1,Cout] 16-bit rows,
+    wpt = adjoint packed weight [Cin, 9, Cout] -> dx [B,H,W,Cin] (hiast_igemm_dgrad_s2: the tile kernel's transposed form)"""
+    _req16(dy, 4, "dy")
+    _req(wpt, dy.dtype, 3, "wpt")
+    B, Hs, Ws, Cout = dy.shape
+    N, taps, KK = wpt.shape
+    assert taps == 9 and KK == Cout and (Hs, Ws) == ((H - 1) // 2 + 1, (W - 1) // 2 + 1), (tuple(dy.shape), tuple(wpt.shape), H, W)
+    dx = torch.empty((B, H, W, N), dtype=dy.dtype, device=dy.device)
+    check(_lib.load().hiast_igemm_dgrad_s2(_ptr(dy), _ptr(wpt), _ptr(dx), B, H, W, N, Cout, fmt_of(dy), _stream()),
+          "hiast_igemm_dgrad_s2")
+    return dx
+
+
 # ------------------------------------------------------------------------------- K10b BN (train) on channels-last bf16
 def _bnh_view(t, name):
     """logical [B,C,H,W] bf16 tensor with channels-last memory -> ([M,C] view, M, C)"""

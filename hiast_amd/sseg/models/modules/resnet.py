@@ -166,7 +166,9 @@ class ResNet(nn.Module):
             if not convs:
                 return
             plan = K.PackPlan([c.weight for c in convs], PL,
-                              [adjoint and (c.stride == (1, 1) or c.kernel_size == (1, 1)) for c in convs])
+                              [adjoint and (c.stride == (1, 1) or c.kernel_size == (1, 1)
+                                            or (c.kernel_size == (3, 3) and c.stride == (2, 2) and c.dilation == (1, 1)))
+                               for c in convs])
             ent = (plan, convs)
             plans[(PL, adjoint)] = ent
         plan, convs = ent

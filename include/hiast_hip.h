@@ -293,6 +293,11 @@ int hiast_igemm_dgrad_bn_stats(const void* dy, const void* wpt, void* da, int B,
                                const float* save_invstd, float* partial, int fmt /* HIAST_FMT_BF16 | HIAST_FMT_FP16 */,
                                hiast_stream_t stream);
 int hiast_igemm_dgrad_bn_stats_rows(int64_t M);
+/* Data gradient of the trunk's 3x3 / stride-2 / padding-1 convolution (layer2.0.conv2; autograd of nn.Conv2d in
+ * Bottleneck.forward, resnet.py:78-98 — round 4, was the library's): dx [B,H,W,Cin] from dy [B,(H-1)/2+1,(W-1)/2+1,Cout]
+ * and the adjoint-packed weight (hiast_pack_conv_weight, transpose = 1), 16-bit rows of format fmt. */
+int hiast_igemm_dgrad_s2(const void* dy, const void* wpt, void* dx, int B, int H, int W, int Cin, int Cout, int fmt,
+                         hiast_stream_t stream);
 int hiast_pack_conv_weight(const float* w, int N, int K, int taps, int fmt, int transpose, void* wp, void* wpt,
                            hiast_stream_t stream);
 int hiast_split_planes(float* x, void* planes, int64_t M, int C, int inverse, hiast_stream_t stream);

@@ -165,3 +165,55 @@ def test_training_forward_with_own_stem_matches_the_library_stem(dt, monkeypatch
     # and test_training_step_arithmetic_given_the_device_gates bounds conv1's gradient in the assembled step.
     assert cos >= (0.97 if dt == torch.float16 else 0.9), cos
     assert torch.allclose(a[2], b[2], rtol=1e-3, atol=1e-4) and torch.allclose(a[3], b[3], rtol=1e-3, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------ strided 3x3 data gradient
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [(2, 32, 48, 128, 128), (1, 33, 47, 128, 128), (3, 16, 18, 64, 128), (1, 40, 24, 256, 256)])
+def test_igemm_dgrad_s2_vs_fp32_on_the_rounded_operands(dt, cfg):
+    """hiast_igemm_dgrad_s2 (data gradient of a 3x3 / stride-2 / padding-1 convolution: the tile kernel's transposed form)
+    against torch's fp32 conv2d_input of the same 16-bit operands: even and odd map sizes, 64 / 128 / 256-column tiles"""
+    from hiast_amd import kernels as K
+    B, H, W, Cin, Cout = cfg
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(4321)
+    Hs, Ws = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    dy = torch.randn(B, Hs, Ws, Cout, generator=g).to(dt).to(dev)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).to(dev)
+    wpt = K.pack_conv_weight(w, K.fmt_of(dy), transpose=True)
+    dx = K.igemm_dgrad_s2(dy, wpt, H, W)
+    assert tuple(dx.shape) == (B, H, W, Cin) and dx.dtype == dt
+    ref = torch.nn.grad.conv2d_input((B, Cin, H, W), w.to(dt).float(), dy.float().permute(0, 3, 1, 2), stride=2,
+                                     padding=1).permute(0, 2, 3, 1)
+    eps = 2.0 ** -10 if dt == torch.float16 else 2.0 ** -7
+    err = (dx.float() - ref).abs()
+    assert (err <= eps * ref.abs() + 2e-5 * ref.abs().max()).all(), float(err.max())
+
+
+def test_strided_bottleneck_backward_without_the_library(monkeypatch):
+    """a layer2.0-shaped block (3x3 stride 2 + strided downsample) on the 16-bit training path: own transposed data gradient
+    against the library's (HIAST_LIB_DGRAD_S2=1 is read at import: the flag is patched on the module)"""
+    from hiast_amd import functional as HF
+    from hiast_amd.sseg.models.modules.resnet import Bottleneck
+    import torch.nn as nn
+    torch.manual_seed(5)
+    dev = torch.device("cuda:0")
+    down = nn.Sequential(nn.Conv2d(256, 512, 1, stride=2, bias=False), nn.BatchNorm2d(512))
+    blk = Bottleneck(256, 128, 2, 1, down).to(dev).train()
+    x0 = torch.randn(2, 256, 32, 48, device=dev).half().contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(2, 512, 16, 24, device=dev).half().contiguous(memory_format=torch.channels_last)
+    res = {}
+    for own in (False, True):
+        monkeypatch.setattr(HF, "_OWN_S2_DGRAD", own)
+        blk.zero_grad()
+        src = x0.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            y = blk(src * 1.0)
+        y.backward(gy)
+        torch.cuda.synchronize()
+        res[own] = (y.detach().float(), src.grad.float(), blk.conv1.weight.grad.clone())
+    assert torch.equal(res[True][0], res[False][0])
+    d = (res[True][1] - res[False][1]).abs()
+    assert float(d.max()) <= 2e-2 * float(res[False][1].abs().max())
+    assert float(d.mean()) <= 2e-3 * float(res[False][1].abs().mean())
+    assert torch.allclose(res[True][2], res[False][2], rtol=0, atol=2e-2 * float(res[False][2].abs().max()))
