@@ -322,17 +322,24 @@ def test_fused_adam_handles_the_loss_scale_on_the_device(K):
 
 
 def test_fp16_training_step_runs_the_trunk_on_the_own_kernels(K, monkeypatch, tmp_path):
-    """`train.amp_dtype: fp16` (apex O1's type): one ConsistencySelfTrainingTrainer step launches no library convolution
-    but the student's 7x7 stem in the forward (the teacher's stem is hiast_stem_eval since round 3) — every bottleneck
-    convolution goes through hiast_igemm_bn_act / hiast_xconv — and the step produces finite losses and gradients; the
-    same holds for bf16"""
+    """`train.amp_dtype: fp16` (apex O1's type): one ConsistencySelfTrainingTrainer step launches NO library convolution
+    (the teacher's stem is hiast_stem_eval since round 3, the student's hiast_stem_train_fwd since round 4; no nn.Conv2d
+    module runs its own forward, and aten's convolution_backward is never called) — every bottleneck convolution goes through
+    hiast_igemm_bn_act / hiast_xconv — and the step produces finite losses and gradients; the same holds for bf16"""
     from test_gpu_trainstep_oracle import _trainer, _state, _inputs, _patch_depth
     _patch_depth(monkeypatch, "r26")
     root = str(tmp_path)
     torch.save(_state("r26"), root + "/init.pth")
-    calls = {"conv_fwd": [], "igemm": 0}
+    calls = {"conv_fwd": [], "igemm": 0, "conv_bwd": 0}
     orig_fwd = torch.nn.Conv2d.forward
     orig_ig = K.igemm_bn_act
+    from torch.utils._python_dispatch import TorchDispatchMode
+
+    class NoLibraryConv(TorchDispatchMode):           # every aten op of the step passes here (autograd's backward included)
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            if "convolution" in str(func):
+                calls["conv_bwd"] += 1
+            return func(*args, **(kwargs or {}))
 
     def spy_fwd(self, x):
         calls["conv_fwd"].append(tuple(self.kernel_size))
@@ -348,10 +355,12 @@ def test_fp16_training_step_runs_the_trunk_on_the_own_kernels(K, monkeypatch, tm
         calls["conv_fwd"].clear()
         calls["igemm"] = 0
         tr = _trainer(root, "O1", amp)
-        losses = tr.train_on(dev(weak), dev(strong), dev(plbl))
-        tr.update_model(tr.g_optimizer, tr.d_optimizer, losses)
+        calls["conv_bwd"] = 0
+        with NoLibraryConv():
+            losses = tr.train_on(dev(weak), dev(strong), dev(plbl))
+            tr.update_model(tr.g_optimizer, tr.d_optimizer, losses)
         torch.cuda.synchronize()
-        assert calls["conv_fwd"] == [(7, 7)], (amp, calls["conv_fwd"])
+        assert calls["conv_fwd"] == [] and calls["conv_bwd"] == 0, (amp, calls["conv_fwd"], calls["conv_bwd"])
         assert calls["igemm"] >= 2 * 28, (amp, calls["igemm"])          # 28 trunk convolutions per forward (+ data gradients)
         assert all(np.isfinite(float(v)) for v in losses.values()), (amp, losses)
         if amp == "fp16":
