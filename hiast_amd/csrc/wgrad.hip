@@ -183,6 +183,9 @@ __device__ __forceinline__ void wgrad_tn_body(unsigned char* smem, const unsigne
         lin += w2 ? img_jump : 0;
     };
     auto issue = [&](int kt, int buf, int pc, bool on, int& xx, int& yy, int& lin) {
+#ifdef WG_ABL_NODMA       // diagnostic build (tools/build_variant.sh): the loop without its LDS-DMA
+        return;
+#endif
         const unsigned dst = dst0 + (unsigned)(buf * WG_STAGE + pc * 1024);
         if (TAPS == 1 || !is_x) {
             wg_dma16(is_x ? xrs : yrs, dst, on ? pv[pc & 3] : OOB, (kt * WG_ROWS + 4 * pc) * pitch2);
@@ -247,6 +250,9 @@ __device__ __forceinline__ void wgrad_tn_body(unsigned char* smem, const unsigne
         for (int pc = 0; pc < WG_PCS; ++pc) issue(s0, s0, pc, s0 < nk, w_xx, w_yy, w_lin);
     wg_bf16x8 fa[2][4], fb[2][2];                                 // fragments of the sub-steps (even | odd set)
     auto read_set = [&](int set, const unsigned char* st, int kk) {
+#ifdef WG_ABL_NOREAD      // diagnostic build: MFMAs on whatever the registers hold
+        return;
+#endif
 #pragma unroll
         for (int a = 0; a < 4; ++a)
             fa[set][a] = wg_join(wg_tr_read(st + oa[a][0] + kk * 4096), wg_tr_read(st + oa[a][1] + kk * 4096));
@@ -255,6 +261,13 @@ __device__ __forceinline__ void wgrad_tn_body(unsigned char* smem, const unsigne
             fb[set][b] = wg_join(wg_tr_read(st + ob[b][0] + kk * 4096), wg_tr_read(st + ob[b][1] + kk * 4096));
     };
     auto mfma_set = [&](int set) {
+#ifdef WG_ABL_NOMFMA      // diagnostic build: the fragments are read (kept alive) but not multiplied
+#pragma unroll
+        for (int a = 0; a < 4; ++a) asm volatile("" ::"v"(fa[set][a]));
+#pragma unroll
+        for (int b = 0; b < 2; ++b) asm volatile("" ::"v"(fb[set][b]));
+        return;
+#endif
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
