@@ -118,6 +118,9 @@ class KernelTimer:
         def aspp2_key(x, wt, bias, dil, workspace=None, planes=None):
             return ("aspp2_fwd", tuple(x.shape), int(bias.numel()), 2 if planes == 2 else (0 if x.dtype == torch.float32 else 1),
                     str(x.dtype).replace("torch.", ""))
+        def wg_key(jobs):
+            return ("wgrad_group",) + tuple((tuple(j[0].shape), int(j[1].shape[3]), int(j[2])) for j in jobs)
+        self.wrap(K, "conv_wgrad_group", wg_key)
         self.wrap(K, "aspp_fwd", aspp_key)
         self.wrap(K, "aspp2_fwd", aspp2_key)
         self.wrap(K, "igemm_bn_act", ig_key)
@@ -149,6 +152,22 @@ def roofline_of(key, avg_ms, n, steps):
                           "algorithmic %.0f MB" % (pj["source"], pj["hbm_bytes_uncorrected"] / 1e6,
                                                    pj["algorithmic_bytes"] / 1e6))
         return d
+    if key[0] == "wgrad_group":
+        # grouped weight gradients of one bottleneck: jobs = ((dy shape [B,H,W,Cout], Cin, k), ...)
+        flop = sum(2.0 * j[0][0] * j[0][1] * j[0][2] * j[0][3] * j[1] * j[2] ** 2 for j in key[1:])
+        operands = sum(2.0 * j[0][0] * j[0][1] * j[0][2] * (j[0][3] + j[1]) for j in key[1:])
+        tiles = sum((j[0][3] // 256) * (j[1] // 256) * j[2] ** 2 for j in key[1:])
+        partial = 2.0 * tiles * (256 // tiles) * 256 * 256 * 4        # written by the blocks, read by the reduction
+        ach = flop / (avg_ms * 1e-3) / 1e12
+        return {"kernel": "hiast::wgrad_group_kernel + wgrad_group_reduce_kernel (the %d weight gradients of a bottleneck in one "
+                          "launch: transposed-read GEMM over the pixel index, fixed-order reduce)" % (len(key) - 1),
+                "bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": None,
+                "avg_launch_ms": avg_ms, "launches_per_step": n / steps,
+                "note": "algorithmic %.1f GFLOP per launch pair (%s); operands %.0f MB + fp32 partial tiles %.0f MB (written and "
+                        "read once) -> %.2f TB/s = %.0f%% of the 8 TB/s HBM roof; %d tiles x %d pixel ranges"
+                        % (flop / 1e9, ", ".join("%dx%d %d->%d" % (j[2], j[2], j[1], j[0][3]) for j in key[1:]),
+                           operands / 1e6, partial / 1e6, (operands + partial) / (avg_ms * 1e-3) / 1e12,
+                           100.0 * (operands + partial) / 8e12 / (avg_ms * 1e-3), tiles, 256 // tiles)}
     if key[0] == "aspp2_fwd":
         # whole ASPP head forward (tap GEMM + 33-tap shift-add), the kernel group the north star names
         shp, Cout, mode = key[1], key[2], key[3]
@@ -781,10 +800,11 @@ def main():
         if groups:
             sampled = 1                                  # steps on which launches were timed
             aspp = [g for g in groups if g[0][0] == "aspp2_fwd"]
-            groups = [g for g in groups if g[0][0] != "aspp2_fwd"]   # (its GEMM is also counted in the igemm groups)
+            wg = [g for g in groups if g[0][0] == "wgrad_group"]      # (reported beside the convolution groups, below)
+            groups = [g for g in groups if g[0][0] not in ("aspp2_fwd", "wgrad_group")]   # (the ASPP GEMM is also counted in the igemm groups)
             key, avg_ms, n, _tot = groups[0]            # dominant hand-written launch group of the step
             out["roofline"] = roofline_of(key, avg_ms, n, sampled)
-            others = [roofline_of(k, a, c, sampled) for k, a, c, _ in groups[1:4] + aspp[:2]]
+            others = [roofline_of(k, a, c, sampled) for k, a, c, _ in groups[1:4] + wg[:1] + aspp[:2]]
             out["roofline_other"] = [{kk: o[kk] for kk in ("kernel", "bound", "achieved", "peak", "unit", "frac",
                                                             "traffic", "avg_launch_ms", "launches_per_step", "note")}
                                      for o in others]

@@ -15,10 +15,11 @@ import torch.nn.functional as F
 from hiast_amd import functional as HF
 
 
-def bn_act(bn, x, res=None, relu=True):
-    """relu?(bn(x) [+ res]) — one fused HIP op on the device (hiast_bn_*), plain torch on CPU tensors"""
+def bn_act(bn, x, res=None, relu=True, partial=None):
+    """relu?(bn(x) [+ res]) — one fused HIP op on the device (hiast_bn_*), plain torch on CPU tensors.
+    partial: per-block (Σx, Σx²) from the producing kernel's epilogue (device only)"""
     if x.is_cuda:
-        return HF.bn_act(x, bn, res, relu)
+        return HF.bn_act(x, bn, res, relu, partial=partial)
     y = bn(x)
     if res is not None:
         y = y + res
@@ -276,8 +277,7 @@ class ResNet(nn.Module):
         prev = HF._nbt_batched[0]
         HF._nbt_batched[0] = batched or prev
         try:
-            x = HF.maxpool(bn_act(self.bn1, x) if stem_partial is None else HF.bn_act(x, self.bn1, partial=stem_partial),
-                           self.maxpool)
+            x = HF.maxpool(bn_act(self.bn1, x, partial=stem_partial), self.maxpool)
             low = self.layer1(x)
             x = self.layer4(self.layer3(self.layer2(low)))
         finally:

@@ -781,8 +781,13 @@ def test_training_trunk_channels_last_as_accurate_as_nchw_path(K):
     for k in ("layer1", "layer2", "layer3", "layer4", "pred"):
         e_nchw, e_nhwc = d(res["fp32"][k], res["nchw"][k]), d(res["fp32"][k], res["nhwc"][k])
         assert e_nhwc <= 1.3 * e_nchw + 2e-3, (k, e_nchw, e_nhwc)
-    assert d(res["nchw"]["layer1"], res["nhwc"]["layer1"]) < 2e-2
-    assert d(res["nchw"]["layer2"], res["nhwc"]["layer2"]) < 5e-2
+    # (round 4: the two paths no longer share the stem convolution — K9k against the library's — so their bf16 roundings are
+    # independent from the first layer on, and each is ~e away from the fp32 forward: what they may differ by from EACH OTHER is
+    # the sum of those two distances; measured 0.025 / 0.10 of the maximum at layer1 / layer2)
+    for k in ("layer1", "layer2"):
+        e_nchw, e_nhwc = d(res["fp32"][k], res["nchw"][k]), d(res["fp32"][k], res["nhwc"][k])
+        assert d(res["nchw"][k], res["nhwc"][k]) <= 1.25 * (e_nchw + e_nhwc) + 2e-3, (k, e_nchw, e_nhwc)
+    assert d(res["nchw"]["layer1"], res["nhwc"]["layer1"]) < 4e-2
     assert torch.allclose(res["nchw"]["rv"], res["nhwc"]["rv"], rtol=5e-2, atol=1e-4)
     for k in ("g_aspp", "g_l4"):       # gradients next to the loss: as aligned with fp32 as the NCHW path's
         cos = lambda a, b: float(torch.nn.functional.cosine_similarity(a.flatten().double(), b.flatten().double(), dim=0))

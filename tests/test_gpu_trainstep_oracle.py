@@ -278,8 +278,8 @@ def _capture_gates(monkeypatch, net):
             masks[names[id(bn)]] = (y.detach() > 0).cpu()
         return y
 
-    def ba(bn, x, res=None, relu=True):
-        y = real_ba(bn, x, res, relu)
+    def ba(bn, x, res=None, relu=True, **kw):
+        y = real_ba(bn, x, res, relu, **kw)
         if relu and torch.is_grad_enabled():
             masks[names[id(bn)]] = (y.detach() > 0).cpu()
         return y

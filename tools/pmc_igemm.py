@@ -19,6 +19,7 @@ SHAPES = {
     "l3conv3_pl1": (8, 64, 128, 256, 1024, 1, 1, 1, True),       # K9e xconv: teacher conv3 + BN + residual + ReLU
     "wgrad_l3conv3": (8, 64, 128, 256, 1024, 1, 1, 1, False),    # K9d: dW of the 256 -> 1024 1x1
     "wgrad_l3conv2": (8, 64, 128, 256, 256, 9, 2, 1, False),     # K9d: dW of the 3x3, dilation 2
+    "wgrad_group_l3": (8, 64, 128, 256, 1024, 0, 2, 1, False),   # K9d (round 4): the three dW of a layer3 bottleneck, one launch
 }
 
 
@@ -27,6 +28,17 @@ def main():
     B, H, W, Cin, Cout, taps, dil, PL, has_res = SHAPES[name]
     dev = torch.device("cuda")
     torch.manual_seed(0)
+    if name == "wgrad_group_l3":
+        mk = lambda c: torch.randn(B, H, W, c, device=dev).half()
+        x1, d1, x2, d2, x3, d3 = mk(Cout), mk(Cin), mk(Cin), mk(Cin), mk(Cin), mk(Cout)
+        jobs = [(d3, x3, 1, 1, 1), (d2, x2, 3, 1, dil), (d1, x1, 1, 1, 1)]
+        for _ in range(6):
+            K.conv_wgrad_group(jobs)
+        torch.cuda.synchronize()
+        alg = sum((j[0].numel() + j[1].numel()) * 2 + j[0].shape[3] * j[1].shape[3] * j[2] ** 2 * 4 for j in jobs)
+        flop = sum(2 * B * H * W * j[0].shape[3] * j[1].shape[3] * j[2] ** 2 for j in jobs)
+        print("shape %s algorithmic_bytes %d flop %d (+ 255 fp32 partial tiles of 256 KiB written and re-read)" % (name, alg, flop))
+        return
     if name.startswith("wgrad"):
         x = torch.randn(B, H, W, Cin, device=dev).bfloat16()
         dy = torch.randn(B, H, W, Cout, device=dev).bfloat16()

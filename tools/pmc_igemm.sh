@@ -9,7 +9,7 @@ rm -rf "$out"; mkdir -p "$out"
 shapes=("$@")
 if [ ${#shapes[@]} -eq 0 ]; then shapes=(l3conv2_pl2 l4conv2_pl2 l3conv3_pl2 l3conv1_pl2 l3conv2_pl1); fi
 for s in "${shapes[@]}"; do
-  case "$s" in wgrad*) filter=wgrad_tn;; l3conv3_pl1) filter=xconv_kernel;; l3conv3_pl2) filter=xconv2_kernel;; *) filter=igemm_bn_act;; esac
+  case "$s" in wgrad_group*) filter=wgrad_group_kernel;; wgrad*) filter=wgrad_tn;; l3conv3_pl1) filter=xconv_kernel;; l3conv3_pl2) filter=xconv2_kernel;; *) filter=igemm_bn_act;; esac
   for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
     tag=$(echo "$c" | tr ' ' '_' | cut -c1-20)
     rocprofv3 --pmc $c --output-format csv -d "$out/${s}_$tag" -o p -- python3 tools/pmc_igemm.py "$s" > "$out/${s}_$tag.log" 2>&1
