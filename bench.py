@@ -159,9 +159,16 @@ def roofline_of(key, avg_ms, n, steps):
         tiles = sum((j[0][3] // 256) * (j[1] // 256) * j[2] ** 2 for j in key[1:])
         partial = 2.0 * tiles * (256 // tiles) * 256 * 256 * 4        # written by the blocks, read by the reduction
         ach = flop / (avg_ms * 1e-3) / 1e12
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r04_pmc_igemm.json")
+        if os.path.exists(pmc) and [tuple(j) for j in key[1:]] == [((8, 64, 128, 1024), 256, 1), ((8, 64, 128, 256), 256, 3),
+                                                                    ((8, 64, 128, 256), 1024, 1)]:
+            for ent in json.load(open(pmc)).get("kernels", []):
+                if ent.get("name") == "wgrad_group_l3":
+                    traffic = ent["hbm_bytes_per_launch"]       # (the group kernel alone; the reduction re-reads the partials)
         return {"kernel": "hiast::wgrad_group_kernel + wgrad_group_reduce_kernel (the %d weight gradients of a bottleneck in one "
                           "launch: transposed-read GEMM over the pixel index, fixed-order reduce)" % (len(key) - 1),
-                "bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": None,
+                "bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": traffic,
                 "avg_launch_ms": avg_ms, "launches_per_step": n / steps,
                 "note": "algorithmic %.1f GFLOP per launch pair (%s); operands %.0f MB + fp32 partial tiles %.0f MB (written and "
                         "read once) -> %.2f TB/s = %.0f%% of the 8 TB/s HBM roof; %d tiles x %d pixel ranges"
@@ -202,7 +209,7 @@ def roofline_of(key, avg_ms, n, steps):
     peak = 2500.0 / 3.0 if PL == 2 else 2500.0
     alg_bytes = (B * Hh * Ww * CC + Cout * taps * CC) * 2 + M * Cout * (4 if out_f32 else 2 * PL) * (2 if has_res else 1)
     traffic = None
-    for pmc in ("r03_pmc_igemm.json", "r02_pmc_igemm.json"):       # (the newest collection that has this launch shape)
+    for pmc in ("r04_pmc_igemm.json", "r03_pmc_igemm.json", "r02_pmc_igemm.json"):       # (the newest collection that has this launch shape)
         pmc = os.path.join(ROOT, "profiles", pmc)
         if traffic is None and os.path.exists(pmc):
             for ent in json.load(open(pmc)).get("kernels", []):
@@ -425,7 +432,8 @@ class HotPath:
             side = self.side if (self.use_side and os.environ.get("HIAST_NO_SIDE_STREAM", "0") != "1") else main
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                teacher_lr = self._graphed(self.ema, self.amp)(self.weak, parts=1, eager=not self.use_side)
+                teacher_lr = self._graphed(self.ema, self.amp)(self.weak, parts=int(os.environ.get("HIAST_BENCH_TEACHER_PARTS", "1")),
+                                                               eager=not self.use_side)
         with torch.autocast("cuda", dtype=self.amp, enabled=self.amp is not None):
             out = self.model(self.strong, lowres=True)
         if self.teacher and side is not main:

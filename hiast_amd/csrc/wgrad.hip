@@ -20,6 +20,7 @@
 // constants ride in the scalar offset, the 3x3 pixel walk is branch-free, fragments are double-buffered across the four
 // sub-steps (182 / 209 VGPRs).  layer3 3x3 0.124 -> 0.105 ms, layer4 3x3 0.408 -> 0.319 ms (with the reduce pass).
 #include <hip/hip_bf16.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -334,12 +335,20 @@ struct WJob {
     const unsigned short* X;
     float* P;               // partials of this job: [nsplit][N][taps][K]
     float* dw;              // result, torch layout [N][K][kh][kw]
-    int M, N, K, taps, s1, m_per_split, tile_begin, f4_begin;
+    int M, N, K, taps, s1, m_per_split, nsplit, f4_begin;
     WGeo geo;
 };
+// map[logical block] = job << 14 | tile << 8 | pixel range.  The jobs of a launch may split the pixel index differently
+// (WG_MAXBLOCKS blocks in all): a block of a 1x1 job streams its rows from HBM once and is bound by that stream, a block of a
+// 3x3 job re-reads its rows nine times from L2 and is bound by the matrix pipes — with the SAME number of pixels per block the
+// 1x1 blocks finish last.  The host gives the 1x1 jobs more, shorter pixel ranges (wgrad_group_plan) and orders the blocks by
+// their position along the pixel index, so that the blocks that share rows (all tiles of one job and range) still sit on one
+// XCD at the same time.
+constexpr int WG_MAXBLOCKS = 256;
 struct WGroup {
     WJob j[WG_MAXJOBS];
-    int njobs, tiles, nsplit;
+    int njobs, nblocks;
+    unsigned short map[WG_MAXBLOCKS];
 };
 
 template <bool F16>
@@ -347,14 +356,9 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WGroup g)
 {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[WG_NST * WG_STAGE];
     const int lid = wg_logical_block(blockIdx.x, gridDim.x);
-    const int split = lid / g.tiles;
-    int t = lid - split * g.tiles, ji = 0;
-#pragma unroll
-    for (int q = 1; q < WG_MAXJOBS; ++q)
-        if (q < g.njobs && t >= g.j[q].tile_begin) ji = q;
-    ji = __builtin_amdgcn_readfirstlane(ji);
+    const unsigned e = __builtin_amdgcn_readfirstlane((unsigned)g.map[lid]);
+    const int ji = (int)(e >> 14), t = (int)((e >> 8) & 63u), split = (int)(e & 255u);
     const WJob& jb = g.j[ji];
-    t -= jb.tile_begin;
     if (jb.taps == 1)
         wgrad_tn_body<1, F16, false>(smem, jb.dY, jb.X, jb.P, jb.M, jb.N, jb.K, jb.geo, jb.m_per_split, t, split);
     else if (jb.s1)
@@ -412,7 +416,7 @@ __global__ __launch_bounds__(256) void wgrad_group_reduce_kernel(const WGroup g)
         if (q < g.njobs && idx4 >= g.j[q].f4_begin) ji = q;
     const WJob& jb = g.j[ji];
     idx4 -= jb.f4_begin;
-    const int N = jb.N, K = jb.K, taps = jb.taps, nsplit = g.nsplit;
+    const int N = jb.N, K = jb.K, taps = jb.taps, nsplit = jb.nsplit;
     const size_t per = (size_t)N * taps * K;
     if (idx4 * 4 >= (long long)per) return;
     const long long idx = idx4 * 4;
@@ -510,7 +514,8 @@ extern "C" int hiast_conv_wgrad_nhwc(const void* dy, const void* x, float* dw, i
 static int wgrad_group_plan(const hiast_wgrad_job* jobs, int njobs, hiast::WGroup& g, size_t& ws_bytes)
 {
     if (!jobs || njobs < 1 || njobs > hiast::WG_MAXJOBS) return HIAST_E_ARG;
-    int tiles = 0;
+    int tiles_of[hiast::WG_MAXJOBS];
+    int tiles = 0, tiles1 = 0, tiles9 = 0;
     long long f4 = 0, mmin = -1;
     for (int i = 0; i < njobs; ++i) {
         const hiast_wgrad_job& q = jobs[i];
@@ -529,27 +534,66 @@ static int wgrad_group_plan(const hiast_wgrad_job* jobs, int njobs, hiast::WGrou
         j.M = (int)M; j.N = q.Cout; j.K = q.Cin; j.taps = q.taps;
         j.s1 = (q.taps == 9 && q.stride == 1 && Wo >= 20) ? 1 : 0;
         j.geo = {q.H, q.W, Ho, Wo, q.stride, q.dil};
-        j.tile_begin = tiles;
         j.f4_begin = (int)f4;
-        tiles += (q.Cout / 256) * (q.Cin / 256) * q.taps;
+        tiles_of[i] = (q.Cout / 256) * (q.Cin / 256) * q.taps;
+        if (tiles_of[i] > 64) return HIAST_E_RANGE;          // (6 bits of the block map)
+        tiles += tiles_of[i];
+        (q.taps == 1 ? tiles1 : tiles9) += tiles_of[i];
         f4 += (long long)q.Cout * q.Cin * q.taps / 4;
         if (f4 >= (1ll << 31)) return HIAST_E_RANGE;
         mmin = (mmin < 0 || M < mmin) ? M : mmin;
     }
-    // ONE round of <= 256 blocks (see wgrad_nsplit), at least 16 k-steps per block
-    long long ns = 256 / tiles;
-    const long long smax = mmin / 512 > 0 ? mmin / 512 : 1;
-    ns = ns < 1 ? 1 : (ns > smax ? smax : ns);
-    ns = ns > 64 ? 64 : ns;
-    g.njobs = njobs; g.tiles = tiles; g.nsplit = (int)ns;
+    if (tiles > hiast::WG_MAXBLOCKS) return HIAST_E_RANGE;
+    // ONE round of <= 256 blocks (see wgrad_nsplit), at least 16 k-steps per block.  Uniform split first; when the launch
+    // mixes 1x1 and 3x3 jobs, the 1x1 jobs get `ratio` times shorter pixel ranges (their blocks take about that much longer
+    // per pixel: HBM-streamed rows against L2-fed ones; HIAST_WGROUP_RATIO, percent, tuning): the pair (s1, s9) with
+    // tiles1 * s1 + tiles9 * s9 <= 256 that minimises max(ratio / s1, 1 / s9)
+    const long long smax = mmin / 512 > 0 ? (mmin / 512 > 64 ? 64 : mmin / 512) : 1;
+    long long s1 = 256 / tiles, s9;
+    s1 = s1 < 1 ? 1 : (s1 > smax ? smax : s1);
+    s9 = s1;
+    static const int ratio_pct = [] { const char* e = getenv("HIAST_WGROUP_RATIO"); const int v = e ? atoi(e) : 100; return v >= 25 && v <= 400 ? v : 100; }();
+    if (tiles1 > 0 && tiles9 > 0 && ratio_pct != 100) {
+        double best = (double)ratio_pct / 100.0 / (double)s1;
+        if (1.0 / (double)s9 > best) best = 1.0 / (double)s9;
+        for (long long a = 1; a <= smax; ++a) {
+            const long long left = 256 - (long long)tiles1 * a;
+            if (left < tiles9) break;
+            long long b = left / tiles9;
+            b = b > smax ? smax : b;
+            const double c1 = (double)ratio_pct / 100.0 / (double)a, c9 = 1.0 / (double)b;
+            const double c = c1 > c9 ? c1 : c9;
+            if (c < best - 1e-12) { best = c; s1 = a; s9 = b; }
+        }
+    }
+    g.njobs = njobs;
     size_t off = 0;
+    int nblocks = 0;
+    struct Ent { double key; int job, tile, split; };
+    Ent ents[hiast::WG_MAXBLOCKS];
     for (int i = 0; i < njobs; ++i) {
         hiast::WJob& j = g.j[i];
+        const long long ns = j.taps == 1 ? s1 : s9;
+        j.nsplit = (int)ns;
         int mps = (int)((j.M + ns - 1) / ns);
         j.m_per_split = ((mps + hiast::WG_ROWS - 1) / hiast::WG_ROWS) * hiast::WG_ROWS;
         j.P = (float*)off;                               // offset for now; the launch adds the workspace base
         off += (size_t)ns * j.N * j.taps * j.K * sizeof(float);
+        for (int sp = 0; sp < (int)ns; ++sp)
+            for (int t = 0; t < tiles_of[i]; ++t) {
+                if (nblocks >= hiast::WG_MAXBLOCKS) return HIAST_E_RANGE;
+                ents[nblocks++] = {((double)sp + 0.5) / (double)ns, i, t, sp};
+            }
     }
+    // order by position along the pixel index (then job, pixel range, tile): a stable insertion sort of <= 256 entries
+    for (int a = 1; a < nblocks; ++a) {
+        const Ent e = ents[a];
+        int b = a - 1;
+        while (b >= 0 && (ents[b].key > e.key || (ents[b].key == e.key && ents[b].job > e.job))) { ents[b + 1] = ents[b]; --b; }
+        ents[b + 1] = e;
+    }
+    for (int a = 0; a < nblocks; ++a) g.map[a] = (unsigned short)((ents[a].job << 14) | (ents[a].tile << 8) | ents[a].split);
+    g.nblocks = nblocks;
     ws_bytes = off;
     return 0;
 }
@@ -579,7 +623,7 @@ extern "C" int hiast_conv_wgrad_group_nhwc(const hiast_wgrad_job* jobs, int njob
     }
     if (al & 15) return HIAST_E_RANGE;
     hipStream_t st = (hipStream_t)stream;
-    const unsigned blocks = (unsigned)(g.tiles * g.nsplit);
+    const unsigned blocks = (unsigned)g.nblocks;
     if (fmt == HIAST_FMT_FP16) hipLaunchKernelGGL(hiast::wgrad_group_kernel<true>, dim3(blocks), dim3(512), 0, st, g);
     else hipLaunchKernelGGL(hiast::wgrad_group_kernel<false>, dim3(blocks), dim3(512), 0, st, g);
     HIAST_CHECK_LAUNCH();

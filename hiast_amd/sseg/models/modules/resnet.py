@@ -1,11 +1,12 @@
 """ResNet-101 trunk without avgpool/fc, parameter names identical to the reference
 (sseg/models/modules/resnet.py:58-98,101-190 — torchvision naming: conv1/bn1/layer{1..4}.{i}.
 conv{1,2,3}/bn{1,2,3}/downsample.{0,1}) so released checkpoints load key-for-key.
-Every bottleneck convolution — inference (pseudo-label pass on fp32-class split planes, teacher forward in bf16)
-and the mixed-precision training forward / data gradient / weight gradient — runs on the hand-written LDS-DMA
-implicit-GEMM kernels (hiast_igemm_bn_act, hiast_conv_wgrad_nhwc) between the fused BatchNorm kernels
-(hiast_bn_nhwc_*); PyTorch-ROCm (MIOpen) keeps the 7x7 stem, the 3x3 stride-2 data gradient, the weight gradients
-below 256 channels, and the whole trunk in fp32 (apex_opt O0) training."""
+Every convolution of the trunk — inference (pseudo-label pass on fp32-class split planes, teacher forward in 16 bits: the
+stem is hiast_stem_eval) and the mixed-precision training forward / data gradient / weight gradient (the stem:
+hiast_stem_train_fwd / hiast_stem_wgrad; the bottlenecks: hiast_igemm_bn_act incl. the transposed form of the strided
+3x3, hiast_conv_wgrad_group_nhwc / hiast_conv_wgrad_nhwc / hiast_conv_wgrad_small_nhwc) — runs on the hand-written
+kernels between the fused BatchNorm kernels (hiast_bn_nhwc_*).  PyTorch-ROCm (MIOpen) carries the trunk only in fp32
+(apex_opt O0) training and on CPU tensors (BASELINE configs[0])."""
 import os
 
 import torch

@@ -242,7 +242,11 @@ int hiast_bn_act_bwd_apply(const void* dy, const void* y, const void* x, const f
  * [Cout][3][3][Cin]).  x [M = B*H*W][K = Cin]; 3x3: padding = dilation, stride 1 or 2, Ho = (H-1)/stride + 1.
  * dtype 2 (1x1 only): bf16 activations in, fp32 out/residual.  mean == NULL: no BatchNorm (a plain GEMM).
  * Cin % 32 == 0, Cout % 64 == 0, 16-byte aligned buffers.
- * hiast_bn_act_nhwc_infer: y[m][c] = act(x[m][c]*scale_c + shift_c) for the stem (library 7x7 conv) output. */
+ * hiast_bn_act_nhwc_infer: y[m][c] = act(x[m][c]*scale_c + shift_c) for the stem (library 7x7 conv) output.
+ * STATUS (round 4): hiast_conv1x1_bn_act_nhwc / hiast_conv3x3_bn_act_nhwc are the round-1 register-staged forms, superseded on
+ * every hot path by hiast_igemm_bn_act (K9c).  They stay in the ABI as the entry for fp32 / row-major NHWC callers (no packed
+ * weights, no operand format) and are exercised by tests/test_gpu_kernels.py and tools/ only; the same translation unit also
+ * holds the fp32-input GEMM behind hiast_aspp2_fwd's fp32 rows and hiast_bn_act_nhwc_infer (inference stem fallback). */
 int hiast_conv1x1_bn_act_nhwc(const void* x, const float* w, const float* gamma, const float* beta,
                               const float* mean, const float* var, float eps, const void* res, int relu,
                               void* y, int64_t M, int K, int N, int dtype, hiast_stream_t stream);
