@@ -327,9 +327,14 @@ class _ConvNhwcFn(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
-    def forward(ctx, x, weight, stride, dil, want_stats, box, packed, in_bn=None, wgroup=None):
+    def forward(ctx, x, weight, stride, dil, want_stats, box, packed, in_bn=None, wgroup=None, xsum=None):
         xv = x.permute(0, 2, 3, 1)
         ctx.wgroup = wgroup                   # (group dict, slot): the weight gradient is deferred to _WGroupFn.backward
+        # xsum = (dict, role): two convolutions read the SAME x (conv1 and the stride-1 downsample of a stage-entry block).
+        # The one whose backward runs first ('give': conv1, created later in the forward) hands its data gradient over
+        # instead of returning it, the other ('take') adds it in the epilogue of its own data-gradient launch: x receives
+        # ONE gradient and autograd's add kernel over the block input (33 - 134 MB, three per step) is not launched.
+        ctx.xsum = xsum if (xsum is not None and stride == 1 and ctx.needs_input_grad[0]) else None
         # in_bn: x = relu(bn(x0)) of a BatchNorm that registered itself there (and has no other consumer): the data
         # gradient of this convolution then also delivers that BatchNorm's backward sums (hiast_igemm_dgrad_bn_stats)
         ctx.in_bn = in_bn if (in_bn is not None and "bn" in in_bn and stride == 1 and ctx.needs_input_grad[0]
@@ -360,7 +365,7 @@ class _ConvNhwcFn(torch.autograd.Function):
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dy, _dpartial=None):
         if dy is None:
-            return None, None, None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None, None, None
         x, weight = ctx.saved_tensors
         stride, dil = ctx.geo
         if dy.dtype != x.dtype:
@@ -396,7 +401,15 @@ class _ConvNhwcFn(torch.autograd.Function):
                                     res_gate=(gated[1] if gated[1].dtype == torch.uint8
                                               else gated[1].permute(0, 2, 3, 1))).permute(0, 3, 1, 2)
             else:
-                dx = K.igemm_bn_act(dy.permute(0, 2, 3, 1), wpt, 1, None, None, False, 1, dil).permute(0, 3, 1, 2)
+                other = None
+                if ctx.xsum is not None and ctx.xsum[1] == "take":
+                    other = ctx.xsum[0].pop("dx", None)       # the gradient conv1's backward left for us (same shape as dx)
+                    ctx.xsum[0]["taken"] = True
+                dx = K.igemm_bn_act(dy.permute(0, 2, 3, 1), wpt, 1, None, None if other is None else other.permute(0, 2, 3, 1),
+                                    False, 1, dil).permute(0, 3, 1, 2)
+        if ctx.xsum is not None and ctx.xsum[1] == "give" and dx is not None and not ctx.xsum[0].get("taken"):
+            ctx.xsum[0]["dx"] = dx             # the downsample convolution's backward (it runs after this one) adds it
+            dx = None
         own_w = need_w and os.environ.get("HIAST_LIB_WGRAD", "0") != "1" and K.conv_wgrad_preferred(
             weight.shape[1], weight.shape[0], k, stride) and (k == 1 or dy.shape[3] >= 4)
         small_w = need_w and not own_w and os.environ.get("HIAST_LIB_WGRAD", "0") != "1" and K.conv_wgrad_small_supported(
@@ -411,7 +424,7 @@ class _ConvNhwcFn(torch.autograd.Function):
             # zero-stride placeholder of the weight's shape (no memory, no kernel) for autograd to pass on to it
             grp, slot = ctx.wgroup
             grp["jobs"][slot] = (dy.permute(0, 2, 3, 1), x.permute(0, 2, 3, 1), k, stride, dil)
-            return dx, _wgrad_token(weight), None, None, None, None, None, None, None
+            return dx, _wgrad_token(weight), None, None, None, None, None, None, None, None
         side = wgrad_side_stream(x.device) if (need_w and not lib_x) else None
         main = torch.cuda.current_stream()
         if side is not None:
@@ -441,7 +454,7 @@ class _ConvNhwcFn(torch.autograd.Function):
                                                                 # (DDP compares strides with its bucket view literally)
         if side is not None and dw is not None:
             dw.record_stream(main)
-        return dx, dw, None, None, None, None, None, None, None
+        return dx, dw, None, None, None, None, None, None, None, None
 
 
 _wgrad_tokens = {}
@@ -809,7 +822,7 @@ class _SubsampleClFn(torch.autograd.Function):
         return g, None
 
 
-def conv_nhwc(x, conv, want_stats=False, box=None, in_bn=None, wgroup=None):
+def conv_nhwc(x, conv, want_stats=False, box=None, in_bn=None, wgroup=None, xsum=None):
     """-> y, or (y, partial) with want_stats (see igemm_bn_act); box: identity-branch hand-off of a bottleneck;
     in_bn: statistics hand-off of the BatchNorm whose output x is (bn_act(..., stat_box=in_bn))"""
     w = conv.weight
@@ -827,7 +840,7 @@ def conv_nhwc(x, conv, want_stats=False, box=None, in_bn=None, wgroup=None):
         x = _SubsampleClFn.apply(x, stride)
         stride = 1
     return _ConvNhwcFn.apply(x, wv, stride, conv.dilation[0], bool(want_stats), box, packed, in_bn,
-                             None if wgroup is None else (wgroup[0], wgroup[1]))
+                             None if wgroup is None else (wgroup[0], wgroup[1]), xsum)
 
 
 _nbt_batched = [False]      # set by ResNet.forward while it has already advanced every num_batches_tracked at once

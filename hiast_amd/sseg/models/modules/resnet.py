@@ -35,12 +35,12 @@ def conv(m, x):
     return m(x)
 
 
-def conv_bn_act(cv, bn, x, res=None, relu=True, conv_box=None, bn_box=None, in_bn=None, stat_box=None, wgroup=None):
+def conv_bn_act(cv, bn, x, res=None, relu=True, conv_box=None, bn_box=None, in_bn=None, stat_box=None, wgroup=None, xsum=None):
     """relu?(bn(conv(x)) [+ res]).  On the channels-last bf16 training path the convolution's epilogue also
     delivers the per-block sums the BatchNorm needs (one pass over the activation less); stat_box / in_bn: the same for
     the BACKWARD sums — this BatchNorm registers itself in stat_box, the next conv_bn_act gets that dict as in_bn."""
     if x.is_cuda and x.dtype in HF.H16 and bn.training and HF.conv_nhwc_ok(x, cv):
-        y, partial = HF.conv_nhwc(x, cv, want_stats=True, box=conv_box, in_bn=in_bn, wgroup=wgroup)
+        y, partial = HF.conv_nhwc(x, cv, want_stats=True, box=conv_box, in_bn=in_bn, wgroup=wgroup, xsum=xsum)
         return HF.bn_act(y, bn, res, relu, partial=partial, box=bn_box, stat_box=stat_box)
     return bn_act(bn, conv(cv, x), res, relu)
 
@@ -85,7 +85,14 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        idt = x if self.downsample is None else conv_bn_act(self.downsample[0], self.downsample[1], x, relu=False)
+        # stage-entry block with a stride-1 downsample: conv1 and the downsample convolution read the same x; their two data
+        # gradients become one (HF._ConvNhwcFn xsum: conv1 hands its gradient to the downsample's data-gradient epilogue)
+        xs = None
+        if (self.downsample is not None and self.downsample[0].stride == (1, 1) and x.is_cuda and x.dtype in HF.H16
+                and self.bn1.training and x.requires_grad and os.environ.get("HIAST_NO_XSUM", "0") != "1"):
+            xs = {}
+        idt = x if self.downsample is None else conv_bn_act(self.downsample[0], self.downsample[1], x, relu=False,
+                                                            xsum=None if xs is None else (xs, "take"))
         # identity blocks on the channels-last training path: conv1's data-gradient epilogue adds the ReLU-masked
         # gradient of the identity branch itself (no masked copy written by bn3's backward, no separate add kernel);
         # `box` is the hand-off between the two autograd nodes of this call
@@ -97,7 +104,8 @@ class Bottleneck(nn.Module):
         if x.is_cuda and x.dtype in HF.H16 and self.bn1.training:
             grp, wv = HF.wgroup_weights((self.conv1, self.conv2, self.conv3), x)
         g = (lambda i: (grp, grp["slot"][i], wv[i]) if wv[i] is not None else None) if grp is not None else (lambda i: None)
-        o = conv_bn_act(self.conv1, self.bn1, x, conv_box=box, stat_box=sb1, wgroup=g(0))
+        o = conv_bn_act(self.conv1, self.bn1, x, conv_box=box, stat_box=sb1, wgroup=g(0),
+                        xsum=None if xs is None else (xs, "give"))
         o = conv_bn_act(self.conv2, self.bn2, o, in_bn=sb1, stat_box=sb2, wgroup=g(1))
         return conv_bn_act(self.conv3, self.bn3, o, res=idt, bn_box=box, in_bn=sb2, wgroup=g(2))        # += identity, ReLU
 

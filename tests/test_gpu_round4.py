@@ -217,3 +217,40 @@ def test_strided_bottleneck_backward_without_the_library(monkeypatch):
     assert float(d.max()) <= 2e-2 * float(res[False][1].abs().max())
     assert float(d.mean()) <= 2e-3 * float(res[False][1].abs().mean())
     assert torch.allclose(res[True][2], res[False][2], rtol=0, atol=2e-2 * float(res[False][2].abs().max()))
+
+
+def test_stage_entry_block_shared_input_gradient_handoff(monkeypatch):
+    """a layer3.0-shaped block (stride-1 downsample): conv1's data gradient is added in the epilogue of the downsample
+    convolution's data gradient (one rounding, no autograd add kernel) — against the two-gradient form (HIAST_NO_XSUM=1);
+    also with a retained graph run twice (the hand-off is consumed once, the second pass falls back to autograd's add)"""
+    import torch.nn as nn
+    from hiast_amd.sseg.models.modules.resnet import Bottleneck
+    torch.manual_seed(7)
+    dev = torch.device("cuda:0")
+    down = nn.Sequential(nn.Conv2d(512, 1024, 1, stride=1, bias=False), nn.BatchNorm2d(1024))
+    blk = Bottleneck(512, 256, 1, 1, down).to(dev).train()
+    x0 = torch.randn(2, 512, 24, 40, device=dev).half().contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(2, 1024, 24, 40, device=dev).half().contiguous(memory_format=torch.channels_last)
+    res = {}
+    for off in ("1", "0"):
+        monkeypatch.setenv("HIAST_NO_XSUM", off)
+        blk.zero_grad()
+        src = x0.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            y = blk(src * 1.0)
+        y.backward(gy, retain_graph=True)
+        g1 = src.grad.clone()
+        src.grad = None
+        blk.zero_grad()
+        y.backward(gy)
+        torch.cuda.synchronize()
+        res[off] = (y.detach().float(), g1.float(), src.grad.float(), blk.conv1.weight.grad.clone(),
+                    blk.downsample[0].weight.grad.clone())
+    a, b = res["0"], res["1"]
+    assert torch.equal(a[0], b[0])
+    for i in (1, 2):        # one fp16 rounding of the sum instead of two
+        d = (a[i] - b[i]).abs()
+        assert (d <= 2.0 ** -9 * b[i].abs() + 2.0 ** -10 * b[i].abs().max()).all(), float(d.max())
+    assert torch.equal(a[2], b[2]) or float((a[2] - b[2]).abs().max()) <= 2.0 ** -9 * float(b[2].abs().max())
+    for i in (3, 4):
+        assert torch.allclose(a[i], b[i], rtol=0, atol=2e-5 * float(b[i].abs().max()))
