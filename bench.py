@@ -161,8 +161,9 @@ def roofline_of(key, avg_ms, n, steps):
         ach = flop / (avg_ms * 1e-3) / 1e12
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r04_pmc_igemm.json")
-        if os.path.exists(pmc) and [tuple(j) for j in key[1:]] == [((8, 64, 128, 1024), 256, 1), ((8, 64, 128, 256), 256, 3),
-                                                                    ((8, 64, 128, 256), 1024, 1)]:
+        if os.path.exists(pmc) and sorted(tuple(j) for j in key[1:]) == sorted([((8, 64, 128, 1024), 256, 1),
+                                                                                 ((8, 64, 128, 256), 256, 3),
+                                                                                 ((8, 64, 128, 256), 1024, 1)]):
             for ent in json.load(open(pmc)).get("kernels", []):
                 if ent.get("name") == "wgrad_group_l3":
                     traffic = ent["hbm_bytes_per_launch"]       # (the group kernel alone; the reduction re-reads the partials)
