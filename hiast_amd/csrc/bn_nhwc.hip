@@ -95,7 +95,7 @@ __device__ __forceinline__ void bnh_store8(unsigned short* p, const float (&v)[8
     unsigned w[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) w[i] = H16<F16>::pack(v[2 * i], v[2 * i + 1]);
-    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    h_store16(p, w[0], w[1], w[2], w[3]);
 }
 
 // Thread t of a 256-thread block owns channel group cg = t % G (G = C/8, a power of two <= 256) and rows

@@ -181,8 +181,8 @@ __global__ __launch_bounds__(512) void stem_train_fwd_kernel(const float* __rest
             const uint2 a0 = s[0], a1 = s[1], a2 = s[2], a3 = s[3];
             if (gy < g.Hc && gx < g.Wc) {
                 unsigned short* d = y + (((size_t)b * g.Hc + gy) * g.Wc + gx) * 64 + ch * 16;
-                *reinterpret_cast<uint4*>(d) = make_uint4(a0.x, a0.y, a1.x, a1.y);
-                *reinterpret_cast<uint4*>(d + 8) = make_uint4(a2.x, a2.y, a3.x, a3.y);
+                h_store16(d, a0.x, a0.y, a1.x, a1.y);
+                h_store16(d + 8, a2.x, a2.y, a3.x, a3.y);
             }
         }
         tile.store(s_in + (buf ^ 1) * TT_IN_BYTES);     // the next tile's pixels -> the other input buffer
