@@ -45,6 +45,14 @@ typedef __attribute__((ext_vector_type(16))) float h_f32x16;
 #ifndef HIAST_NT
 #define HIAST_NT 1
 #endif
+__device__ __forceinline__ void h_store_f32(float* p, float v)
+{
+#if HIAST_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
 typedef unsigned int h_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void h_store16(void* p, unsigned a, unsigned b, unsigned c, unsigned d)
 {
