@@ -89,13 +89,14 @@ __device__ __forceinline__ void bnh_param8(const float* p, const float* some_val
     v[4] = has ? b.x : dflt; v[5] = has ? b.y : dflt; v[6] = has ? b.z : dflt; v[7] = has ? b.w : dflt;
 }
 
+// nt: streaming store (tensors from H_NT_MIN_BYTES on: common.h)
 template <bool F16>
-__device__ __forceinline__ void bnh_store8(unsigned short* p, const float (&v)[8])
+__device__ __forceinline__ void bnh_store8(unsigned short* p, const float (&v)[8], bool nt = false)
 {
     unsigned w[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) w[i] = H16<F16>::pack(v[2 * i], v[2 * i + 1]);
-    h_store16(p, w[0], w[1], w[2], w[3]);
+    h_store16(p, w[0], w[1], w[2], w[3], nt);
 }
 
 // Thread t of a 256-thread block owns channel group cg = t % G (G = C/8, a power of two <= 256) and rows
@@ -319,6 +320,7 @@ __global__ __launch_bounds__(256) void bnh_apply_kernel(const unsigned short* __
                                                         unsigned char* __restrict__ mask)   // optional [M][C/8]: y > 0 bits
 {
     const int G = C >> 3, RPP = 256 / G;
+    const bool nt_out = (long long)M * C * 2 >= H_NT_MIN_BYTES;      // wave-uniform: stream large outputs past the L2
     const int cg = threadIdx.x % G, rsub = threadIdx.x / G;
     // rows of the first chunk are requested before the per-channel parameters (see bnh_partial_kernel)
     constexpr int UNR = BNH_UNR_APPLY;
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(256) void bnh_apply_kernel(const unsigned short* __
                 bits |= (o > 0.f ? 1u : 0u) << k;
                 v[k] = o;
             }
-            bnh_store8<F16>(y + off, v);
+            bnh_store8<F16>(y + off, v, nt_out);
             if (mask) mask[(size_t)r * G + cg] = (unsigned char)bits;
         }
         r0 += step;
@@ -384,6 +386,7 @@ __global__ __launch_bounds__(256) void bnh_bwd_apply_kernel(
     unsigned short* __restrict__ dres, float* __restrict__ dgamma, float* __restrict__ dbeta, long long M, int C)
 {
     const int G = C >> 3, RPP = 256 / G;
+    const bool nt_out = (long long)M * C * 2 >= H_NT_MIN_BYTES;      // wave-uniform: stream large outputs past the L2
     const int cg = threadIdx.x % G, rsub = threadIdx.x / G;
     // rows of the first chunk are requested before the per-channel parameters (see bnh_partial_kernel)
     constexpr int UNR = BNH_UNR_BWD;
@@ -445,8 +448,8 @@ __global__ __launch_bounds__(256) void bnh_bwd_apply_kernel(
                 g[k] = gg;
                 xx[k] = k0[k] * (gg - mg[k] - (xx[k] - mean[k]) * invstd[k] * mgx[k]);
             }
-            bnh_store8<F16>(dx + off, xx);
-            if (DRES) bnh_store8<F16>(dres + off, g);
+            bnh_store8<F16>(dx + off, xx, nt_out);
+            if (DRES) bnh_store8<F16>(dres + off, g, nt_out);
         }
         r0 += step;
         if (r0 < lim) load_rows(r0);

@@ -8,7 +8,8 @@ pytestmark = pytest.mark.gpu
 
 # ------------------------------------------------------------------------------------------------ round 4: grouped weight gradients
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("cfg", [(2, 24, 40, 512, 256, 2), (1, 33, 47, 1024, 256, 2), (3, 16, 24, 1024, 512, 4)])
+@pytest.mark.parametrize("cfg", [(2, 24, 40, 512, 256, 2), (1, 33, 47, 1024, 256, 2), (3, 16, 24, 1024, 512, 4),
+                                 (8, 64, 128, 1024, 256, 2)])        # the last one: BASELINE configs[2], a layer3 block at B = 8
 def test_conv_wgrad_group_vs_single_launches_and_fp32(dt, cfg):
     """hiast_conv_wgrad_group_nhwc (the three weight gradients of a bottleneck in one launch + one reduction) against the
     fp32 weight gradient of the same 16-bit operands and against the one-by-one launches; ragged pixel ranges; repeatable"""
@@ -100,7 +101,7 @@ def test_layer4_block_groups_only_its_1x1_pair(monkeypatch):
 
 # ------------------------------------------------------------------------------------------------ the training stem (K9k)
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("shape", [(2, 64, 128), (1, 70, 90), (3, 33, 47), (2, 128, 256)])
+@pytest.mark.parametrize("shape", [(2, 64, 128), (1, 70, 90), (3, 33, 47), (2, 128, 256), (8, 512, 1024)])
 def test_stem_train_fwd_and_wgrad_vs_fp32_on_the_rounded_operands(dt, shape):
     """hiast_stem_train_fwd / hiast_stem_wgrad (conv 7x7 s2 p3, 3 -> 64, of the mixed-precision training forward) against
     torch's fp32 convolution / weight gradient of the SAME 16-bit-rounded operands: outputs within one rounding of the
@@ -131,7 +132,7 @@ def test_stem_train_fwd_and_wgrad_vs_fp32_on_the_rounded_operands(dt, shape):
     dw = K.stem_wgrad(x, dy)
     refw = torch.nn.grad.conv2d_weight(xr, (64, 3, 7, 7), dy.float().permute(0, 3, 1, 2), stride=2, padding=3)
     assert dw.dtype == torch.float32 and tuple(dw.shape) == (64, 3, 7, 7)
-    assert (dw - refw).abs().max().item() <= 1e-4 * refw.abs().max().item()
+    assert (dw - refw).abs().max().item() <= (1e-4 if B * H * W < (1 << 21) else 1e-3) * refw.abs().max().item()   # (fp32 sums of 1 M terms)
     assert torch.equal(dw, K.stem_wgrad(x, dy))
 
 
