@@ -255,3 +255,82 @@ def test_stage_entry_block_shared_input_gradient_handoff(monkeypatch):
     assert torch.equal(a[2], b[2]) or float((a[2] - b[2]).abs().max()) <= 2.0 ** -9 * float(b[2].abs().max())
     for i in (3, 4):
         assert torch.allclose(a[i], b[i], rtol=0, atol=2e-5 * float(b[i].abs().max()))
+
+
+# ------------------------------------------------------------------------------------------------ round-3 advisor findings
+def test_fused_adam_step_counts_when_a_tensor_sits_out_an_overflow_step():
+    """FusedAdam keeps ONE device-side count of skipped (overflow) steps: a parameter that has no gradient during such a step
+    must not have it subtracted from its own count.  Sequence: both step; only p0 steps and the step overflows; both step —
+    against torch.optim.Adam driven with the unscaled gradients of the steps that were applied to each tensor (round-3 advice:
+    t = step - skipped came out one too small, t = 0 gave 1 - beta^0 = 0 and inf parameters)"""
+    from hiast_amd.utils.utils import FusedAdam
+    torch.manual_seed(11)
+    dev = torch.device("cuda:0")
+    p_own = [torch.randn(64, 16, device=dev).requires_grad_(True), torch.randn(33, device=dev).requires_grad_(True)]
+    p_ref = [p.detach().clone().requires_grad_(True) for p in p_own]
+    own = FusedAdam(p_own, lr=1e-2)
+    ref = torch.optim.Adam(p_ref, lr=1e-2)
+    scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 8, growth_interval=1000)
+    scaler.scale(torch.zeros((), device=dev))
+    # (who has a gradient, overflow?)
+    plan = [((0, 1), False), ((0,), True), ((1,), False), ((0, 1), False), ((1,), True), ((0, 1), False)]
+    for who, overflow in plan:
+        scale = float(scaler.get_scale())
+        gs = {i: torch.randn_like(p_own[i]) for i in who}
+        for i, p in enumerate(p_own):
+            p.grad = None
+            if i in who:
+                p.grad = gs[i] * scale
+                if overflow:
+                    p.grad.view(-1)[0] = float("nan")
+        scaler.step(own)
+        scaler.update()
+        if not overflow:
+            for i, p in enumerate(p_ref):
+                p.grad = gs[i].clone() if i in who else None
+            ref.step()
+        for a, b in zip(p_own, p_ref):
+            assert torch.isfinite(a).all()
+            assert torch.allclose(a.detach(), b.detach(), rtol=2e-6, atol=2e-7), (who, overflow)
+    own._fold_steps()
+    assert [int(own.state[p]["step"]) for p in p_own] == [int(ref.state[p]["step"]) for p in p_ref] == [3, 4]
+
+
+def test_small_channel_weight_gradients_on_two_streams_do_not_share_partials(monkeypatch):
+    """round-3 advice (high): layer2.0's strided 3x3 has its weight gradient on the MAIN stream (its data gradient used to be
+    the library's), the other small-channel weight gradients of the block on the SIDE stream, and all of them shared one
+    partial-sum workspace per device — a race.  The workspaces are per (device, stream) now; with the side stream on and kept
+    busy, every weight gradient of the block equals the single-stream run bit for bit, repeatedly"""
+    import torch.nn as nn
+    from hiast_amd import functional as HF
+    from hiast_amd import kernels as K
+    from hiast_amd.sseg.models.modules.resnet import Bottleneck
+    torch.manual_seed(13)
+    dev = torch.device("cuda:0")
+    down = nn.Sequential(nn.Conv2d(256, 512, 1, stride=2, bias=False), nn.BatchNorm2d(512))
+    blk = Bottleneck(256, 128, 2, 1, down).to(dev).train()
+    x0 = torch.randn(4, 256, 64, 96, device=dev).half().contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(4, 512, 32, 48, device=dev).half().contiguous(memory_format=torch.channels_last)
+    names = ("conv1", "conv2", "conv3")
+
+    def run(overlap):
+        HF._wgrad_overlap[0] = overlap
+        blk.zero_grad()
+        src = x0.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            y = blk(src * 1.0)
+        y.backward(gy)
+        HF.wgrad_stream_join()
+        torch.cuda.synchronize()
+        return [getattr(blk, n).weight.grad.clone() for n in names] + [blk.downsample[0].weight.grad.clone()]
+    try:
+        for own_s2 in (True, False):        # (False: the round-3 arrangement — library data gradient, weight gradient on main)
+            monkeypatch.setattr(HF, "_OWN_S2_DGRAD", own_s2)
+            want = run(False)
+            for _ in range(4):
+                got = run(True)
+                for a, b in zip(got, want):
+                    assert torch.equal(a, b)
+    finally:
+        HF._wgrad_overlap[0] = False
+    assert len({k for k in K._wgrad_ws if k[0] == "small"}) >= 2      # one workspace per stream that launched them
