@@ -528,8 +528,10 @@ def wgroup_weights(convs, x):
     # = 204 blocks leave a fifth of the CUs idle (698 against 622 us) — there only the 1x1 pair is grouped (32 tiles x 8
     # ranges: 265 against 300 us) and the 3x3 keeps its own launch (36 tiles x 7 ranges).
     tiles = [(c.in_channels // 256) * (c.out_channels // 256) * c.kernel_size[0] ** 2 for c in convs]
-    fill = lambda idx: sum(tiles[i] for i in idx) * (256 // sum(tiles[i] for i in idx)) / 256.0 if sum(
-        tiles[i] for i in idx) <= 256 else 0.0
+
+    def fill(idx):      # fraction of the 256 CUs one round of (tiles x pixel ranges) blocks occupies
+        t = sum(tiles[i] for i in idx)
+        return t * (256 // t) / 256.0 if 0 < t <= 256 else 0.0
     member = list(range(len(convs)))
     if fill(member) < 0.9:
         member = [i for i in member if convs[i].kernel_size[0] == 1]
