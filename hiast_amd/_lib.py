@@ -56,6 +56,8 @@ SIGNATURES = {
     "hiast_igemm_bn_act": (c_int, [c_vp] * 6 + [c_f32, c_vp, c_int, c_vp] + [c_int] * 10 + [c_vp, c_vp, c_int, c_vp]),
     "hiast_igemm_stats_rows": (c_int, [c_i64, c_int, c_int, c_int, c_int]),
     "hiast_igemm_dgrad_bn_stats": (c_int, [c_vp, c_vp, c_vp] + [c_int] * 7 + [c_vp] * 6 + [c_int, c_vp]),
+    "hiast_xconv_dgrad_gated_bn_stats_rows": (c_int, [c_i64, c_int, c_int]),
+    "hiast_xconv_dgrad_gated_bn_stats": (c_int, [c_vp] * 10 + [c_i64, c_int, c_int, c_int, c_vp]),
     "hiast_igemm_dgrad_s2": (c_int, [c_vp, c_vp, c_vp] + [c_int] * 6 + [c_vp]),
     "hiast_igemm_dgrad_bn_stats_rows": (c_int, [c_i64]),
     "hiast_bn_nhwc_stats_from_partial": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),

@@ -180,6 +180,7 @@ def _sync_world(bn):
     return 1
 
 
+_BN3_FUSION = os.environ.get("HIAST_NO_BN3_FUSION", "0") != "1"     # bn3's backward sums from the next block's conv1 data gradient
 _OWN_S2_DGRAD = os.environ.get("HIAST_LIB_DGRAD_S2", "0") != "1"      # (=1: the library's data gradient for the strided 3x3)
 
 # read ONCE at import: the ranks of a job must issue the collectives of the statistics group at matching points, a switch
@@ -288,6 +289,12 @@ class _BnActNhwcFn(torch.autograd.Function):
             stat_box["bn"] = (x.detach(), sm, si, gamma, beta)
             stat_box["world"] = world
             ctx.stat_box = stat_box
+        elif stat_box is not None and ctx.gate == 3:
+            # bn3 of a bottleneck (residual + ReLU, gate bits written): conv1 of the NEXT identity block may deliver this layer's
+            # backward sums from the epilogue that writes the gradient of y (hiast_xconv_dgrad_gated_bn_stats, round 4)
+            stat_box["bn3"] = (x.detach(), out[3], sm, si)
+            stat_box["world"] = world
+            ctx.stat_box = stat_box
         return y
 
     @staticmethod
@@ -327,8 +334,15 @@ class _ConvNhwcFn(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
-    def forward(ctx, x, weight, stride, dil, want_stats, box, packed, in_bn=None, wgroup=None, xsum=None):
+    def forward(ctx, x, weight, stride, dil, want_stats, box, packed, in_bn=None, wgroup=None, xsum=None, in_bn3=None):
         xv = x.permute(0, 2, 3, 1)
+        # in_bn3: x is the output of the PREVIOUS bottleneck (relu(bn3(.) + identity), registered there) and this is conv1 of an
+        # identity block whose backward adds the identity gradient itself: its data gradient also delivers that bn3's sums
+        ctx.in_bn3 = None
+        if (in_bn3 is not None and "bn3" in in_bn3 and box is not None and stride == 1 and weight.shape[2] == 1
+                and ctx.needs_input_grad[0] and _BN3_FUSION
+                and K.xconv_dgrad_gated_bn_stats_ok(x.shape[0] * x.shape[2] * x.shape[3], weight.shape[0], weight.shape[1])):
+            ctx.in_bn3 = in_bn3
         ctx.wgroup = wgroup                   # (group dict, slot): the weight gradient is deferred to _WGroupFn.backward
         # xsum = (dict, role): two convolutions read the SAME x (conv1 and the stride-1 downsample of a stage-entry block).
         # The one whose backward runs first ('give': conv1, created later in the forward) hands its data gradient over
@@ -365,7 +379,7 @@ class _ConvNhwcFn(torch.autograd.Function):
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dy, _dpartial=None):
         if dy is None:
-            return None, None, None, None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None, None, None, None
         x, weight = ctx.saved_tensors
         stride, dil = ctx.geo
         if dy.dtype != x.dtype:
@@ -396,6 +410,17 @@ class _ConvNhwcFn(torch.autograd.Function):
                 else:
                     ctx.in_bn["bwd_partial"] = bpartial
                 dx = dxv.permute(0, 3, 1, 2)
+            elif gated is not None and ctx.in_bn3 is not None and gated[1].dtype == torch.uint8:
+                # ... and the backward sums of the previous block's bn3, whose output's gradient this launch writes (K9e')
+                bx3, bmask, sm3, si3 = ctx.in_bn3["bn3"]
+                dxv, bpartial = K.xconv_dgrad_gated_bn_stats(dy.permute(0, 2, 3, 1), wpt, gated[0].permute(0, 2, 3, 1), gated[1],
+                                                             bx3.permute(0, 2, 3, 1), bmask, sm3, si3)
+                if ctx.in_bn3.get("world", 1) > 1 and not _NO_ASYNC_STAT:
+                    bsums = K.bn_nhwc_stats_from_partial(bpartial)
+                    ctx.in_bn3["bwd_sums"] = (bsums, _stat_all_reduce(bsums, async_op=True))
+                else:
+                    ctx.in_bn3["bwd_partial"] = bpartial
+                dx = dxv.permute(0, 3, 1, 2)
             elif gated is not None:    # + dy_block * (y_block > 0): the identity branch's gradient, in the epilogue
                 dx = K.igemm_bn_act(dy.permute(0, 2, 3, 1), wpt, 1, None, gated[0].permute(0, 2, 3, 1), False, 1, dil,
                                     res_gate=(gated[1] if gated[1].dtype == torch.uint8
@@ -424,7 +449,7 @@ class _ConvNhwcFn(torch.autograd.Function):
             # zero-stride placeholder of the weight's shape (no memory, no kernel) for autograd to pass on to it
             grp, slot = ctx.wgroup
             grp["jobs"][slot] = (dy.permute(0, 2, 3, 1), x.permute(0, 2, 3, 1), k, stride, dil)
-            return dx, _wgrad_token(weight), None, None, None, None, None, None, None, None
+            return dx, _wgrad_token(weight), None, None, None, None, None, None, None, None, None
         side = wgrad_side_stream(x.device) if (need_w and not lib_x) else None
         main = torch.cuda.current_stream()
         if side is not None:
@@ -454,7 +479,7 @@ class _ConvNhwcFn(torch.autograd.Function):
                                                                 # (DDP compares strides with its bucket view literally)
         if side is not None and dw is not None:
             dw.record_stream(main)
-        return dx, dw, None, None, None, None, None, None, None, None
+        return dx, dw, None, None, None, None, None, None, None, None, None
 
 
 _wgrad_tokens = {}
@@ -824,7 +849,7 @@ class _SubsampleClFn(torch.autograd.Function):
         return g, None
 
 
-def conv_nhwc(x, conv, want_stats=False, box=None, in_bn=None, wgroup=None, xsum=None):
+def conv_nhwc(x, conv, want_stats=False, box=None, in_bn=None, wgroup=None, xsum=None, in_bn3=None):
     """-> y, or (y, partial) with want_stats (see igemm_bn_act); box: identity-branch hand-off of a bottleneck;
     in_bn: statistics hand-off of the BatchNorm whose output x is (bn_act(..., stat_box=in_bn))"""
     w = conv.weight
@@ -842,7 +867,7 @@ def conv_nhwc(x, conv, want_stats=False, box=None, in_bn=None, wgroup=None, xsum
         x = _SubsampleClFn.apply(x, stride)
         stride = 1
     return _ConvNhwcFn.apply(x, wv, stride, conv.dilation[0], bool(want_stats), box, packed, in_bn,
-                             None if wgroup is None else (wgroup[0], wgroup[1]), xsum)
+                             None if wgroup is None else (wgroup[0], wgroup[1]), xsum, in_bn3)
 
 
 _nbt_batched = [False]      # set by ResNet.forward while it has already advanced every num_batches_tracked at once

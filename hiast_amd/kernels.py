@@ -1059,6 +1059,41 @@ def igemm_dgrad_bn_stats(dy, wpt, dil, bn_x, gamma, beta, save_mean, save_invstd
     return da, partial
 
 
+def xconv_dgrad_gated_bn_stats_ok(M, K, N):
+    """shapes hiast_xconv_dgrad_gated_bn_stats takes (conv1 of a layer3 identity block)"""
+    return _lib.load().hiast_xconv_dgrad_gated_bn_stats_rows(int(M), int(K), int(N)) > 0
+
+
+def xconv_dgrad_gated_bn_stats(dy, wpt, res, res_gate, bn_x, bn_mask, save_mean, save_invstd):
+    """conv1's data gradient of an identity bottleneck + the backward sums of the previous block's bn3 (K9e'):
+    dy [B,H,W,K] (K = 256), wpt adjoint packed [N,1,K], res [B,H,W,N] + res_gate u8 [M,N/8] (this block's output gradient and
+    ReLU gate bits), bn_x [B,H,W,N] + bn_mask u8 [M,N/8] + save_mean / save_invstd [N] (the previous block's bn3)
+    -> (dx [B,H,W,N], partial fp32 [rows,N,2])"""
+    _req16(dy, 4, "dy")
+    _req(wpt, dy.dtype, 3, "wpt")
+    _req(res, dy.dtype, 4, "res")
+    _req(bn_x, dy.dtype, 4, "bn_x")
+    B, H, W, Kc = dy.shape
+    N, taps, KK = wpt.shape
+    M = B * H * W
+    assert taps == 1 and KK == Kc and tuple(res.shape) == (B, H, W, N) and tuple(bn_x.shape) == (B, H, W, N)
+    for t, nm in ((res_gate, "res_gate"), (bn_mask, "bn_mask")):
+        _req(t, torch.uint8, 2, nm)
+        assert tuple(t.shape) == (M, N // 8), nm
+    _req(save_mean, torch.float32, 1, "save_mean")
+    _req(save_invstd, torch.float32, 1, "save_invstd")
+    lib = _lib.load()
+    rows = lib.hiast_xconv_dgrad_gated_bn_stats_rows(M, Kc, N)
+    if rows <= 0:
+        raise _lib.HiastLibraryError("hiast_xconv_dgrad_gated_bn_stats: unsupported shape M=%d K=%d N=%d" % (M, Kc, N))
+    dx = torch.empty((B, H, W, N), dtype=dy.dtype, device=dy.device)
+    partial = torch.empty((rows, N, 2), dtype=torch.float32, device=dy.device)
+    check(lib.hiast_xconv_dgrad_gated_bn_stats(_ptr(dy), _ptr(wpt), _ptr(res), _ptr(res_gate), _ptr(bn_x), _ptr(bn_mask),
+                                               _ptr(save_mean), _ptr(save_invstd), _ptr(dx), _ptr(partial), M, Kc, N,
+                                               fmt_of(dy), _stream()), "hiast_xconv_dgrad_gated_bn_stats")
+    return dx, partial
+
+
 def igemm_dgrad_s2(dy, wpt, H, W):
     """data gradient of a 3x3 / stride-2 / padding-1 trunk convolution: dy [B,(H-1)//2+1,(W-1)//2+1,Cout] 16-bit rows,
     wpt = adjoint packed weight [Cin, 9, Cout] -> dx [B,H,W,Cin] (hiast_igemm_dgrad_s2: the tile kernel's transposed form)"""

@@ -35,12 +35,13 @@ def conv(m, x):
     return m(x)
 
 
-def conv_bn_act(cv, bn, x, res=None, relu=True, conv_box=None, bn_box=None, in_bn=None, stat_box=None, wgroup=None, xsum=None):
+def conv_bn_act(cv, bn, x, res=None, relu=True, conv_box=None, bn_box=None, in_bn=None, stat_box=None, wgroup=None, xsum=None,
+                in_bn3=None):
     """relu?(bn(conv(x)) [+ res]).  On the channels-last bf16 training path the convolution's epilogue also
     delivers the per-block sums the BatchNorm needs (one pass over the activation less); stat_box / in_bn: the same for
     the BACKWARD sums — this BatchNorm registers itself in stat_box, the next conv_bn_act gets that dict as in_bn."""
     if x.is_cuda and x.dtype in HF.H16 and bn.training and HF.conv_nhwc_ok(x, cv):
-        y, partial = HF.conv_nhwc(x, cv, want_stats=True, box=conv_box, in_bn=in_bn, wgroup=wgroup, xsum=xsum)
+        y, partial = HF.conv_nhwc(x, cv, want_stats=True, box=conv_box, in_bn=in_bn, wgroup=wgroup, xsum=xsum, in_bn3=in_bn3)
         return HF.bn_act(y, bn, res, relu, partial=partial, box=bn_box, stat_box=stat_box)
     return bn_act(bn, conv(cv, x), res, relu)
 
@@ -104,10 +105,16 @@ class Bottleneck(nn.Module):
         if x.is_cuda and x.dtype in HF.H16 and self.bn1.training:
             grp, wv = HF.wgroup_weights((self.conv1, self.conv2, self.conv3), x)
         g = (lambda i: (grp, grp["slot"][i], wv[i]) if wv[i] is not None else None) if grp is not None else (lambda i: None)
+        # x may carry the registration of the previous block's bn3 (below): conv1's data gradient of an identity block then also
+        # delivers that BatchNorm's backward sums (HF._ConvNhwcFn in_bn3)
         o = conv_bn_act(self.conv1, self.bn1, x, conv_box=box, stat_box=sb1, wgroup=g(0),
-                        xsum=None if xs is None else (xs, "give"))
+                        xsum=None if xs is None else (xs, "give"), in_bn3=getattr(x, "_hiast_bn3", None) if box is not None else None)
         o = conv_bn_act(self.conv2, self.bn2, o, in_bn=sb1, stat_box=sb2, wgroup=g(1))
-        return conv_bn_act(self.conv3, self.bn3, o, res=idt, bn_box=box, in_bn=sb2, wgroup=g(2))        # += identity, ReLU
+        sb3 = {}
+        y = conv_bn_act(self.conv3, self.bn3, o, res=idt, bn_box=box, in_bn=sb2, stat_box=sb3, wgroup=g(2))   # += identity, ReLU
+        if "bn3" in sb3:
+            y._hiast_bn3 = sb3         # read by the next block (the one consumer of y besides its identity path)
+        return y
 
     def forward_eval_planes(self, x, fmt):
         """inference on channels-last 16-bit activations [B,H,W,planes*C] in operand format `fmt` (K.FMT_SPLIT_BF16: split

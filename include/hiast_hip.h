@@ -302,6 +302,17 @@ int hiast_igemm_dgrad_bn_stats_rows(int64_t M);
  * and the adjoint-packed weight (hiast_pack_conv_weight, transpose = 1), 16-bit rows of format fmt. */
 int hiast_igemm_dgrad_s2(const void* dy, const void* wpt, void* dx, int B, int H, int W, int Cin, int Cout, int fmt,
                          hiast_stream_t stream);
+/* Data gradient of conv1 of an IDENTITY bottleneck (K = 256 -> N = 1024 in layer3) that also delivers the backward sums of the
+ * PREVIOUS block's bn3 (round 4; autograd of `out = relu(bn3(conv3(out)) + identity)` followed by the next block's conv1,
+ * resnet.py:78-98): dx [M][N] = dy [M][K] x wpt (adjoint packed) + res where the bit of res_gate is set (the identity
+ * branch's gradient of THIS block: res = gradient of its output, res_gate = gate bits of its ReLU, [M][N/8] bytes); and
+ * partial fp32 [hiast_xconv_dgrad_gated_bn_stats_rows][N][2] = per-block (Σg, Σ g*xhat) with g = stored dx where the bit of
+ * bn_mask is set and xhat = (bn_x - save_mean) * save_invstd: what hiast_bn_nhwc_bwd_stats computes in a pass of its own
+ * over (dx, bn_x, bn_mask).  K == 256, N % 256 == 0, M >= 4096 (else rows() returns 0: use hiast_igemm_bn_act + that pass). */
+int hiast_xconv_dgrad_gated_bn_stats_rows(int64_t M, int K, int N);
+int hiast_xconv_dgrad_gated_bn_stats(const void* dy, const void* wpt, const void* res, const void* res_gate, const void* bn_x,
+                                     const void* bn_mask, const float* save_mean, const float* save_invstd, void* dx,
+                                     float* partial, int64_t M, int K, int N, int fmt, hiast_stream_t stream);
 int hiast_pack_conv_weight(const float* w, int N, int K, int taps, int fmt, int transpose, void* wp, void* wpt,
                            hiast_stream_t stream);
 int hiast_split_planes(float* x, void* planes, int64_t M, int C, int inverse, hiast_stream_t stream);

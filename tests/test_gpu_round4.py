@@ -334,3 +334,83 @@ def test_small_channel_weight_gradients_on_two_streams_do_not_share_partials(mon
     finally:
         HF._wgrad_overlap[0] = False
     assert len({k for k in K._wgrad_ws if k[0] == "small"}) >= 2      # one workspace per stream that launched them
+
+
+# ------------------------------------------------------------------------------------------------ bn3 backward sums from conv1's dgrad
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(8, 64, 128), (2, 50, 77), (1, 64, 65)])
+def test_xconv_dgrad_gated_bn_stats_vs_the_two_separate_launches(dt, shape):
+    """hiast_xconv_dgrad_gated_bn_stats (conv1's data gradient of an identity bottleneck + the backward sums of the previous
+    block's bn3 from its epilogue) against the gated data gradient (hiast_igemm_bn_act) followed by the statistics pass
+    (hiast_bn_nhwc_bwd_stats) it replaces: the gradient bit for bit (same products, same order), the sums to fp32 summation
+    order; ragged M and a tail panel"""
+    from hiast_amd import kernels as K
+    B, H, W = shape
+    dev = torch.device("cuda:0")
+    Kc, N = 256, 1024
+    M = B * H * W
+    g = torch.Generator(device="cpu").manual_seed(99)
+    dy = torch.randn(B, H, W, Kc, generator=g).to(dt).to(dev)
+    w = (torch.randn(Kc, N, 1, 1, generator=g) * (2.0 / Kc) ** 0.5).to(dev)        # conv1: N -> Kc
+    wpt = K.pack_conv_weight(w, K.fmt_of(dy), transpose=True)
+    res = torch.randn(B, H, W, N, generator=g).to(dt).to(dev)
+    gate = torch.randint(0, 256, (M, N // 8), generator=g, dtype=torch.uint8).to(dev)
+    bx = torch.randn(B, H, W, N, generator=g).to(dt).to(dev)
+    bmask = torch.randint(0, 256, (M, N // 8), generator=g, dtype=torch.uint8).to(dev)
+    sm = torch.randn(N, generator=g).to(dev) * 0.1
+    si = (torch.rand(N, generator=g) + 0.5).to(dev)
+    if not K.xconv_dgrad_gated_bn_stats_ok(M, Kc, N):
+        pytest.skip("shape below the kernel's minimum")
+    dx, partial = K.xconv_dgrad_gated_bn_stats(dy, wpt, res, gate, bx, bmask, sm, si)
+    want = K.igemm_bn_act(dy, wpt, 1, None, res, False, 1, 1, res_gate=gate)
+    assert torch.equal(dx, want)
+    sums = K.bn_nhwc_stats_from_partial(partial)
+    to_nchw = lambda t: t.permute(0, 3, 1, 2)
+    ref = K.bn_nhwc_bwd_stats(to_nchw(want), bmask, to_nchw(bx), None, None, sm, si, 3)
+    scale = ref.abs().max(dim=0).values
+    assert ((sums - ref).abs() <= 1e-5 * scale + 1e-3).all(), float((sums - ref).abs().max())
+
+
+def test_two_identity_bottlenecks_bn3_sums_from_the_next_blocks_conv1(monkeypatch):
+    """two layer3-shaped identity blocks in a row on the 16-bit training path: the first block's bn3 takes its backward sums from
+    the epilogue of the second block's conv1 data gradient (no statistics pass of its own) — against the unfused form
+    (HF._BN3_FUSION = False): same outputs, gradients up to the order of the fp32 sums; the fused path really ran"""
+    import torch.nn as nn
+    from hiast_amd import functional as HF
+    from hiast_amd import kernels as K
+    from hiast_amd.sseg.models.modules.resnet import Bottleneck
+    torch.manual_seed(21)
+    dev = torch.device("cuda:0")
+    net = nn.Sequential(Bottleneck(1024, 256, 1, 2), Bottleneck(1024, 256, 1, 2)).to(dev).train()
+    x0 = torch.randn(2, 1024, 48, 64, device=dev).half().contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(2, 1024, 48, 64, device=dev).half().contiguous(memory_format=torch.channels_last)
+    calls = {"fused": 0, "stats3": 0}
+    real_f, real_s = K.xconv_dgrad_gated_bn_stats, K.bn_nhwc_bwd_stats
+
+    def spy_f(*a, **k):
+        calls["fused"] += 1
+        return real_f(*a, **k)
+
+    def spy_s(dy, y, x, gamma, beta, sm, si, gate):
+        calls["stats3"] += int(gate == 3)
+        return real_s(dy, y, x, gamma, beta, sm, si, gate)
+    monkeypatch.setattr(K, "xconv_dgrad_gated_bn_stats", spy_f)
+    monkeypatch.setattr(K, "bn_nhwc_bwd_stats", spy_s)
+    res = {}
+    for fuse in (False, True):
+        monkeypatch.setattr(HF, "_BN3_FUSION", fuse)
+        calls["fused"] = calls["stats3"] = 0
+        net.zero_grad()
+        src = x0.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            y = net(src * 1.0)
+        y.backward(gy)
+        torch.cuda.synchronize()
+        res[fuse] = (y.detach().float(), src.grad.float(), [p.grad.clone() for p in net.parameters() if p.grad is not None])
+        assert (calls["fused"], calls["stats3"]) == ((1, 1) if fuse else (0, 2)), calls
+    a, b = res[True], res[False]
+    assert torch.equal(a[0], b[0])
+    d = (a[1] - b[1]).abs()
+    assert float(d.max()) <= 2e-2 * float(b[1].abs().max()) and float(d.mean()) <= 1e-3 * float(b[1].abs().mean())
+    for u, v in zip(a[2], b[2]):
+        assert torch.allclose(u, v, rtol=0, atol=5e-3 * float(v.abs().max()))
