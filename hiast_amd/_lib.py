@@ -54,6 +54,8 @@ SIGNATURES = {
     "hiast_conv3x3_bn_act_nhwc": (c_int, [c_vp] * 6 + [c_f32, c_int, c_vp] + [c_int] * 8 + [c_vp]),
     "hiast_bn_act_nhwc_infer": (c_int, [c_vp] * 6 + [c_f32, c_int, c_i64, c_int, c_int, c_vp]),
     "hiast_igemm_bn_act": (c_int, [c_vp] * 6 + [c_f32, c_vp, c_int, c_vp] + [c_int] * 10 + [c_vp, c_vp, c_int, c_vp]),
+    "hiast_bottleneck_tail_ok": (c_int, [c_int] * 7),
+    "hiast_bottleneck_tail": (c_int, [c_vp] * 6 + [c_f32] + [c_vp] * 5 + [c_f32, c_vp, c_vp] + [c_int] * 7 + [c_vp]),
     "hiast_igemm_stats_rows": (c_int, [c_i64, c_int, c_int, c_int, c_int]),
     "hiast_igemm_dgrad_bn_stats": (c_int, [c_vp, c_vp, c_vp] + [c_int] * 7 + [c_vp] * 6 + [c_int, c_vp]),
     "hiast_xconv_dgrad_gated_bn_stats_rows": (c_int, [c_i64, c_int, c_int]),

@@ -1036,6 +1036,39 @@ def igemm_bn_act(x, wp, planes, bn, res, relu, stride=1, dil=1, out_f32=False, w
     return (y, partial) if want_stats else y
 
 
+def bottleneck_tail_ok(x, planes, conv2, conv3):
+    """does hiast_bottleneck_tail take conv2 -> bn2 -> relu -> conv3 -> bn3 -> (+res) -> relu of this block on x?"""
+    PL = 2 if int(planes) == 2 else 1
+    B, H, W, CC = x.shape
+    if (conv2.kernel_size != (3, 3) or conv2.stride != (1, 1) or conv2.padding != conv2.dilation or conv2.groups != 1
+            or conv3.kernel_size != (1, 1) or CC != PL * conv2.in_channels or conv2.out_channels != conv2.in_channels):
+        return False
+    return bool(_lib.load().hiast_bottleneck_tail_ok(B, H, W, conv2.out_channels, conv3.out_channels, 1, fmt_of(x, PL)))
+
+
+def bottleneck_tail(x, w2p, bn2, w3p, bn3, res, planes, dil):
+    """relu(bn3(conv3(relu(bn2(conv2(x))))) + res) in one launch (K9m): x [B,H,W,planes*256], w2p / w3p from pack_conv_weight
+    ([256,9,planes*256], [Cout,1,planes*256]), bn2 / bn3 in eval mode, res like the output [B,H,W,planes*Cout]"""
+    _req16(x, 4, "x")
+    PL = 2 if int(planes) == 2 else 1
+    fmt = fmt_of(x, PL)
+    _req(w2p, x.dtype, 3, "w2p")
+    _req(w3p, x.dtype, 3, "w3p")
+    B, H, W, CC = x.shape
+    Cmid = CC // PL
+    N = w3p.shape[0]
+    assert tuple(w2p.shape) == (Cmid, 9, PL * Cmid) and tuple(w3p.shape) == (N, 1, PL * Cmid), (tuple(w2p.shape), tuple(w3p.shape))
+    _req(res, x.dtype, 4, "res")
+    assert tuple(res.shape) == (B, H, W, PL * N), (tuple(res.shape), (B, H, W, PL * N))
+    y = torch.empty((B, H, W, PL * N), dtype=x.dtype, device=x.device)
+    g2, b2, mu2, var2, eps2 = _bn_params(bn2)
+    g3, b3, mu3, var3, eps3 = _bn_params(bn3)
+    check(_lib.load().hiast_bottleneck_tail(_ptr(x), _ptr(w2p), g2, b2, mu2, var2, eps2, _ptr(w3p), g3, b3, mu3, var3, eps3,
+                                            _ptr(res), _ptr(y), B, H, W, Cmid, N, int(dil), fmt, _stream()),
+          "hiast_bottleneck_tail")
+    return y
+
+
 def igemm_dgrad_bn_stats(dy, wpt, dil, bn_x, gamma, beta, save_mean, save_invstd):
     """data gradient of a stride-1 trunk convolution whose input was A = relu(bn(bn_x)):
     dy bf16 [B,H,W,Cin'], wpt = adjoint packed weight [Cout', taps, Cin'] -> (dA bf16 [B,H,W,Cout'],

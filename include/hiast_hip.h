@@ -281,6 +281,22 @@ int hiast_igemm_bn_act(const void* x, const void* wp, const float* gamma, const 
                        int Cout, int taps, int stride, int dil, int fmt /* HIAST_FMT_*: "planes" above = 2 for SPLIT_BF16, 1 otherwise;
                        FP16: everything said of planes = 1 with fp16 rows */, int out_f32, float* stats,
                        const void* res_gate, int gate_mask, hiast_stream_t stream);
+/* ---- K9m (round 5): the tail of a bottleneck in the inference forwards as ONE launch ------------------------------------
+ *     y = relu( bn3( conv3_1x1( relu( bn2( conv2_3x3(x) ) ) ) ) + res )
+ * (Bottleneck.forward, sseg/models/modules/resnet.py:84-98, in the eval forward of IASPseudoGenerator.run,
+ * workflows/pseudo_label_generator.py:190-192, and of the EMA teacher, trainer/consistency_self_training_trainer.py:92-126.)
+ * Replaces two hiast_igemm_bn_act launches; the Cmid-channel activation between the two convolutions stays in registers
+ * (b2b.hip).  Operand formats and packed weights exactly as hiast_igemm_bn_act: x [B,H,W,planes*Cmid], w2p packed
+ * [Cmid][9][planes*Cmid] (3x3, stride 1, padding = dilation = dil), w3p packed [Cout][1][planes*Cmid], res / y
+ * [B,H,W,planes*Cout]; both BatchNorms in eval form (gamma / beta may be NULL = 1 / 0).  Same products in the same order as
+ * the two launches.  Cmid == 256, Cout % 64 == 0, Cout <= 1024, B*H*W >= 4096, every tensor < 2 GiB, 16-byte aligned:
+ * hiast_bottleneck_tail_ok() says whether the caller should take it: the shape limits above AND HIAST_B2B=1 in the
+ * environment — the launch is opt-in: bit-equal to the two launches but measured slower in the step. */
+int hiast_bottleneck_tail_ok(int B, int H, int W, int Cmid, int Cout, int stride, int fmt);
+int hiast_bottleneck_tail(const void* x, const void* w2p, const float* gamma2, const float* beta2, const float* mean2,
+                          const float* var2, float eps2, const void* w3p, const float* gamma3, const float* beta3,
+                          const float* mean3, const float* var3, float eps3, const void* res, void* y, int B, int H, int W,
+                          int Cmid, int Cout, int dil, int fmt /* HIAST_FMT_* */, hiast_stream_t stream);
 /* host: number of partial-sum rows hiast_igemm_bn_act writes into `stats` [rows][Cout][2] for M = B*Ho*Wo output pixels
  * (one row per block of the kernel chosen for the shape) */
 int hiast_igemm_stats_rows(int64_t M, int Cin, int Cout, int taps, int fmt);
