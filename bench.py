@@ -209,13 +209,17 @@ def roofline_of(key, avg_ms, n, steps):
     ach = flop / (avg_ms * 1e-3) / 1e12
     peak = 2500.0 / 3.0 if PL == 2 else 2500.0
     alg_bytes = (B * Hh * Ww * CC + Cout * taps * CC) * 2 + M * Cout * (4 if out_f32 else 2 * PL) * (2 if has_res else 1)
-    traffic = None
+    traffic = traffic_source = None
     for pmc in ("r04_pmc_igemm.json", "r03_pmc_igemm.json", "r02_pmc_igemm.json"):       # (the newest collection that has this launch shape)
-        pmc = os.path.join(ROOT, "profiles", pmc)
-        if traffic is None and os.path.exists(pmc):
-            for ent in json.load(open(pmc)).get("kernels", []):
+        path = os.path.join(ROOT, "profiles", pmc)
+        if traffic is None and os.path.exists(path):
+            for ent in json.load(open(path)).get("kernels", []):
                 if ent.get("key") == [B, Hh, Ww, Cin, Cout, taps, PL, dil]:
                     traffic = ent["hbm_bytes_per_launch"]
+                    # NOT measured in this run: PMC counters need their own rocprofv3 --pmc passes (tools/pmc_igemm.sh)
+                    traffic_source = ("profiles/%s (round %s: separate rocprofv3 --pmc passes over this launch shape, "
+                                      "(2*FETCH_SIZE + WRITE_SIZE)*1024 per dispatch; read from the file, not collected by "
+                                      "this bench run)" % (pmc, pmc[2]))
     is_xconv = (PL == 1 and taps == 1 and Cin == 256 and Cout % 512 == 0 and not out_f32 and M >= 4096
                 and os.environ.get("HIAST_XCONV", "1") != "0" and not (has_bn and has_res and not relu))
     is_xconv2 = (PL == 2 and taps == 1 and Cin == 256 and Cout % 256 == 0 and not out_f32 and M >= 4096 and has_bn
@@ -237,15 +241,19 @@ def roofline_of(key, avg_ms, n, steps):
     flavour = ("fp32-equivalent flops: the kernel issues 3 bf16 MFMA flops per algorithmic flop (hi*hi + lo*hi + hi*lo), "
                "MFMA ceiling = dense bf16 peak 2500/3 TFLOP/s" if PL == 2 else "plain bf16 MFMA, ceiling 2500 TFLOP/s dense")
     shape = "B=%d %dx%d Cin=%d Cout=%d taps=%d dil=%d" % (B, Hh, Ww, Cin, Cout, taps, dil)
+    # both conventions, side by side: issued MFMA flops (3 per algorithmic flop on split planes) and algorithmic flops, each
+    # against the plain dense 16-bit peak of 2500 TFLOP/s
+    fracs = {"frac_issued": ach * (3.0 if PL == 2 else 1.0) / 2500.0, "frac_algorithmic_vs_dense": ach / 2500.0,
+             "traffic_source": traffic_source}
     if f_hbm > f_mfma:
         return {"kernel": name, "bound": "hbm", "achieved": hbm_tbs * 1e3, "peak": 8000.0, "unit": "GB/s", "frac": f_hbm,
-                "traffic": traffic, "avg_launch_ms": avg_ms, "launches_per_step": n / steps,
+                **fracs, "traffic": traffic, "avg_launch_ms": avg_ms, "launches_per_step": n / steps,
                 "note": "algorithmic %.0f MB per launch (%s: input + weights + output%s, 16-bit%s); the MFMA side: %.1f "
                         "GFLOP -> %.0f TFLOP/s = %.0f%% of its ceiling (%s)"
                         % (alg_bytes / 1e6, shape, " + residual" if has_res else "", " hi|lo pairs" if PL == 2 else "",
                            flop / 1e9, ach, 100.0 * f_mfma, flavour)}
     return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": f_mfma,
-            "traffic": traffic, "avg_launch_ms": avg_ms, "launches_per_step": n / steps,
+            **fracs, "traffic": traffic, "avg_launch_ms": avg_ms, "launches_per_step": n / steps,
             "note": "algorithmic %.1f GFLOP per launch (%s); %s; algorithmic HBM bytes per launch %.0f MB -> %.2f TB/s = "
                     "%.0f%% of the 8 TB/s HBM roof" % (flop / 1e9, shape, flavour, alg_bytes / 1e6, hbm_tbs, 100.0 * f_hbm)}
 
@@ -279,9 +287,18 @@ class HotPath:
         from hiast_amd import functional as HF
         HF.enable_wgrad_overlap(True)       # train_step() joins the side stream before the optimiser step
         # synthetic batch, resident on the device (normalised float images: what Dataset.transform emits)
-        g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-        self.weak = torch.randn(B, 3, H, W, generator=g).to(device)
-        self.strong = (self.weak * 1.05 + 0.02).contiguous() if self.teacher else self.weak
+        # TWO seeded batches, alternating step by step (round 5): the histogram-contention-sensitive pass 1 and the clocks are
+        # not measured on one data distribution only
+        self.batches = []
+        for i in range(2):
+            g = torch.Generator(device="cpu").manual_seed(1234 + rank + 7919 * i)
+            weak = torch.randn(B, 3, H, W, generator=g)
+            if i == 1:          # a second distribution: smoother images with another contrast
+                weak = torch.nn.functional.avg_pool2d(weak, 3, 1, 1) * 2.2 + 0.1
+            weak = weak.to(device)
+            self.batches.append((weak, (weak * 1.05 + 0.02).contiguous() if self.teacher else weak))
+        self.weak, self.strong = self.batches[0]
+        self._step_no = 0
         self.thr = 0.9 * np.ones(C)
         self.class_mean_probs = np.zeros(C)
         self._hist_host = self._hist_ready = None
@@ -467,6 +484,8 @@ class HotPath:
     def step(self, marks=None):
         """marks: optional list of 5 events bracketing the four parts"""
         host = self.host_marks = [0.0] * 5       # host clock at the same points: how long the ENQUEUE of each part takes
+        self.weak, self.strong = self.batches[self._step_no % len(self.batches)]
+        self._step_no += 1
 
         def rec(i):
             host[i] = time.perf_counter()
@@ -785,6 +804,8 @@ def main():
             "loss_scale": ({"final": float(hp.scaler.get_scale()), "settle_steps_before_timing": settle,
                             "optimizer_steps_skipped_in_timed_region": skipped} if hp.scaler is not None else None),
             "data": "synthetic",
+            "data_detail": "two seeded synthetic batches per rank, alternating step by step (white noise; smoothed noise at "
+                           "another contrast), resident in HBM",
             "config": {"workload": "configs[2] self-training round (%s, region-adaptive reg on) bs=%d/GPU @1024x512 "
                                    "+ configs[1] IAS pseudo-label pass on the same batch" % (args.trainer, args.batch),
                        "images_per_gpu_per_step": args.batch, "num_classes": C,
@@ -814,8 +835,9 @@ def main():
             key, avg_ms, n, _tot = groups[0]            # dominant hand-written launch group of the step
             out["roofline"] = roofline_of(key, avg_ms, n, sampled)
             others = [roofline_of(k, a, c, sampled) for k, a, c, _ in groups[1:4] + wg[:1] + aspp[:2]]
-            out["roofline_other"] = [{kk: o[kk] for kk in ("kernel", "bound", "achieved", "peak", "unit", "frac",
-                                                            "traffic", "avg_launch_ms", "launches_per_step", "note")}
+            out["roofline_other"] = [{kk: o[kk] for kk in ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_issued",
+                                                            "frac_algorithmic_vs_dense", "traffic", "traffic_source",
+                                                            "avg_launch_ms", "launches_per_step", "note") if kk in o}
                                      for o in others]
         if not args.no_cpu_baseline and world == 1:
             try:

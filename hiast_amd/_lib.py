@@ -50,8 +50,6 @@ SIGNATURES = {
     "hiast_bn_act_bwd_stats": (c_int, [c_vp] * 5 + [c_int, c_int, c_int, c_i64, c_int, c_vp, c_vp]),
     "hiast_bn_act_bwd_apply": (c_int, [c_vp] * 7 + [c_int, ctypes.c_double, c_int, c_vp, c_vp, c_vp, c_vp,
                                        c_int, c_int, c_i64, c_int, c_vp]),
-    "hiast_conv1x1_bn_act_nhwc": (c_int, [c_vp] * 6 + [c_f32, c_vp, c_int, c_vp, c_i64, c_int, c_int, c_int, c_vp]),
-    "hiast_conv3x3_bn_act_nhwc": (c_int, [c_vp] * 6 + [c_f32, c_int, c_vp] + [c_int] * 8 + [c_vp]),
     "hiast_bn_act_nhwc_infer": (c_int, [c_vp] * 6 + [c_f32, c_int, c_i64, c_int, c_int, c_vp]),
     "hiast_igemm_bn_act": (c_int, [c_vp] * 6 + [c_f32, c_vp, c_int, c_vp] + [c_int] * 10 + [c_vp, c_vp, c_int, c_vp]),
     "hiast_bottleneck_tail_ok": (c_int, [c_int] * 7),

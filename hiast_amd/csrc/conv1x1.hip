@@ -416,75 +416,37 @@ __global__ __launch_bounds__(256) void bn_act_nhwc_bf16_kernel(const unsigned sh
 
 }  // namespace hiast
 
+// Since round 5 the only caller of the register-staged kernel is the plain GEMM below (the fp32-row form of the ASPP tap GEMM,
+// hiast_aspp2_fwd): the round-1 C-ABI entries hiast_conv1x1_bn_act_nhwc / hiast_conv3x3_bn_act_nhwc had no product caller left
+// (every trunk convolution runs on hiast_igemm_bn_act) and were removed from the ABI; the BN / residual / ReLU / 3x3 variants of
+// the kernel template are no longer instantiated.
 template <typename TA, typename TO>
-static int launch_conv_t(const void* x, const float* w, const float* gamma, const float* beta, const float* mean,
-                         const float* var, float eps, const void* res, int relu, void* y, int64_t M, int K, int N,
-                         int taps, hiast::ConvGeo geo, hipStream_t st)
+static int launch_gemm_t(const void* x, const float* w, void* y, int64_t M, int K, int N, hipStream_t st)
 {
     const int BN = (N % 128 == 0) ? 128 : 64;
     dim3 grid((unsigned)((M + hiast::C1_BM - 1) / hiast::C1_BM), N / BN);
-#define L(BNV, T, RES, RELU)                                                                                       \
-    hipLaunchKernelGGL((hiast::conv1x1_bn_act_kernel<TA, TO, BNV, T, RES, RELU>), grid, dim3(256), 0, st,          \
-                       (const TA*)x, w, gamma, beta, mean, var, eps, (const TO*)res, (TO*)y, (int)M, K, N, geo)
-#define LL(BNV, T)                                                              \
-    if (res) { if (relu) L(BNV, T, true, true); else L(BNV, T, true, false); }  \
-    else { if (relu) L(BNV, T, false, true); else L(BNV, T, false, false); }
-    if (taps == 1) { if (BN == 128) { LL(128, 1) } else { LL(64, 1) } }
-    else { if (BN == 128) { LL(128, 9) } else { LL(64, 9) } }
-#undef LL
+    const hiast::ConvGeo geo = {0, 0, 0, 0, 1, 1};
+#define L(BNV)                                                                                                     \
+    hipLaunchKernelGGL((hiast::conv1x1_bn_act_kernel<TA, TO, BNV, 1, false, false>), grid, dim3(256), 0, st,       \
+                       (const TA*)x, w, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,       \
+                       (const float*)nullptr, 0.f, (const TO*)nullptr, (TO*)y, (int)M, K, N, geo)
+    if (BN == 128) L(128); else L(64);
 #undef L
     HIAST_CHECK_LAUNCH();
     return 0;
-}
-
-static int launch_conv(const void* x, const float* w, const float* gamma, const float* beta, const float* mean,
-                       const float* var, float eps, const void* res, int relu, void* y, int64_t M, int K, int N,
-                       int taps, hiast::ConvGeo geo, int dtype, hipStream_t st)
-{
-    if (!x || !w || !y || (mean && !var)) return HIAST_E_ARG;
-    if (M <= 0 || K <= 0 || N <= 0) return HIAST_E_ARG;
-    if (K % hiast::C1_BK != 0 || N % 64 != 0 || M > (1ll << 31) - 256 || dtype < 0 || dtype > 2) return HIAST_E_RANGE;
-    if ((((uintptr_t)x) | ((uintptr_t)w) | ((uintptr_t)y) | ((uintptr_t)res)) & 15) return HIAST_E_RANGE;
-    if (taps != 1) {   // buffer-descriptor addressing of the 3x3 input: byte offsets and the out-of-range marker need 31 bits
-        const size_t in_pix = (size_t)(M / ((size_t)geo.Ho * geo.Wo)) * geo.H * geo.W;
-        if (in_pix * K * (dtype ? 2 : 4) >= (1ull << 31)) return HIAST_E_RANGE;
-    }
-    if (dtype == 0)
-        return launch_conv_t<float, float>(x, w, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, st);
-    if (dtype == 2)
-        return launch_conv_t<__hip_bfloat16, float>(x, w, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps,
-                                                    geo, st);
-    return launch_conv_t<__hip_bfloat16, __hip_bfloat16>(x, w, gamma, beta, mean, var, eps, res, relu, y, M, K, N,
-                                                         taps, geo, st);
 }
 
 // plain GEMM entry for other translation units (aspp2.hip): Y[M][N] = X[M][K] * W[N][K]^T, no BN / residual / ReLU.
 // dtype: 0 = fp32 in (split-bf16 arithmetic) / fp32 out, 1 = bf16 in / bf16 out, 2 = bf16 in / fp32 out.
 int hiast_gemm_nt_launch(const void* x, const float* w, void* y, int64_t M, int K, int N, int dtype, hipStream_t st)
 {
-    hiast::ConvGeo geo = {0, 0, 0, 0, 1, 1};
-    return launch_conv(x, w, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, 0, y, M, K, N, 1, geo, dtype, st);
-}
-
-extern "C" int hiast_conv1x1_bn_act_nhwc(const void* x, const float* w, const float* gamma, const float* beta,
-                                         const float* mean, const float* var, float eps, const void* res,
-                                         int relu, void* y, int64_t M, int K, int N, int dtype,
-                                         hiast_stream_t stream)
-{
-    hiast::ConvGeo geo = {0, 0, 0, 0, 1, 1};
-    return launch_conv(x, w, gamma, beta, mean, var, eps, res, relu, y, M, K, N, 1, geo, dtype, (hipStream_t)stream);
-}
-
-extern "C" int hiast_conv3x3_bn_act_nhwc(const void* x, const float* w, const float* gamma, const float* beta,
-                                         const float* mean, const float* var, float eps, int relu, void* y,
-                                         int B, int H, int W, int Cin, int Cout, int stride, int dil, int dtype,
-                                         hiast_stream_t stream)
-{
-    if (B <= 0 || H <= 0 || W <= 0 || stride <= 0 || dil <= 0) return HIAST_E_ARG;
-    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
-    hiast::ConvGeo geo = {H, W, Ho, Wo, stride, dil};
-    return launch_conv(x, w, gamma, beta, mean, var, eps, nullptr, relu, y, (int64_t)B * Ho * Wo, Cin, Cout, 9, geo,
-                       dtype, (hipStream_t)stream);
+    if (!x || !w || !y) return HIAST_E_ARG;
+    if (M <= 0 || K <= 0 || N <= 0) return HIAST_E_ARG;
+    if (K % hiast::C1_BK != 0 || N % 64 != 0 || M > (1ll << 31) - 256 || dtype < 0 || dtype > 2) return HIAST_E_RANGE;
+    if ((((uintptr_t)x) | ((uintptr_t)w) | ((uintptr_t)y)) & 15) return HIAST_E_RANGE;
+    if (dtype == 0) return launch_gemm_t<float, float>(x, w, y, M, K, N, st);
+    if (dtype == 2) return launch_gemm_t<__hip_bfloat16, float>(x, w, y, M, K, N, st);
+    return launch_gemm_t<__hip_bfloat16, __hip_bfloat16>(x, w, y, M, K, N, st);
 }
 
 extern "C" int hiast_bn_act_nhwc_infer(const void* x, void* y, const float* gamma, const float* beta,

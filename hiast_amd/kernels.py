@@ -713,45 +713,6 @@ def _bn_params(bn):
     return (_ptr(bn.weight), _ptr(bn.bias), _ptr(bn.running_mean), _ptr(bn.running_var), float(bn.eps))
 
 
-def conv1x1_bn_act_nhwc(x2d, weight, bn, res2d=None, relu=True):
-    """x2d [M,K] fp32|bf16 (NHWC activations flattened), weight [N,K,1,1] or [N,K] fp32, bn: a BatchNorm2d in
-    eval mode (running statistics) -> y [M,N] of x2d's dtype."""
-    dt = _act_dtype(x2d)
-    _req(x2d, x2d.dtype, 2, "x2d")
-    M, K_ = x2d.shape
-    w = weight.reshape(weight.shape[0], -1)
-    _req(w, torch.float32, 2, "weight")
-    N = w.shape[0]
-    assert w.shape[1] == K_
-    if res2d is not None:
-        _req(res2d, x2d.dtype, 2, "res2d")
-        assert tuple(res2d.shape) == (M, N)
-    y = torch.empty((M, N), dtype=x2d.dtype, device=x2d.device)
-    g, b, mu, var, eps = _bn_params(bn)
-    check(_lib.load().hiast_conv1x1_bn_act_nhwc(_ptr(x2d), _ptr(w), g, b, mu, var, eps, _ptr(res2d),
-                                                int(bool(relu)), _ptr(y), M, K_, N, dt, _stream()),
-          "hiast_conv1x1_bn_act_nhwc")
-    return y
-
-
-def conv3x3_bn_act_nhwc(x_nhwc, weight, bn, stride, dil, relu=True):
-    """x_nhwc [B,H,W,Cin] fp32|bf16 contiguous; weight [Cout,Cin,3,3] fp32 (torch layout; repacked here to
-    [Cout,3,3,Cin]); -> y [B,Ho,Wo,Cout] of x's dtype"""
-    dt = _act_dtype(x_nhwc)
-    _req(x_nhwc, x_nhwc.dtype, 4, "x_nhwc")
-    B, H, W, Cin = x_nhwc.shape
-    Cout = weight.shape[0]
-    assert tuple(weight.shape) == (Cout, Cin, 3, 3) and weight.dtype == torch.float32
-    wp = weight.detach().permute(0, 2, 3, 1).contiguous()
-    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
-    y = torch.empty((B, Ho, Wo, Cout), dtype=x_nhwc.dtype, device=x_nhwc.device)
-    g, b, mu, var, eps = _bn_params(bn)
-    check(_lib.load().hiast_conv3x3_bn_act_nhwc(_ptr(x_nhwc), _ptr(wp), g, b, mu, var, eps, int(bool(relu)), _ptr(y),
-                                                B, H, W, Cin, Cout, int(stride), int(dil), dt, _stream()),
-          "hiast_conv3x3_bn_act_nhwc")
-    return y
-
-
 def bn_act_nhwc_infer(x2d, bn, relu=True):
     dt = _act_dtype(x2d)
     _req(x2d, x2d.dtype, 2, "x2d")

@@ -228,31 +228,12 @@ int hiast_bn_act_bwd_apply(const void* dy, const void* y, const void* x, const f
                            double count, int relu, void* dx, void* dres, float* dgamma, float* dbeta, int B,
                            int C, int64_t HW, int dtype, hiast_stream_t stream);
 
-/* ---- K9: trunk convolutions of the inference forwards, fused with BN(eval) + residual + ReLU ---------
- * conv1 -> bn1 -> relu, conv2 -> bn2 -> relu and conv3 -> bn3 -> (+= identity) -> relu of Bottleneck.forward,
- * sseg/models/modules/resnet.py:78-98 (separate cuDNN / ATen passes there), each as ONE kernel on
- * channels-last (NHWC) activations:
- *   y[m][n] = act((Σ_k x[m][k]*w[n][k]) * gamma_n/sqrt(var_n+eps) + (beta_n - mean_n*...) (+ res[m][n]))
- * dtype 0: fp32 activations, "split-bf16" arithmetic (hi*hi + hi*lo + lo*hi on bf16 MFMA, fp32 accumulate):
- *          ~5e-6 of max|y| vs fp64, i.e. fp32-class results at 3/16 of the fp32-MFMA cost — the
- *          pseudo-label forward (the reference runs it in fp32, workflows/pseudo_label_generator.py:190-191);
- * dtype 1: bf16 activations in/out, plain bf16 MFMA — the EMA-teacher forward under mixed precision
- *          (workflows/trainer/consistency_self_training_trainer.py:113-116 under apex O1).
- * Weights stay fp32 master copies: w [N = Cout][K] (1x1: the conv weight as stored; 3x3: permuted (0,2,3,1) to
- * [Cout][3][3][Cin]).  x [M = B*H*W][K = Cin]; 3x3: padding = dilation, stride 1 or 2, Ho = (H-1)/stride + 1.
- * dtype 2 (1x1 only): bf16 activations in, fp32 out/residual.  mean == NULL: no BatchNorm (a plain GEMM).
- * Cin % 32 == 0, Cout % 64 == 0, 16-byte aligned buffers.
- * hiast_bn_act_nhwc_infer: y[m][c] = act(x[m][c]*scale_c + shift_c) for the stem (library 7x7 conv) output.
- * STATUS (round 4): hiast_conv1x1_bn_act_nhwc / hiast_conv3x3_bn_act_nhwc are the round-1 register-staged forms, superseded on
- * every hot path by hiast_igemm_bn_act (K9c).  They stay in the ABI as the entry for fp32 / row-major NHWC callers (no packed
- * weights, no operand format) and are exercised by tests/test_gpu_kernels.py and tools/ only; the same translation unit also
- * holds the fp32-input GEMM behind hiast_aspp2_fwd's fp32 rows and hiast_bn_act_nhwc_infer (inference stem fallback). */
-int hiast_conv1x1_bn_act_nhwc(const void* x, const float* w, const float* gamma, const float* beta,
-                              const float* mean, const float* var, float eps, const void* res, int relu,
-                              void* y, int64_t M, int K, int N, int dtype, hiast_stream_t stream);
-int hiast_conv3x3_bn_act_nhwc(const void* x, const float* w, const float* gamma, const float* beta,
-                              const float* mean, const float* var, float eps, int relu, void* y, int B, int H,
-                              int W, int Cin, int Cout, int stride, int dil, int dtype, hiast_stream_t stream);
+/* ---- K9 (round 1): BN(eval) (+ ReLU) on channels-last rows ------------------------------------------------------------
+ * hiast_bn_act_nhwc_infer: y[m][c] = act(x[m][c]*scale_c + shift_c) behind the library 7x7 stem of the inference forwards
+ * (sseg/models/modules/resnet.py:177-184) when the fused stem kernels do not apply.  dtype 0: fp32 rows, 1: bf16 rows.
+ * (Round 5: the round-1 convolution entries this block used to declare, hiast_conv1x1_bn_act_nhwc / hiast_conv3x3_bn_act_nhwc,
+ * had no product caller since hiast_igemm_bn_act (K9c) took every trunk convolution and were REMOVED from the ABI; their
+ * translation unit keeps the fp32-row GEMM behind hiast_aspp2_fwd.) */
 int hiast_bn_act_nhwc_infer(const void* x, void* y, const float* gamma, const float* beta, const float* mean,
                             const float* var, float eps, int relu, int64_t M, int C, int dtype,
                             hiast_stream_t stream);

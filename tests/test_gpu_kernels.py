@@ -1050,32 +1050,6 @@ def test_trunk_fused_matches_plain_modules(K):
     assert err < 2e-3, float(err)
 
 
-@pytest.mark.parametrize("shape", [(4096, 256, 64), (1000, 64, 256), (8192, 1024, 256), (300, 2048, 512)])
-@pytest.mark.parametrize("res,relu", [(False, True), (True, True), (False, False)])
-def test_conv1x1_split_bf16_vs_fp64(K, shape, res, relu):
-    """fused 1x1 conv + BN(eval) + residual + ReLU (split-bf16 MFMA) vs float64: <= 3e-5 of max|y|
-    (fp32-class; the contract for logits is 1e-3)."""
-    M, Kd, N = shape
-    x = synth.normal_f32(201, (M, Kd), 1.0)
-    w = synth.normal_f32(202, (N, Kd), (2.0 / Kd) ** 0.5)
-    r = synth.normal_f32(203, (M, N), 1.0) if res else None
-    bn = torch.nn.BatchNorm2d(N).cuda().eval()
-    with torch.no_grad():
-        bn.weight.copy_(torch.from_numpy(1 + synth.normal_f32(204, (N,), 0.2)))
-        bn.bias.copy_(torch.from_numpy(synth.normal_f32(205, (N,), 0.2)))
-        bn.running_mean.copy_(torch.from_numpy(synth.normal_f32(206, (N,), 0.3)))
-        bn.running_var.copy_(torch.from_numpy(0.5 + synth.rng(207).random(N, dtype=np.float32)))
-    y = K.conv1x1_bn_act_nhwc(dev(x), dev(w), bn, dev(r) if res else None, relu).cpu().double()
-    sc = bn.weight.double().cpu() / torch.sqrt(bn.running_var.double().cpu() + bn.eps)
-    sh = bn.bias.double().cpu() - bn.running_mean.double().cpu() * sc
-    want = (torch.from_numpy(x).double() @ torch.from_numpy(w).double().t()) * sc + sh
-    if res:
-        want = want + torch.from_numpy(r).double()
-    if relu:
-        want = torch.relu(want)
-    assert (y - want).abs().max() <= 3e-5 * want.abs().max()
-
-
 def test_bn_act_nhwc_infer(K):
     M, C = 1234, 64
     x = synth.normal_f32(211, (M, C), 2.0)
@@ -1087,60 +1061,6 @@ def test_bn_act_nhwc_infer(K):
     y = K.bn_act_nhwc_infer(dev(x), bn, True)
     want = torch.relu(bn(dev(x).t().reshape(1, C, M, 1))).reshape(C, M).t()
     assert torch.allclose(y, want, rtol=1e-5, atol=1e-5)
-
-
-@pytest.mark.parametrize("cfg", [(2, 17, 23, 64, 64, 1, 1), (1, 16, 32, 256, 256, 1, 2), (1, 13, 9, 128, 128, 2, 1),
-                                 (2, 8, 16, 512, 512, 1, 4), (1, 33, 65, 32, 64, 1, 2)])
-def test_conv3x3_split_bf16_vs_fp64(K, cfg):
-    """fused 3x3 (dilated / strided) conv + BN(eval) + ReLU on channels-last fp32 vs float64 F.conv2d"""
-    B, H, W, Cin, Cout, stride, dil = cfg
-    x = synth.normal_f32(221, (B, Cin, H, W), 1.0)
-    w = synth.normal_f32(222, (Cout, Cin, 3, 3), (2.0 / (9 * Cin)) ** 0.5)
-    bn = torch.nn.BatchNorm2d(Cout).cuda().eval()
-    with torch.no_grad():
-        bn.weight.copy_(torch.from_numpy(1 + synth.normal_f32(224, (Cout,), 0.2)))
-        bn.bias.copy_(torch.from_numpy(synth.normal_f32(225, (Cout,), 0.2)))
-        bn.running_mean.copy_(torch.from_numpy(synth.normal_f32(226, (Cout,), 0.3)))
-        bn.running_var.copy_(torch.from_numpy(0.5 + synth.rng(227).random(Cout, dtype=np.float32)))
-    xn = dev(x).permute(0, 2, 3, 1).contiguous()
-    y = K.conv3x3_bn_act_nhwc(xn, dev(w), bn, stride, dil, True).permute(0, 3, 1, 2).cpu().double()
-    ref = torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), None, stride, dil, dil)
-    sc = bn.weight.double().cpu() / torch.sqrt(bn.running_var.double().cpu() + bn.eps)
-    sh = bn.bias.double().cpu() - bn.running_mean.double().cpu() * sc
-    ref = torch.relu(ref * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
-    assert y.shape == ref.shape
-    assert (y - ref).abs().max() <= 3e-5 * ref.abs().max()
-
-
-@pytest.mark.parametrize("shape", [(4096, 256, 64), (1000, 64, 256), (8192, 1024, 256)])
-def test_conv1x1_bf16_vs_fp64(K, shape):
-    """bf16-activation flavour (teacher forward): bf16 inputs, fp32 accumulate, bf16 output"""
-    M, Kd, N = shape
-    x = torch.from_numpy(synth.normal_f32(231, (M, Kd), 1.0)).cuda().bfloat16()
-    w = synth.normal_f32(232, (N, Kd), (2.0 / Kd) ** 0.5)
-    r = torch.from_numpy(synth.normal_f32(233, (M, N), 1.0)).cuda().bfloat16()
-    bn = torch.nn.BatchNorm2d(N).cuda().eval()
-    with torch.no_grad():
-        bn.running_var.copy_(torch.from_numpy(0.5 + synth.rng(237).random(N, dtype=np.float32)))
-        bn.running_mean.copy_(torch.from_numpy(synth.normal_f32(236, (N,), 0.3)))
-    y = K.conv1x1_bn_act_nhwc(x, dev(w), bn, r, True)
-    assert y.dtype == torch.bfloat16
-    sc = bn.weight.double().cpu() / torch.sqrt(bn.running_var.double().cpu() + bn.eps)
-    sh = bn.bias.double().cpu() - bn.running_mean.double().cpu() * sc
-    wb = torch.from_numpy(w).bfloat16().double()
-    want = torch.relu((x.double().cpu() @ wb.t()) * sc + sh + r.double().cpu())
-    assert (y.double().cpu() - want).abs().max() <= 1.2e-2 * want.abs().max()     # bf16 output rounding
-
-
-def test_conv3x3_bf16_vs_fp64(K):
-    B, H, W, Cin, Cout, stride, dil = 1, 16, 32, 256, 256, 1, 2
-    x = torch.from_numpy(synth.normal_f32(241, (B, Cin, H, W), 1.0)).cuda().bfloat16()
-    w = synth.normal_f32(242, (Cout, Cin, 3, 3), (2.0 / (9 * Cin)) ** 0.5)
-    bn = torch.nn.BatchNorm2d(Cout).cuda().eval()
-    y = K.conv3x3_bn_act_nhwc(x.permute(0, 2, 3, 1).contiguous(), dev(w), bn, stride, dil, True)
-    ref = torch.nn.functional.conv2d(x.double().cpu(), torch.from_numpy(w).bfloat16().double(), None, stride, dil, dil)
-    ref = torch.relu(ref / (1 + bn.eps) ** 0.5)
-    assert (y.permute(0, 3, 1, 2).double().cpu() - ref).abs().max() <= 1.2e-2 * ref.abs().max()
 
 
 def test_teacher_bf16_fast_path_close_to_library_path(K):

@@ -88,16 +88,6 @@ def main():
                 res = torch.randn(Bn, Hh, Ww, PL * Cout_, device=dev).bfloat16() if has_res else None
                 med, best = timeit(lambda: K.igemm_bn_act(xp, wp, PL, bn, res, True, 1, dl), n=20, warm=5)
                 row += " PL%d %7.3f ms %6.0f TF/s(alg) |" % (PL, med, gf / med)
-            # the earlier register-staged kernels on fp32 / bf16 channels-last activations
-            for dt in (torch.float32, torch.bfloat16):
-                xx = x32.to(dt)
-                if taps == 1:
-                    r2 = torch.randn(Bn * Hh * Ww, Cout_, device=dev).to(dt) if has_res else None
-                    fn = lambda: K.conv1x1_bn_act_nhwc(xx.view(-1, Cin_), wt_, bn, r2, True)
-                else:
-                    fn = lambda: K.conv3x3_bn_act_nhwc(xx, wt_, bn, 1, dl, True)
-                med, best = timeit(fn, n=20, warm=5)
-                row += " old %s %7.3f ms |" % ("f32" if dt == torch.float32 else "bf16", med)
             # library: torch conv2d bf16 (MIOpen), NCHW
             xn = x32.permute(0, 3, 1, 2).contiguous().bfloat16()
             wb = wt_.bfloat16()
@@ -185,25 +175,3 @@ def main():
 
 if __name__ == "__main__":
     main()
-
-
-def bench_conv1x1():
-    import torch
-    dev = torch.device("cuda")
-    for (M, Kd, N, res) in [(65536, 1024, 256, False), (65536, 256, 1024, True), (65536, 2048, 512, False),
-                            (65536, 512, 2048, True), (262144, 256, 64, False), (262144, 64, 256, True),
-                            (65536, 512, 128, False), (65536, 128, 512, True)]:
-        x = torch.randn(M, Kd, device=dev)
-        w = torch.randn(N, Kd, device=dev) * 0.05
-        r = torch.randn(M, N, device=dev) if res else None
-        bn = torch.nn.BatchNorm2d(N).to(dev).eval()
-        med, best = timeit(lambda: K.conv1x1_bn_act_nhwc(x, w, bn, r, True))
-        fl = 2.0 * M * Kd * N / 1e9
-        byt = (M * Kd + M * N * (2 if res else 1) + N * Kd) * 4 / 1e9
-        f32 = timeit(lambda: torch.mm(x, w.t()))[0]
-        print("conv1x1 M%d K%d N%d res=%d: %7.3f ms  %6.1f TF/s fp32-equiv (%.0f TF/s bf16 MFMA)  %5.2f TB/s | torch.mm fp32 %7.3f ms"
-              % (M, Kd, N, res, med, fl / med, 3 * fl / med, byt / med, f32))
-
-
-if __name__ == "__main__" and len(sys.argv) > 2 and "conv1x1" in sys.argv[2]:
-    bench_conv1x1()
