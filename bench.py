@@ -342,7 +342,7 @@ class HotPath:
     def _allreduce(self, t):
         if self.world > 1:      # histogram / class sums of the pseudo-label pass: auxiliary communicator (utils/comm.py)
             from hiast_amd.utils import comm
-            dist.all_reduce(t, group=comm.aux_group())
+            comm.all_reduce(t, "aux")
         return t
 
     # One step = the pseudo-label pass and the training step on the same batch.  Both are split at the point where the
@@ -731,6 +731,8 @@ def main():
         torch.cuda.synchronize()
     marker()
     timer.on = True
+    from hiast_amd.utils import comm as _comm
+    coll_before = dict(_comm.COUNTS)
     # phases are timed with HIP events on the launch stream: no host synchronisation inside the timed region (the only
     # blocking point is the histogram read-back the IAS threshold update needs), so consecutive steps pipeline
     marks, host_parts = [], []
@@ -749,6 +751,19 @@ def main():
             host_parts.append([1e3 * (hp.host_marks[i + 1] - hp.host_marks[i]) for i in range(4)])
     sync()
     elapsed = time.perf_counter() - t0
+    # collectives issued per step and communicator inside the timed region (host-side counters; the reducer's own bucket count)
+    collectives = None
+    if world > 1:
+        collectives = {"syncbn_stat_all_reduces": (_comm.COUNTS["stat"] - coll_before["stat"]) / float(args.steps),
+                       "pseudo_label_aux_all_reduces": (_comm.COUNTS["aux"] - coll_before["aux"]) / float(args.steps),
+                       "gradient_buckets": None,
+                       "expected": {"syncbn_stat_all_reduces": 2 * sum(1 for m in hp.model.modules()
+                                                                       if isinstance(m, torch.nn.SyncBatchNorm)),
+                                    "pseudo_label_aux_all_reduces": 3}}
+        try:
+            collectives["gradient_buckets"] = int(hp.model._get_ddp_logging_data().get("num_buckets_reduced"))
+        except Exception:
+            pass
     # phase split from the FIRST timed step only: it runs every part on the main stream (see above); in the other steps
     # the pseudo-label forward runs beside the training forwards and the marks of the main stream do not separate them
     ser = marks[:1]
@@ -817,7 +832,7 @@ def main():
                                   "events); the other steps overlap the parts on four streams"},
             # host time spent ENQUEUING each part (steps without per-launch events; the third entry includes the wait
             # for the histogram): the sum must stay below ms_per_step or the step is launch-bound
-            "final_losses": final_losses, "ranks_agree": ranks_agree,
+            "final_losses": final_losses, "ranks_agree": ranks_agree, "collectives_per_step": collectives,
             "step_boundary_gap_ms": ({"mean": float(np.mean(gaps)), "max": float(np.max(gaps)), "steps": len(gaps),
                                       "note": "HIP events on the main stream behind the last launch of a step and in front "
                                               "of the first launch of the next (unprofiled run)"} if gaps else None),

@@ -9,6 +9,7 @@ import os
 import torch
 
 from . import kernels as K
+from . import switches as SW
 
 ASPP_DILATIONS = (6, 12, 18, 24)
 H16 = (torch.bfloat16, torch.float16)       # the two 16-bit types of the mixed-precision path (K.FMT_BF16 / K.FMT_FP16):
@@ -192,9 +193,8 @@ def _stat_all_reduce(t, async_op=False):
     """SyncBN exchange: sum of the per-rank statistics, on the communicator reserved for it (utils/comm.py: these
     [C,2] reduces sit between two kernels of the main stream and must not queue behind DDP's 32 MB gradient buckets or
     the pseudo-label histogram on the default communicator).  async_op: -> the work handle (the caller waits)"""
-    import torch.distributed as dist
     from hiast_amd.utils import comm
-    return dist.all_reduce(t, group=comm.stat_group(), async_op=async_op)
+    return comm.all_reduce(t, "stat", async_op=async_op)
 
 
 class _BnActFn(torch.autograd.Function):
@@ -255,7 +255,7 @@ class _BnActNhwcFn(torch.autograd.Function):
         # ReLU gate of the backward: recomputed from x when there is no residual input; with a residual the forward
         # writes a bit mask (1/16 of y's bytes) that both backward passes (and the identity hand-off) read instead of y
         ctx.gate = 0 if not relu else (3 if res is not None else 2)
-        if ctx.gate == 3 and os.environ.get("HIAST_NO_BN_MASK", "0") == "1":
+        if ctx.gate == 3 and SW.on("HIAST_NO_BN_MASK"):
             ctx.gate = 1                                # A/B switch: gate read from y itself
         want_mask = ctx.gate == 3
         if world == 1 and partial is not None:      # no all-reduce point: statistics + apply straight from the partials
@@ -349,10 +349,18 @@ class _ConvNhwcFn(torch.autograd.Function):
         # instead of returning it, the other ('take') adds it in the epilogue of its own data-gradient launch: x receives
         # ONE gradient and autograd's add kernel over the block input (33 - 134 MB, three per step) is not launched.
         ctx.xsum = xsum if (xsum is not None and stride == 1 and ctx.needs_input_grad[0]) else None
+        if ctx.xsum is not None:
+            # the 'take' convolution (the downsample: its forward runs first) announces itself; 'give' hands its gradient over only
+            # to a taker that exists — if the downsample leg took another path (e.g. its BatchNorm in eval mode while bn1 trains)
+            # nothing would ever pop the gradient and conv1's input gradient would be dropped silently
+            if ctx.xsum[1] == "take":
+                ctx.xsum[0]["taker"] = True
+            elif not ctx.xsum[0].get("taker"):
+                ctx.xsum = None
         # in_bn: x = relu(bn(x0)) of a BatchNorm that registered itself there (and has no other consumer): the data
         # gradient of this convolution then also delivers that BatchNorm's backward sums (hiast_igemm_dgrad_bn_stats)
         ctx.in_bn = in_bn if (in_bn is not None and "bn" in in_bn and stride == 1 and ctx.needs_input_grad[0]
-                              and os.environ.get("HIAST_NO_BN_BWD_FUSION", "0") != "1") else None
+                              and not SW.on("HIAST_NO_BN_BWD_FUSION")) else None
         ctx.set_materialize_grads(False)     # no zero tensor for the (non-differentiable) statistics output
         ctx.wpt = None
         ctx.box = None
@@ -435,9 +443,9 @@ class _ConvNhwcFn(torch.autograd.Function):
         if ctx.xsum is not None and ctx.xsum[1] == "give" and dx is not None and not ctx.xsum[0].get("taken"):
             ctx.xsum[0]["dx"] = dx             # the downsample convolution's backward (it runs after this one) adds it
             dx = None
-        own_w = need_w and os.environ.get("HIAST_LIB_WGRAD", "0") != "1" and K.conv_wgrad_preferred(
+        own_w = need_w and not SW.on("HIAST_LIB_WGRAD") and K.conv_wgrad_preferred(
             weight.shape[1], weight.shape[0], k, stride) and (k == 1 or dy.shape[3] >= 4)
-        small_w = need_w and not own_w and os.environ.get("HIAST_LIB_WGRAD", "0") != "1" and K.conv_wgrad_small_supported(
+        small_w = need_w and not own_w and not SW.on("HIAST_LIB_WGRAD") and K.conv_wgrad_small_supported(
             weight.shape[1], weight.shape[0], k, stride)
         # The weight gradient is off the critical path of the backward pass (nothing but the optimiser consumes it)
         # and MFMA-bound, while the BatchNorm backward passes that follow on the main stream are HBM-bound: in a
@@ -540,8 +548,8 @@ class _WGroupFn(torch.autograd.Function):
 def wgroup_weights(convs, x):
     """-> (group dict, [weight views]) when the weight gradients of `convs` (the convolutions of one bottleneck) can be
     computed by one grouped launch on the training path of x, else (None, None)"""
-    if (len(convs) < 2 or len(convs) > 4 or os.environ.get("HIAST_NO_WGROUP", "0") == "1"
-            or os.environ.get("HIAST_LIB_WGRAD", "0") == "1" or not torch.is_grad_enabled()):
+    if (len(convs) < 2 or len(convs) > 4 or SW.on("HIAST_NO_WGROUP")
+            or SW.on("HIAST_LIB_WGRAD") or not torch.is_grad_enabled()):
         return None, None
     for c in convs:
         k = c.kernel_size[0]

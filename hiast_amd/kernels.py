@@ -9,6 +9,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from . import switches as _SW
 from ._lib import NBINS, check
 
 
@@ -795,10 +796,16 @@ def stem_eval(x, weight, bn, fmt):
 
 def stem_train_supported(conv):
     """the module hiast_stem_train_fwd / hiast_stem_wgrad replace: Conv2d(3, 64, 7, 2, 3, bias=False)"""
-    import os
-    return (os.environ.get("HIAST_LIB_STEM", "0") != "1"
+    return (not _SW.on("HIAST_LIB_STEM")
             and (conv.in_channels, conv.out_channels, conv.kernel_size, conv.stride, conv.padding, conv.dilation, conv.groups)
             == (3, 64, (7, 7), (2, 2), (3, 3), (1, 1), 1) and conv.bias is None)
+
+
+def stem_train_shape_ok(x):
+    """the K9k stem kernels take this batch (their 31-bit addressing: B*Hc*Wc*64 and B*3*H*W below 2^31) — otherwise the caller
+    keeps the library stem (the image gradient, which K9k never computes, is the caller's other reason to)"""
+    B, _, H, W = x.shape
+    return x.dtype == torch.float32 and _lib.load().hiast_stem_train_blocks(int(B), int(H), int(W)) > 0
 
 
 def stem_train_fwd(x, weight, fmt):

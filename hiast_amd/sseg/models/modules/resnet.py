@@ -90,14 +90,14 @@ class Bottleneck(nn.Module):
         # gradients become one (HF._ConvNhwcFn xsum: conv1 hands its gradient to the downsample's data-gradient epilogue)
         xs = None
         if (self.downsample is not None and self.downsample[0].stride == (1, 1) and x.is_cuda and x.dtype in HF.H16
-                and self.bn1.training and x.requires_grad and os.environ.get("HIAST_NO_XSUM", "0") != "1"):
+                and self.bn1.training and x.requires_grad and not HF.SW.on("HIAST_NO_XSUM")):
             xs = {}
         idt = x if self.downsample is None else conv_bn_act(self.downsample[0], self.downsample[1], x, relu=False,
                                                             xsum=None if xs is None else (xs, "take"))
         # identity blocks on the channels-last training path: conv1's data-gradient epilogue adds the ReLU-masked
         # gradient of the identity branch itself (no masked copy written by bn3's backward, no separate add kernel);
         # `box` is the hand-off between the two autograd nodes of this call
-        box = {} if (self.downsample is None and os.environ.get("HIAST_NO_IDT_HANDOFF", "0") != "1") else None
+        box = {} if (self.downsample is None and not HF.SW.on("HIAST_NO_IDT_HANDOFF")) else None
         sb1, sb2 = {}, {}       # bn1 -> conv2's data gradient, bn2 -> conv3's: backward statistics from the dgrad epilogue
         # layer3 / layer4 on the 16-bit training path: the three weight gradients of the block are ONE grouped launch at the
         # end of its backward (HF._WGroupFn) instead of three launches that each fill the chip with partial tiles
@@ -275,7 +275,8 @@ class ResNet(nn.Module):
             if self.training and torch.is_grad_enabled():
                 self.prepack(3 if torch.get_autocast_dtype("cuda") == torch.float16 else 1, adjoint=True)
             from hiast_amd import kernels as K
-            if self.bn1.training and K.stem_train_supported(self.conv1):
+            if (self.bn1.training and K.stem_train_supported(self.conv1) and not x.requires_grad
+                    and K.stem_train_shape_ok(x)):
                 # K9k: own stem convolution straight from the fp32 NCHW batch, + the sums bn1 needs (HIAST_LIB_STEM=1: library)
                 x, stem_partial = HF.stem_conv_train(x, self.conv1)
             else:

@@ -60,6 +60,19 @@ def reset():
     _groups.clear()
 
 
+# Collectives issued per communicator (host-side counters, a few ns each): the invariant a first run on a new backend is
+# checked against — per self-training step at N > 1: 2 x (number of SyncBN layers) [C,2] reduces on the statistics group
+# (ResNet-101: 208), 3 on the auxiliary group (histogram + the two class sums), DDP's gradient buckets on the default group
+# (43.8 M fp32 parameters in 32 MB buckets: 6; counted by the reducer itself, `_get_ddp_logging_data()`).
+COUNTS = {"stat": 0, "aux": 0}
+
+
+def all_reduce(t, which, async_op=False, **kw):
+    """dist.all_reduce on the `which` ('stat' | 'aux') communicator, counted"""
+    COUNTS[which] += 1
+    return dist.all_reduce(t, group=stat_group() if which == "stat" else aux_group(), async_op=async_op, **kw)
+
+
 def usable_cpus():
     """CPUs this process may actually use: affinity mask capped by the cgroup quota (an MI355X box shows 256 logical
     CPUs and grants 16; thread pools sized by os.cpu_count() run 10x slower there than pools sized by the quota)"""

@@ -244,7 +244,7 @@ class BasePseudoGenerator:
     # -- one batch ---------------------------------------------------------------------------
     def _allreduce(self, t):
         if self.world > 1:      # histogram / class sums: on the auxiliary communicator (utils/comm.py)
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=comm.aux_group())
+            comm.all_reduce(t, "aux", op=dist.ReduceOp.SUM)
         return t
 
     def select_and_save_confident_label(self, img_paths, state=None):

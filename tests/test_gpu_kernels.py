@@ -6,6 +6,8 @@ import numpy as np
 import pytest
 import torch
 
+from hiast_amd import switches as SW
+
 import synth
 from oracle import cref, ias_ref, losses_ref
 
@@ -720,7 +722,7 @@ def test_bottleneck_identity_handoff_matches_autograd_add(K, monkeypatch):
     gy = _cl(dev(_bf16r(synth.normal_f32(951, (2, 256, 24, 40)))).bfloat16())
     outs = []
     for off in ("1", "0"):
-        monkeypatch.setenv("HIAST_NO_IDT_HANDOFF", off)
+        monkeypatch.setitem(SW.SWITCHES, "HIAST_NO_IDT_HANDOFF", off == "1")
         blk.zero_grad()
         # the block input is itself the output of an op (as in the trunk), so that its gradient is what autograd delivers
         src = x0.clone().requires_grad_(True)

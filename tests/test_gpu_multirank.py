@@ -45,9 +45,20 @@ def _check(out, batch, gpus=2, scaling="weak"):
     assert "cpu_baseline" not in out
 
 
+def _check_collectives(out):
+    """the per-step invariant of the N > 1 path (round 5): 6 gradient buckets (175 MB of fp32 gradients in 32 MB buckets), 208
+    [C,2] statistics reduces (104 SyncBN layers, forward + backward), 3 auxiliary reduces (histogram + the two class sums) —
+    what the first RCCL run is compared with"""
+    c = out["collectives_per_step"]
+    assert c["expected"] == {"syncbn_stat_all_reduces": 208, "pseudo_label_aux_all_reduces": 3}, c
+    assert c["syncbn_stat_all_reduces"] == 208 and c["pseudo_label_aux_all_reduces"] == 3, c
+    assert c["gradient_buckets"] == 6, c
+
+
 def test_bench_two_ranks_through_spawn_ranks_gloo_same_device():
     out, err = _run_bench(["--same-device", "--backend", "gloo", "--batch", "2"])
     _check(out, 2)
+    _check_collectives(out)
     assert "grad strides do not match bucket view" not in err
 
 
@@ -56,6 +67,7 @@ def test_bench_two_ranks_through_spawn_ranks_rccl():
         pytest.skip("RCCL needs one device per rank; %d visible" % torch.cuda.device_count())
     out, err = _run_bench(["--batch", "2"])
     _check(out, 2)
+    _check_collectives(out)
     assert "grad strides do not match bucket view" not in err
 
 

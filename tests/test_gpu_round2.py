@@ -5,6 +5,8 @@ import numpy as np
 import pytest
 import torch
 
+from hiast_amd import switches as SW
+
 import synth
 
 pytestmark = pytest.mark.gpu
@@ -128,7 +130,7 @@ def test_bottleneck_backward_with_and_without_statistics_fusion(monkeypatch):
     gout = torch.from_numpy(synth.normal_f32(921, (2, 1024, 24, 40))).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
     res = {}
     for flag in ("0", "1"):
-        monkeypatch.setenv("HIAST_NO_BN_BWD_FUSION", flag)
+        monkeypatch.setitem(SW.SWITCHES, "HIAST_NO_BN_BWD_FUSION", flag == "1")
         for p in blk.parameters():
             p.grad = None
         x = x0.clone().requires_grad_()

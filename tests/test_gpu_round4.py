@@ -3,6 +3,8 @@ that defers the three weight gradients of a bottleneck to one launch (functional
 import pytest
 import torch
 
+from hiast_amd import switches as SW
+
 pytestmark = pytest.mark.gpu
 
 
@@ -55,7 +57,7 @@ def test_bottleneck_grouped_weight_gradients_match_the_per_convolution_path(dt, 
     # (two passes: the second ACCUMULATES into .grad — on the main stream only: with the side stream on, a step must not
     # accumulate, as on the per-convolution path)
     for mode, passes in (("single", 2), ("group", 2), ("single1", 1), ("group_side", 1)):
-        monkeypatch.setenv("HIAST_NO_WGROUP", "1" if mode.startswith("single") else "0")
+        monkeypatch.setitem(SW.SWITCHES, "HIAST_NO_WGROUP", mode.startswith("single"))
         HF._wgrad_overlap[0] = mode == "group_side"
         blk.zero_grad()
         for _ in range(passes):
@@ -86,7 +88,7 @@ def test_layer4_block_groups_only_its_1x1_pair(monkeypatch):
     assert grp is not None and wv[1] is None and grp["slot"] == [0, None, 1]
     res = {}
     for mode in ("single", "group"):
-        monkeypatch.setenv("HIAST_NO_WGROUP", "1" if mode == "single" else "0")
+        monkeypatch.setitem(SW.SWITCHES, "HIAST_NO_WGROUP", mode == "single")
         blk.zero_grad()
         src = x0.clone().requires_grad_(True)
         with torch.autocast("cuda", dtype=torch.float16):
@@ -147,7 +149,7 @@ def test_training_forward_with_own_stem_matches_the_library_stem(dt, monkeypatch
     x = torch.randn(2, 3, 96, 160, device=dev)
     out = {}
     for lib in ("1", "0"):
-        monkeypatch.setenv("HIAST_LIB_STEM", lib)
+        monkeypatch.setitem(SW.SWITCHES, "HIAST_LIB_STEM", lib == "1")
         net.zero_grad()
         for m in net.modules():
             if isinstance(m, torch.nn.BatchNorm2d):
@@ -234,7 +236,7 @@ def test_stage_entry_block_shared_input_gradient_handoff(monkeypatch):
     gy = torch.randn(2, 1024, 24, 40, device=dev).half().contiguous(memory_format=torch.channels_last)
     res = {}
     for off in ("1", "0"):
-        monkeypatch.setenv("HIAST_NO_XSUM", off)
+        monkeypatch.setitem(SW.SWITCHES, "HIAST_NO_XSUM", off == "1")
         blk.zero_grad()
         src = x0.clone().requires_grad_(True)
         with torch.autocast("cuda", dtype=torch.float16):

@@ -124,3 +124,44 @@ def test_eval_forward_takes_the_one_launch_tail(K, monkeypatch):
     dh = float((h1 - h0).abs().max()) / float(h0.abs().max())
     print("eval forward 512x1024: one-launch tail vs two launches: split planes %.3g, bf16 %.3g of max|logit|" % (d, dh))
     assert d <= 2e-5 and dh <= 2e-2
+
+
+# ------------------------------------------------------------------------------------------------ round-4 advisor findings
+def test_shared_input_gradient_is_not_dropped_when_the_downsample_leg_takes_another_path(monkeypatch):
+    """stage-entry block whose downsample BatchNorm is in eval mode while bn1 trains: the downsample convolution then runs as the
+    plain module and never takes conv1's data gradient — conv1 must return it itself (round 4 stored it for a taker that did
+    not exist and the block input lost that part of its gradient)"""
+    import torch.nn as nn
+    from hiast_amd import switches as SW
+    from hiast_amd.sseg.models.modules.resnet import Bottleneck
+    torch.manual_seed(7)
+    dev = torch.device("cuda:0")
+    down = nn.Sequential(nn.Conv2d(512, 1024, 1, stride=1, bias=False), nn.BatchNorm2d(1024))
+    blk = Bottleneck(512, 256, 1, 1, down).to(dev).train()
+    blk.downsample[1].eval()                    # frozen statistics on the identity leg only
+    x0 = torch.randn(2, 512, 24, 40, device=dev).half().contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(2, 1024, 24, 40, device=dev).half().contiguous(memory_format=torch.channels_last)
+    res = {}
+    for off in (True, False):
+        monkeypatch.setitem(SW.SWITCHES, "HIAST_NO_XSUM", off)
+        src = x0.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            y = blk(src * 1.0)
+        y.backward(gy)
+        res[off] = src.grad.float()
+    d = (res[False] - res[True]).abs()
+    assert float(res[True].abs().max()) > 0
+    assert (d <= 2.0 ** -9 * res[True].abs() + 2.0 ** -10 * res[True].abs().max()).all(), float(d.max())
+
+
+def test_training_stem_keeps_the_image_gradient():
+    """the K9k stem never computes the image gradient: a batch that requires one (adversarial inputs, saliency) must take the
+    library stem, as it did before K9k existed"""
+    from hiast_amd.sseg.models.modules.resnet import build_resnet101
+    torch.manual_seed(3)
+    net = build_resnet101(output_stride=8).cuda().train()
+    x = torch.randn(1, 3, 64, 128, device="cuda", requires_grad=True)
+    with torch.autocast("cuda", dtype=torch.float16):
+        y = net(x)
+    y.float().square().mean().backward()
+    assert x.grad is not None and bool(torch.isfinite(x.grad).all()) and float(x.grad.abs().max()) > 0

@@ -9,7 +9,7 @@ cl = lambda a: torch.from_numpy(a).cuda().bfloat16().contiguous(memory_format=to
 x0 = cl(synth.normal_f32(950, (2, 256, 24, 40))); gy = cl(synth.normal_f32(951, (2, 256, 24, 40)))
 outs = []
 for off in ("1", "0"):
-    os.environ["HIAST_NO_IDT_HANDOFF"] = off
+    from hiast_amd import switches as SW; SW.SWITCHES["HIAST_NO_IDT_HANDOFF"] = off == "1"
     blk.zero_grad()
     src = x0.clone().requires_grad_(True)
     xin = src * 1.0
