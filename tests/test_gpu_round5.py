@@ -127,31 +127,42 @@ def test_eval_forward_takes_the_one_launch_tail(K, monkeypatch):
 
 
 # ------------------------------------------------------------------------------------------------ round-4 advisor findings
-def test_shared_input_gradient_is_not_dropped_when_the_downsample_leg_takes_another_path(monkeypatch):
-    """stage-entry block whose downsample BatchNorm is in eval mode while bn1 trains: the downsample convolution then runs as the
-    plain module and never takes conv1's data gradient — conv1 must return it itself (round 4 stored it for a taker that did
-    not exist and the block input lost that part of its gradient)"""
+def test_shared_input_gradient_is_not_dropped_without_a_taker():
+    """the xsum hand-off of a stage-entry block (conv1 'gives' its data gradient to the downsample convolution's epilogue): a
+    'give' convolution whose partner never registered as taker (its leg took another path) must return its input gradient itself
+    — round 4 parked it in the shared dict, where nothing picked it up"""
     import torch.nn as nn
-    from hiast_amd import switches as SW
-    from hiast_amd.sseg.models.modules.resnet import Bottleneck
+    from hiast_amd import functional as HF
     torch.manual_seed(7)
     dev = torch.device("cuda:0")
-    down = nn.Sequential(nn.Conv2d(512, 1024, 1, stride=1, bias=False), nn.BatchNorm2d(1024))
-    blk = Bottleneck(512, 256, 1, 1, down).to(dev).train()
-    blk.downsample[1].eval()                    # frozen statistics on the identity leg only
+    conv = nn.Conv2d(512, 256, 1, bias=False).to(dev)
     x0 = torch.randn(2, 512, 24, 40, device=dev).half().contiguous(memory_format=torch.channels_last)
-    gy = torch.randn(2, 1024, 24, 40, device=dev).half().contiguous(memory_format=torch.channels_last)
-    res = {}
-    for off in (True, False):
-        monkeypatch.setitem(SW.SWITCHES, "HIAST_NO_XSUM", off)
+    gy = torch.randn(2, 256, 24, 40, device=dev).half().contiguous(memory_format=torch.channels_last)
+    grads = []
+    for xsum in (None, ({}, "give")):
         src = x0.clone().requires_grad_(True)
         with torch.autocast("cuda", dtype=torch.float16):
-            y = blk(src * 1.0)
+            y = HF.conv_nhwc(src * 1.0, conv, xsum=xsum)
         y.backward(gy)
-        res[off] = src.grad.float()
-    d = (res[False] - res[True]).abs()
-    assert float(res[True].abs().max()) > 0
-    assert (d <= 2.0 ** -9 * res[True].abs() + 2.0 ** -10 * res[True].abs().max()).all(), float(d.max())
+        assert src.grad is not None and float(src.grad.abs().max()) > 0
+        grads.append(src.grad.clone())
+    assert torch.equal(grads[0], grads[1])
+    # ... and with a registered taker the pair still delivers ONE summed gradient (tests/test_gpu_round4.py covers the values)
+    xs = {}
+    src = x0.clone().requires_grad_(True)
+    xin = src * 1.0
+    conv_t = nn.Conv2d(512, 256, 1, bias=False).to(dev)
+    with torch.autocast("cuda", dtype=torch.float16):
+        yt = HF.conv_nhwc(xin, conv_t, xsum=(xs, "take"))
+        yg = HF.conv_nhwc(xin, conv, xsum=(xs, "give"))
+    assert xs.get("taker") is True
+    (yg.float() * gy.float()).sum().add((yt.float() * gy.float()).sum()).backward()
+    ref = x0.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.float16):
+        r = (HF.conv_nhwc(ref * 1.0, conv).float() * gy.float()).sum() + (HF.conv_nhwc(ref * 1.0, conv_t).float() * gy.float()).sum()
+    r.backward()
+    d = (src.grad.float() - ref.grad.float()).abs()
+    assert (d <= 2.0 ** -9 * ref.grad.float().abs() + 2.0 ** -9 * ref.grad.float().abs().max()).all(), float(d.max())
 
 
 def test_training_stem_keeps_the_image_gradient():
