@@ -242,14 +242,18 @@ class BaseTrainer:
         there is a 'D_loss', the discriminator step.  fp16 (amp_dtype) goes through the dynamic loss scaler like
         apex's amp.scale_loss (:129-131); bf16 autocast needs no loss scaling."""
         scaler = getattr(self, "scaler", None)
-        g_loss = sum(torch.mean(v) for k, v in losses.items() if "D_" not in k)
-        g_optimizer.zero_grad(set_to_none=True)
-        HF.enable_wgrad_overlap(self.wgrad_overlap)
-        try:
-            (scaler.scale(g_loss) if scaler else g_loss).backward()
-        finally:
-            HF.enable_wgrad_overlap(False)
-        HF.wgrad_stream_join()      # single-process runs issue the trunk's weight gradients on a side stream
+        if self.__dict__.pop("_backward_done", False):
+            pass        # train() already ran forward AND backward (GraphedTrainStep: one captured HIP graph); the gradients
+                        # are in place — and static: they must not be set to None
+        else:
+            g_loss = sum(torch.mean(v) for k, v in losses.items() if "D_" not in k)
+            g_optimizer.zero_grad(set_to_none=True)
+            HF.enable_wgrad_overlap(self.wgrad_overlap)
+            try:
+                (scaler.scale(g_loss) if scaler else g_loss).backward()
+            finally:
+                HF.enable_wgrad_overlap(False)
+            HF.wgrad_stream_join()      # single-process runs issue the trunk's weight gradients on a side stream
         self._sync_grads(g_optimizer)
         if scaler:
             scaler.step(g_optimizer)        # unscales, skips the step on inf / NaN gradients

@@ -17,6 +17,77 @@ from hiast_amd.utils.result_recorder import ResultRecorder
 from hiast_amd.workflows.trainer.base_trainer import BaseTrainer
 
 
+class GraphedTrainStep:
+    """train_on() + the backward pass of one HIAST iteration as ONE captured HIP graph (round 5).
+
+    Why: an iteration is ~1000 kernel launches; through the DataLoader the trainer's host loop (36-40 ms) sat within 10 % of its
+    device time (39.5 ms, profiles/r04_trainer_end_to_end.txt) — every further kernel gain would have been invisible.  What is
+    captured: EMA-teacher forward (side stream), student forward, fused 4-term loss, backward incl. the grouped weight gradients
+    on their side stream and the weight re-packing of both trunks (the launches of reference steps
+    workflows/trainer/consistency_self_training_trainer.py:92-126 + the backward of base_trainer.py:127-131).  What stays
+    eager: the batch's H2D copy + normalisation, the loss scaler's non-finite check, FusedAdam, the EMA update, the scheduler
+    (the learning rate is a launch ARGUMENT of the optimiser kernel), validation, checkpoints.  Static shapes: a change of the
+    batch's shape re-captures.  The first WARM iterations of a shape run eagerly (allocator, lazy initialisations).
+    Gradients are bit-equal to the eager step's (tests/test_gpu_round5.py): same kernels, same order, same streams.
+    Single process only — under DDP the reducer's hooks have to run, the step stays eager."""
+    WARM = 3
+
+    def __init__(self, trainer):
+        self.tr = trainer
+        self.graph = None
+        self.key = None
+        self.seen = 0
+
+    def _plans(self):
+        nets = [self.tr.model.module, self.tr.ema_model]
+        for net in nets:
+            for m in net.modules():
+                for ent in m.__dict__.get("_hiast_plans", {}).values():
+                    yield ent[0]
+
+    def _run(self, weak, strong, plbl):
+        tr = self.tr
+        losses = tr.train_on(weak, strong, plbl)
+        g_loss = sum(torch.mean(v) for k, v in losses.items() if "D_" not in k)
+        HF.enable_wgrad_overlap(tr.wgrad_overlap)
+        try:
+            (tr.scaler.scale(g_loss) if tr.scaler else g_loss).backward()
+        finally:
+            HF.enable_wgrad_overlap(False)
+        HF.wgrad_stream_join()
+        return losses
+
+    def __call__(self, weak, strong, plbl):
+        tr = self.tr
+        key = (tuple(weak.shape), weak.dtype, tuple(strong.shape), tuple(plbl.shape), plbl.dtype, strong is weak)
+        if key != self.key:
+            self.key, self.graph, self.seen = key, None, 0
+        if self.graph is None:
+            self.seen += 1
+            if self.seen <= self.WARM:                        # eager iterations of this shape
+                tr.g_optimizer.zero_grad(set_to_none=True)
+                return self._run(weak, strong, plbl)
+            self.s_weak = weak.clone()
+            self.s_strong = self.s_weak if strong is weak else strong.clone()
+            self.s_plbl = plbl.clone()
+            for plan in self._plans():
+                plan.versions = None              # the re-pack launches must be IN the graph whatever moved last
+            tr.g_optimizer.zero_grad(set_to_none=True)        # the graph's backward allocates the (from now on static) gradients
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                losses = self._run(self.s_weak, self.s_strong, self.s_plbl)
+            self.graph = g
+            self.losses = {k: v.detach() for k, v in losses.items()}
+        else:
+            self.s_weak.copy_(weak, non_blocking=True)
+            if self.s_strong is not self.s_weak:
+                self.s_strong.copy_(strong, non_blocking=True)
+            self.s_plbl.copy_(plbl, non_blocking=True)
+        self.graph.replay()
+        return self.losses
+
+
 @TRAINER.register("ConsistencySelfTrainingTrainer")
 class ConsistencySelfTrainingTrainer(BaseTrainer):
 
@@ -92,4 +163,19 @@ class ConsistencySelfTrainingTrainer(BaseTrainer):
             strong = weak
         else:
             (weak, strong), plbl = du.to_device_batch([weak, strong], plbl, self.device)
+        if self.graph_train_enabled():
+            # forward + backward from a captured HIP graph (GraphedTrainStep): update_model() finds the gradients in place
+            if getattr(self, "_graphed_step", None) is None:
+                self._graphed_step = GraphedTrainStep(self)
+            losses = self._graphed_step(weak, strong, plbl)
+            self._backward_done = True
+            return losses
         return self.train_on(weak, strong, plbl)
+
+    def graph_train_enabled(self):
+        """cfg-free switch (HIAST_GRAPH_TRAIN=1, read once): 16-bit single-process training only"""
+        on = self.__dict__.get("_graph_train")
+        if on is None:
+            on = self._graph_train = (os.environ.get("HIAST_GRAPH_TRAIN", "0") == "1" and self.world == 1
+                                      and self.amp_dtype is not None and not getattr(self, "manual_allreduce", False))
+        return on

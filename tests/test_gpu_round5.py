@@ -2,6 +2,8 @@
 ReLU of a layer3 bottleneck in ONE launch for the two inference forwards (reference: Bottleneck.forward,
 sseg/models/modules/resnet.py:84-98) — against the two launches it replaces (same products, same order: bit-equal) and
 against float64 on the operand values, in the three operand formats, with ragged tiles and the tail rows."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -176,3 +178,71 @@ def test_training_stem_keeps_the_image_gradient():
         y = net(x)
     y.float().square().mean().backward()
     assert x.grad is not None and bool(torch.isfinite(x.grad).all()) and float(x.grad.abs().max()) > 0
+
+
+# ------------------------------------------------------------------------------------------------ the captured training step
+@pytest.mark.parametrize("amp", ["fp16", "bf16"])
+def test_graphed_training_step_gradients_bit_equal_to_the_eager_step(tmp_path_factory, monkeypatch, amp):
+    """GraphedTrainStep (teacher forward, student forward, fused loss, backward incl. the grouped weight gradients and both
+    trunks' weight re-packing as ONE HIP graph) against the eager launches of the same step: every gradient tensor and the four
+    losses bit-equal — on the captured batch and on NEW batches pushed through the static buffers; after an optimiser step
+    (the re-pack inside the graph picks the new weights up) the replay still equals the eager step"""
+    import test_gpu_trainstep_oracle as TS
+    from hiast_amd.workflows.trainer.consistency_self_training_trainer import GraphedTrainStep
+    depth = "r26"
+    TS._patch_depth(monkeypatch, depth)
+    root = str(tmp_path_factory.mktemp("graphed_" + amp))
+    torch.save(TS._state(depth), os.path.join(root, "init.pth"))
+    tr = TS._trainer(root, "O1", amp)
+    if tr.scaler is not None:       # a scale at which nothing overflows: NaN would make the comparison vacuous
+        tr.scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 8, growth_interval=10 ** 6)
+    dev = tr.device
+    weak, strong, plbl = (torch.from_numpy(a).to(dev) for a in TS._inputs())
+    weak2, strong2 = (weak * 0.9 + 0.05).contiguous(), (strong.flip(3) * 1.1).contiguous()
+    plbl2 = plbl.flip(2).contiguous()
+    gs = GraphedTrainStep(tr)
+    params = dict(tr.model.module.named_parameters())
+
+    def eager(w, s, p):
+        tr.g_optimizer.zero_grad(set_to_none=True)
+        losses = gs._run(w, s, p)
+        torch.cuda.synchronize()
+        return ({k: v.detach().clone() for k, v in losses.items()},
+                {k: q.grad.detach().clone() for k, q in params.items() if q.grad is not None})
+
+    def graphed(w, s, p):
+        losses = gs(w, s, p)
+        torch.cuda.synchronize()
+        return ({k: v.detach().clone() for k, v in losses.items()},
+                {k: q.grad.detach().clone() for k, q in params.items() if q.grad is not None})
+
+    def same(a, b, what):
+        assert set(a[0]) == set(b[0]) and set(a[1]) == set(b[1]) and len(a[1]) >= 30
+        for k in a[0]:
+            assert torch.equal(a[0][k], b[0][k]), (what, k, float(a[0][k]), float(b[0][k]))
+        for k in a[1]:
+            assert bool(torch.isfinite(a[1][k]).all()), (what, k)
+            assert torch.equal(a[1][k], b[1][k]), (what, k, float((a[1][k] - b[1][k]).abs().max()))
+
+    e1, e2 = eager(weak, strong, plbl), eager(weak2, strong2, plbl2)
+    assert not torch.equal(e1[1]["seg_model.backbone.conv1.weight"], e2[1]["seg_model.backbone.conv1.weight"])
+    for _ in range(GraphedTrainStep.WARM):
+        g = graphed(weak, strong, plbl)             # eager iterations of the shape
+        assert gs.graph is None
+        same(e1, g, "warm-up iteration")
+    g = graphed(weak, strong, plbl)                 # capture + first replay
+    assert gs.graph is not None
+    same(e1, g, "capture")
+    same(e2, graphed(weak2, strong2, plbl2), "replay on a new batch")
+    same(e1, graphed(weak, strong, plbl), "replay on the first batch again")
+    # an optimiser step moves the weights: the graph's own re-pack launches must pick them up
+    tr._backward_done = True
+    tr.update_model(tr.g_optimizer, tr.d_optimizer, g[0])
+    tr.after_update(1)
+    g3 = graphed(weak2, strong2, plbl2)
+    gsaved = gs.graph
+    gs.graph, gs.key = None, None                   # (eager reference on the updated weights; the static gradients stay allocated)
+    e3 = eager(weak2, strong2, plbl2)
+    assert not torch.equal(e3[1]["seg_model.backbone.layer3.0.conv2.weight"], e2[1]["seg_model.backbone.layer3.0.conv2.weight"])
+    same(e3, g3, "replay after an optimiser step")
+    del gsaved
