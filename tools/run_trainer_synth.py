@@ -110,6 +110,8 @@ try:
         wait[0] = 0.0
         parts.clear()
         t0 = time.time()
+        c0 = time.process_time()                # CPU time of the main process: a host loop that is BLOCKED on a full launch queue is
+                                                # not busy (wall time alone cannot tell the two apart)
         idle = 0                                # iterations at whose end the device had already finished everything enqueued
         for it in range(warm + 1, warm + iters + 1):
             tr.step(it)
@@ -117,11 +119,12 @@ try:
             ev.record()
             idle += int(ev.query())
         t_host = (time.time() - t0) / iters     # host time per iteration (enqueue + data), before the final drain
+        t_cpu = (time.process_time() - c0) / iters
         print("  device already idle at the end of %d of %d iterations (host-bound iterations)" % (idle, iters), flush=True)
         torch.cuda.synchronize()
         dt = (time.time() - t0) / iters
-        print("  host loop %.1f ms/iter of which %.1f ms in next_target_batch()" % (t_host * 1e3, wait[0] / iters * 1e3),
-              flush=True)
+        print("  host loop %.1f ms/iter wall (%.1f ms of CPU time in the main process) of which %.1f ms in next_target_batch()"
+              % (t_host * 1e3, t_cpu * 1e3, wait[0] / iters * 1e3), flush=True)
         if parts:
             print("  breakdown (ms/iter): " + ", ".join("%s %.1f" % (k, v / iters * 1e3) for k, v in parts.items()), flush=True)
         del tr.next_target_batch                # (the instance attribute; the class method is back)
