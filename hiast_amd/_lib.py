@@ -59,7 +59,7 @@ SIGNATURES = {
     "hiast_xconv_dgrad_gated_bn_stats_rows": (c_int, [c_i64, c_int, c_int]),
     "hiast_xconv_dgrad_gated_bn_stats": (c_int, [c_vp] * 10 + [c_i64, c_int, c_int, c_int, c_vp]),
     "hiast_igemm_dgrad_s2": (c_int, [c_vp, c_vp, c_vp] + [c_int] * 6 + [c_vp]),
-    "hiast_igemm_dgrad_bn_stats_rows": (c_int, [c_i64]),
+    "hiast_igemm_dgrad_bn_stats_rows": (c_int, [c_i64, c_int, c_int, c_int]),
     "hiast_bn_nhwc_stats_from_partial": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
     "hiast_conv_wgrad_workspace_bytes": (c_sz, [c_int] * 6),
     "hiast_conv_wgrad_nhwc": (c_int, [c_vp, c_vp, c_vp] + [c_int] * 9 + [c_vp, c_sz, c_vp]),
@@ -131,7 +131,7 @@ def load():
             raise HiastLibraryError("libhiast_hip.so does not export %s" % name) from e
         fn.restype = res
         fn.argtypes = args
-    if lib.hiast_version() != 4:
+    if lib.hiast_version() != 5:
         raise HiastLibraryError("libhiast_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -302,7 +302,13 @@ extern "C" int hiast_igemm_dgrad_s2(const void* dy, const void* wpt, void* dx, i
                              H, W, -2, 1, fmt, 0, (hipStream_t)stream, nullptr, nullptr, 0, 0);
 }
 
-extern "C" int hiast_igemm_dgrad_bn_stats_rows(int64_t M) { return M <= 0 ? 0 : (int)((M + hiast::IG_BM - 1) / hiast::IG_BM); }
+// rows of the partial-sum buffer of hiast_igemm_dgrad_bn_stats: one per block row of the tile form the launch takes
+extern "C" int hiast_igemm_dgrad_bn_stats_rows(int64_t M, int Cin, int Cout, int taps)
+{
+    if (M <= 0) return 0;
+    const int bm = ig_block_rows(M, Cin, Cout, taps, 0);
+    return (int)((M + bm - 1) / bm);
+}
 
 extern "C" int hiast_igemm_bn_act(const void* x, const void* wp, const float* gamma, const float* beta,
                                   const float* mean, const float* var, float eps, const void* res, int relu, void* y,
@@ -338,7 +344,8 @@ extern "C" int hiast_igemm_stats_rows(int64_t M, int Cin, int Cout, int taps, in
     const int planes = hiast_fmt_planes(fmt);
     if (M <= 0 || Cin <= 0 || Cout <= 0) return 0;
     if (hiast_xconv_ok(M, Cin, Cout, planes, taps, 0, 0, 0, 0, 0, 0, 1)) return hiast_xconv_stats_rows(M, Cout);
-    return (int)((M + hiast::IG_BM - 1) / hiast::IG_BM);
+    const int bm = ig_block_rows(M, Cin, Cout, taps, 0);
+    return (int)((M + bm - 1) / bm);
 }
 
 extern "C" int hiast_pack_conv_weight(const float* w, int N, int K, int taps, int fmt, int transpose, void* wp,

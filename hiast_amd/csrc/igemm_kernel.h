@@ -49,6 +49,17 @@ typedef __attribute__((ext_vector_type(16))) float ig_f32x16;
 typedef __attribute__((ext_vector_type(4))) float ig_f32x4;
 
 constexpr int IG_BM = 256;
+// automatic choice of the 128 x 128 / two-blocks-per-CU form (ig_half_tile below); M pixels, K -> N channels, 1x1 only
+// Measured (profiles/r05_ab_igemm_half_tile.txt): stand-alone the 128 x 128 form wins wherever the 256-row form leaves half of
+// the chip idle (<= 128 blocks: the 1024 -> 256 launch of a 4-image batch 71 -> 53 us in split planes, 38 -> 32 us in fp16) and
+// loses 5-12 % where the 256-row form fills the chip once (B = 8: 50 -> 55 us; the operands pass the L2 -> LDS path twice).
+// In the step the 4-image launches are the two sub-batches of an inference forward on two streams — two half-chip launches
+// side by side already fill the chip, and the step did not move (55.5 / 55.5 against 55.7 / 55.8 ms) — so the automatic rule takes
+// the quarter-chip launches only (<= 64 blocks): the pseudo-label generator at the reference's batch size 2 runs 247 -> 271
+// images/s end to end with it.
+#ifndef IG_HALF_AUTO
+#define IG_HALF_AUTO(M, K, N) ((((M) + 255) / 256) * (((N) % 256 == 0) ? (N) / 256 : (N) / 128) <= 64)
+#endif
 
 #ifdef IG_STAMP       // diagnostic build (tools/igemm_stamps.py): cycles a wave spends in the parts of a k-step, summed over the loop
 __device__ unsigned ig_stamp_buf[1024 * 8 * 8 + 32 * 64];
@@ -171,9 +182,14 @@ __device__ __forceinline__ size_t ig_elem(size_t m, int c, int C)
 // (geo.H x geo.W) its output gradient: tap (ty, tx) of output pixel (y, x) reads source pixel ((y + ty - 1) / 2, (x + tx - 1) / 2)
 // when both are even and nothing otherwise (the weights are packed in adjoint form as for a stride-1 data gradient).  The
 // parity test joins the in-image test of the DMA address; three of four taps fetch zeros (which the DMA writes for free).
+// BM (round 5): rows of the block tile = 32 x the number of waves.  256 (8 waves, one block per CU: the form every MFMA-bound launch
+// uses) or 128 with BN = 128 (4 waves, 80 KiB of LDS: TWO blocks per CU, one wave of each per SIMD) — the HBM-bound 1x1 launches
+// with a long reduction (1024 -> 256, 2048 -> 512) run ONE round of 256-row tiles, so nothing overlapped their ~19 us of
+// prologue + epilogue; as 128 x 128 tiles a CU always holds two blocks that are out of phase — one streams its operands while
+// the other one stores its tile.  The A tile is then read by two column blocks (neighbours on one XCD: L2).
 template <int PL, bool OUTF32, int BN, int TAPS, bool RES, bool RELU, int GATE = 0, int STATS = 0, bool F16 = false,
-          bool UPS = false>
-__global__ __launch_bounds__(512) void igemm_bn_act_kernel(
+          bool UPS = false, int BM = IG_BM>
+__global__ __launch_bounds__(BM * 2) void igemm_bn_act_kernel(
     const unsigned short* __restrict__ X, const unsigned short* __restrict__ Wp, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ var, float eps,
     const unsigned short* __restrict__ R, void* __restrict__ Yv, int M, int K, int N, IGeo geo,
@@ -184,20 +200,23 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
     static_assert(!F16 || PL == 1, "fp16 rows are a one-plane format");
     static_assert(!UPS || (TAPS == 9 && PL == 1 && !RES && !RELU && GATE == 0 && STATS == 0 && !OUTF32), "transposed stride 2: plain 3x3");
     using HT = H16<F16>;
-    constexpr int WN = BN / 64, WM = 8 / WN;
+    constexpr int NWV = BM / 32;                        // waves per block (8 | 4)
+    static_assert((BM == 256 || (BM == 128 && BN <= 128)) && NWV * 64 == BM * 2, "block tile: 256 x BN (8 waves) or 128 x <=128 (4 waves)");
+    constexpr int WN = BN / 64, WM = NWV / WN;
+    static_assert(WM >= 1 && WM * WN == NWV, "wave grid");
     static_assert(!STATS || (PL == 1 && !OUTF32 && !RES && !RELU && GATE == 0), "statistics epilogue: plain bf16 launches only");
     constexpr bool XROWS = RES || STATS == 2;           // the epilogue reads rows of R (residual | BN input)
-    constexpr int TM = IG_BM / WM / 32;                 // 32-row tiles per wave (4 | 2 | 1)
-    constexpr int A_BYTES = IG_BM * 128, B_BYTES = BN * 128;
+    constexpr int TM = BM / WM / 32;                    // 32-row tiles per wave (4 | 2 | 1)
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
     // LDS: THREE stages of the activation tile and TWO of the weight tile (160 KiB at BN = 256).  The fill rate of a tile
     // is (bytes in flight) / latency, and with one 64 KiB tile in flight per CU the launches were bound by exactly that
     // (removing every MFMA left the kernel time unchanged): the activation rows — first touched in HBM — are requested
     // two k-steps ahead, the weight rows (L2 hits, the same for every block) one.
     constexpr int NSA = 3, NSB = 2;
     constexpr int LDS_BYTES = NSA * A_BYTES + NSB * B_BYTES;
-    constexpr int BG = BN / 64;                         // 8-row B groups per wave (4 | 2 | 1)
+    constexpr int BG = BN / 8 / NWV;                    // 8-row B groups per wave (4 | 2 | 1)
     constexpr int EP = 68;                              // padded row of a wave's private epilogue tile (floats)
-    static_assert(LDS_BYTES >= 8 * 32 * EP * 4, "epilogue staging must fit in the tile buffers");
+    static_assert(LDS_BYTES >= NWV * 32 * EP * 4, "epilogue staging must fit in the tile buffers");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -212,7 +231,7 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
         bn_ = lid % gy;
         bm = lid / gy;
     }
-    const int m0 = bm * IG_BM, n0 = bn_ * BN;
+    const int m0 = bm * BM, n0 = bn_ * BN;
     const int KS = (K * PL) >> 6;                       // slabs per row (= k-steps per tap)
     const int nk = TAPS * KS;
 
@@ -386,8 +405,10 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
         // The two waves of a SIMD (w and w + 4) share its matrix pipe and the arbiter serves the older one first: left
         // alone, waves 0-3 ran ahead and waves 4-7 finished each k-step ~900 cycles later with the pipe 45 % busy.  The
         // priority is handed over in the middle of the k-step, so that both finish together.
-        if (wave < 4) __builtin_amdgcn_s_setprio(1);
-        else __builtin_amdgcn_s_setprio(0);
+        if (NWV == 8) {                                  // (4-wave blocks: one wave of the block per SIMD, nothing to hand over)
+            if (wave < 4) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
         IG_T(t3);
 #ifdef IG_STAMP
         unsigned tile_t[NA + 1];
@@ -410,7 +431,7 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
 #ifndef IG_FLIP8
 #define IG_FLIP8 4
 #endif
-            if (a == NA * IG_FLIP8 / 8) {
+            if (NWV == 8 && a == NA * IG_FLIP8 / 8) {
                 if (wave < 4) __builtin_amdgcn_s_setprio(0);
                 else __builtin_amdgcn_s_setprio(1);
             }
@@ -637,7 +658,7 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
             }
         }
         __syncthreads();                                // the private epilogue tiles are free now
-        float* sS = reinterpret_cast<float*>(smem);     // [8 waves][64 channels][2]
+        float* sS = reinterpret_cast<float*>(smem);     // [waves][64 channels][2]
         if (erow == 0) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -646,7 +667,7 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
             }
         }
         __syncthreads();
-        for (int e = tid; e < BN * 2; e += 512) {
+        for (int e = tid; e < BN * 2; e += NWV * 64) {
             const int c = e >> 1, which = e & 1;        // column of the block tile
             const int wnc = c >> 6, cl = c & 63;
             float t = 0.f;
@@ -658,6 +679,21 @@ __global__ __launch_bounds__(512) void igemm_bn_act_kernel(
 }
 
 }  // namespace hiast
+
+// host: does this launch run on 128 x 128 tiles, two 4-wave blocks per CU (BM = 128 above)?  ONE rule for the launch and for the
+// callers that size the per-block statistics buffers (hiast_igemm_stats_rows, hiast_igemm_dgrad_bn_stats_rows).
+// HIAST_IGEMM_HALF=0 / 1: never / every 1x1 launch with N % 128 == 0 (A/B and tests); unset: the HBM-bound shapes measured faster
+// (profiles/r05_ab_igemm_half_tile.txt).
+static inline int ig_half_tile(int64_t M, int K, int N, int taps, int out_f32)
+{
+    if (taps != 1 || out_f32 || N % 128 != 0 || M < 4096) return 0;
+    if (const char* e = getenv("HIAST_IGEMM_HALF")) return atoi(e) != 0;
+    return IG_HALF_AUTO(M, K, N);
+}
+static inline int ig_block_rows(int64_t M, int K, int N, int taps, int out_f32)
+{
+    return ig_half_tile(M, K, N, taps, out_f32) ? 128 : hiast::IG_BM;
+}
 
 template <int PL, bool OUTF32, bool F16 = false>
 static int launch_igemm_t(const void* x, const void* wp, const float* gamma, const float* beta, const float* mean,
@@ -676,7 +712,11 @@ static int launch_igemm_t(const void* x, const void* wp, const float* gamma, con
         const int v = atoi(env);
         if ((v == 64 || v == 128 || v == 256) && N % v == 0) BN = v;
     }
-    dim3 grid((unsigned)((M + hiast::IG_BM - 1) / hiast::IG_BM), (N + BN - 1) / BN);
+    const bool half = geo.stride >= 0 && ig_half_tile(M, K, N, taps, OUTF32 ? 1 : 0) != 0;
+    if (half) BN = 128;
+    const int BMr = half ? 128 : hiast::IG_BM;
+    dim3 grid((unsigned)((M + BMr - 1) / BMr), (N + BN - 1) / BN);
+    const dim3 block((unsigned)(BMr * 2));
     const int gate = !res_gate ? 0 : (gate_mask ? 2 : 1);
     if (geo.stride < 0) {                                   // transposed stride-2 3x3 (UPS): plain 16-bit launches only
         if constexpr (PL == 1 && !OUTF32) {
@@ -693,44 +733,39 @@ static int launch_igemm_t(const void* x, const void* wp, const float* gamma, con
             return HIAST_E_RANGE;
         }
     }
-#define L(BNV, T, RES, RELU, G)                                                                                      \
-    hipLaunchKernelGGL((hiast::igemm_bn_act_kernel<PL, OUTF32, BNV, T, RES, RELU, G, 0, F16>), grid, dim3(512), 0, st,    \
+#define LK(BNV, T, RES, RELU, G, S, BMV)                                                                              \
+    hipLaunchKernelGGL((hiast::igemm_bn_act_kernel<PL, OUTF32, BNV, T, RES, RELU, G, S, F16, false, BMV>), grid, block, 0, st, \
                        (const unsigned short*)x, (const unsigned short*)wp, gamma, beta, mean, var, eps,              \
                        (const unsigned short*)res, y, (int)M, K, N, geo, stats, (const unsigned short*)res_gate)
-#define LG(BNV, T)                                                                      \
+#define LG(BNV, T, BMV)                                                                 \
     if constexpr (PL == 1 && !OUTF32) {                                                 \
-        if (gate == 1) L(BNV, T, true, false, 1); else L(BNV, T, true, false, 2);       \
+        if (gate == 1) LK(BNV, T, true, false, 1, 0, BMV); else LK(BNV, T, true, false, 2, 0, BMV); \
     }
-#define LS(BNV, T)                                                                      \
+#define LS(BNV, T, BMV)                                                                 \
     if constexpr (PL == 1 && !OUTF32) {                                                 \
-        if (stats_mode == 2)                                                            \
-        hipLaunchKernelGGL((hiast::igemm_bn_act_kernel<PL, OUTF32, BNV, T, false, false, 0, 2, F16>), grid, dim3(512), 0, st, \
-                           (const unsigned short*)x, (const unsigned short*)wp, gamma, beta, mean, var, eps,                     \
-                           (const unsigned short*)res, y, (int)M, K, N, geo, stats, (const unsigned short*)res_gate);       \
-        else                                                                            \
-        hipLaunchKernelGGL((hiast::igemm_bn_act_kernel<PL, OUTF32, BNV, T, false, false, 0, 1, F16>), grid, dim3(512), 0, st, \
-                           (const unsigned short*)x, (const unsigned short*)wp, gamma, beta, mean, var, eps,                     \
-                           (const unsigned short*)res, y, (int)M, K, N, geo, stats, (const unsigned short*)res_gate);       \
+        if (stats_mode == 2) LK(BNV, T, false, false, 0, 2, BMV);                       \
+        else LK(BNV, T, false, false, 0, 1, BMV);                                       \
     }
-#define LL(BNV, T)                                                                      \
-    if (stats_mode == 2) { LS(BNV, T) }                                                 \
+#define LL(BNV, T, BMV)                                                                 \
+    if (stats_mode == 2) { LS(BNV, T, BMV) }                                            \
     else if (res) {                                                                     \
-        if (relu) L(BNV, T, true, true, 0);                                             \
-        else if (gate == 0) L(BNV, T, true, false, 0);                                  \
-        else { LG(BNV, T) }                                                             \
-    } else if (relu) L(BNV, T, false, true, 0);                                         \
-    else if (!stats) L(BNV, T, false, false, 0);                                        \
-    else { LS(BNV, T) }
-#define LLL                                                                                                 \
-    if (taps == 1) { if (BN == 256) { LL(256, 1) } else if (BN == 128) { LL(128, 1) } else { LL(64, 1) } }  \
-    else { if (BN == 256) { LL(256, 9) } else if (BN == 128) { LL(128, 9) } else { LL(64, 9) } }
-    LLL
-#undef LLL
+        if (relu) LK(BNV, T, true, true, 0, 0, BMV);                                    \
+        else if (gate == 0) LK(BNV, T, true, false, 0, 0, BMV);                         \
+        else { LG(BNV, T, BMV) }                                                        \
+    } else if (relu) LK(BNV, T, false, true, 0, 0, BMV);                                \
+    else if (!stats) LK(BNV, T, false, false, 0, 0, BMV);                               \
+    else { LS(BNV, T, BMV) }
+    if (half) {
+        if constexpr (!OUTF32) { LL(128, 1, 128) }
+    } else if (taps == 1) {
+        if (BN == 256) { LL(256, 1, 256) } else if (BN == 128) { LL(128, 1, 256) } else { LL(64, 1, 256) }
+    } else {
+        if (BN == 256) { LL(256, 9, 256) } else if (BN == 128) { LL(128, 9, 256) } else { LL(64, 9, 256) }
+    }
 #undef LL
 #undef LS
 #undef LG
-#undef L
+#undef LK
     HIAST_CHECK_LAUNCH();
     return 0;
 }
-

@@ -1052,7 +1052,7 @@ def igemm_dgrad_bn_stats(dy, wpt, dil, bn_x, gamma, beta, save_mean, save_invstd
     _req(save_invstd, torch.float32, 1, "save_invstd")
     lib = _lib.load()
     da = torch.empty((B, H, W, N), dtype=dy.dtype, device=dy.device)
-    rows = lib.hiast_igemm_dgrad_bn_stats_rows(B * H * W)
+    rows = lib.hiast_igemm_dgrad_bn_stats_rows(B * H * W, Cin, N, taps)     # one row per block of the tile form the launch takes
     partial = torch.empty((rows, N, 2), dtype=torch.float32, device=dy.device)
     check(lib.hiast_igemm_dgrad_bn_stats(_ptr(dy), _ptr(wpt), _ptr(da), B, H, W, Cin, N, taps, int(dil), _ptr(bn_x),
                                          _ptr(gamma), _ptr(beta), _ptr(save_mean), _ptr(save_invstd), _ptr(partial),

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HIAST_ABI_VERSION 4
+#define HIAST_ABI_VERSION 5
 
 #define HIAST_E_ARG   (-1) /* null pointer / non-positive extent */
 #define HIAST_E_RANGE (-2) /* extent outside what the kernels are built for */
@@ -285,7 +285,7 @@ int hiast_igemm_stats_rows(int64_t M, int Cin, int Cout, int taps, int fmt);
  * transpose; Cin = channels of dy, Cout = channels of dA; bf16 channels-last rows), for the case that A = relu(bn(x)):
  * the epilogue also emits the per-block sums of that BatchNorm's backward pass, partial[rows][Cout][2] = (Σg, Σ g*xhat)
  * with g = dA where gamma*(x-mean)*invstd + beta > 0 (the stored bf16 dA), xhat = (x-mean)*invstd — what
- * hiast_bn_nhwc_bwd_stats(relu = 2) computes with one more read of dA and x.  rows = hiast_igemm_dgrad_bn_stats_rows(M);
+ * hiast_bn_nhwc_bwd_stats(relu = 2) computes with one more read of dA and x.  rows = hiast_igemm_dgrad_bn_stats_rows(M, Cin, Cout, taps) (one row per block row of the tile form the launch takes);
  * hiast_bn_nhwc_stats_from_partial reduces them to the sums hiast_bn_nhwc_bwd_apply takes.  gamma / beta may be NULL
  * (1 / 0).  Replaces the autograd of conv -> bn -> relu (Bottleneck.forward, sseg/models/modules/resnet.py:78-98: cuDNN
  * data gradient + ATen batch_norm_backward reduce, each a pass of its own). */
@@ -293,7 +293,7 @@ int hiast_igemm_dgrad_bn_stats(const void* dy, const void* wpt, void* da, int B,
                                int dil, const void* bn_x, const float* gamma, const float* beta, const float* save_mean,
                                const float* save_invstd, float* partial, int fmt /* HIAST_FMT_BF16 | HIAST_FMT_FP16 */,
                                hiast_stream_t stream);
-int hiast_igemm_dgrad_bn_stats_rows(int64_t M);
+int hiast_igemm_dgrad_bn_stats_rows(int64_t M, int Cin, int Cout, int taps);
 /* Data gradient of the trunk's 3x3 / stride-2 / padding-1 convolution (layer2.0.conv2; autograd of nn.Conv2d in
  * Bottleneck.forward, resnet.py:78-98 — round 4, was the library's): dx [B,H,W,Cin] from dy [B,(H-1)/2+1,(W-1)/2+1,Cout]
  * and the adjoint-packed weight (hiast_pack_conv_weight, transpose = 1), 16-bit rows of format fmt. */

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), s
     assert sorted(_lib.SIGNATURES) == syms
-    assert lib.hiast_version() == 4
+    assert lib.hiast_version() == 5
     assert b"workspace" in lib.hiast_error_string(-3)
 
 
