@@ -686,6 +686,8 @@ __global__ __launch_bounds__(BM * 2) void igemm_bn_act_kernel(
 // (profiles/r05_ab_igemm_half_tile.txt).
 static inline int ig_half_tile(int64_t M, int K, int N, int taps, int out_f32)
 {
+    // (1x1 only: on the 3x3 launches the form was measured 20-25 % slower wherever the 256-row form fills the chip — twice the
+    // L2 -> LDS bytes and a third more fragment reads per flop in an MFMA-bound loop — profiles/r05_ab_igemm_half_tile.txt)
     if (taps != 1 || out_f32 || N % 128 != 0 || M < 4096) return 0;
     if (const char* e = getenv("HIAST_IGEMM_HALF")) return atoi(e) != 0;
     return IG_HALF_AUTO(M, K, N);
