@@ -282,7 +282,12 @@ __global__ __launch_bounds__(BM * 2) void igemm_bn_act_kernel(
         const int tap = TAPS == 1 ? 0 : kt - j * TAPS;
         int voff;
         if (TAPS == 1) {
+#ifdef IG_SLABMAJOR_A      // diagnostic build (tools/ab_slabmajor.py): the A operand stored slab-major inside each 256-row tile
+                           // ([tile][slab][row][128 B]: a k-step's tile is ONE contiguous 32 KiB run) — timing only
+            voff = (aok[g] & on) ? (an[g] / BM) * (BM * KS * 128) + (an[g] % BM) * 128 + achunk[g] : OOB;
+#else
             voff = (aok[g] & on) ? an[g] * (KS * 128) + achunk[g] : OOB;
+#endif
         } else {
             int yy = ay[g] + (tap / 3 - 1) * geo.dil, xx = ax[g] + (tap % 3 - 1) * geo.dil;
             bool par = true;
@@ -294,7 +299,11 @@ __global__ __launch_bounds__(BM * 2) void igemm_bn_act_kernel(
             const int pix = (an[g] * geo.H + yy) * geo.W + xx;
             voff = ok ? pix * (KS * 128) + achunk[g] : OOB;
         }
+#ifdef IG_SLABMAJOR_A
+        ig_dma16(xrs, smem + sa * A_BYTES + (4 * wave + g) * 1024, voff, TAPS == 1 ? j * (BM * 128) : j * 128);
+#else
         ig_dma16(xrs, smem + sa * A_BYTES + (4 * wave + g) * 1024, voff, j * 128);
+#endif
     };
     auto dma_b = [&](int kt, int sb, int g, bool on) {
         const int j = TAPS == 1 ? kt : kt / TAPS;

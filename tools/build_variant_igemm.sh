@@ -1,7 +1,7 @@
 #!/bin/bash
-# two translation units with one flag: igemm.hip + igemm_f16.hip
+# two translation units with one flag: igemm.hip + igemm_f16.hip -> hiast_amd/csrc/_ab/libhiast_<name>.so
 set -e
-cd /root/repo/hiast_amd/csrc
+cd "$(dirname "$0")/../hiast_amd/csrc"
 name=$1; shift
 make -s libhiast_hip.so
 mkdir -p _ab
