@@ -49,6 +49,16 @@ typedef __attribute__((ext_vector_type(16))) float ig_f32x16;
 typedef __attribute__((ext_vector_type(4))) float ig_f32x4;
 
 constexpr int IG_BM = 256;
+// which launches run the early-barrier k-loop (igemm_bn_act_kernel): a compile-time choice per (planes, taps).  Measured
+// (profiles/r05_ab_early_barrier.txt, A/B of two builds on one box): split-plane 3x3 -4 % per launch (layer3 192.6 -> 184.2 us,
+// layer4 606 -> 582), step 54.7 -> 54.3 ms; 16-bit 3x3 -1 ... -3 % (step: no further gain); 1x1 launches 0 ... +9 % SLOWER (their A
+// operand comes from HBM and the early barrier leaves its DMA one step of latency instead of 1.5-2).
+#ifndef IG_EARLY_BARRIER
+#define IG_EARLY_BARRIER(PL, TAPS) ((TAPS) == 9 && (PL) == 2)
+#endif
+#ifndef IG_FLIP8
+#define IG_FLIP8 4
+#endif
 // automatic choice of the 128 x 128 / two-blocks-per-CU form (ig_half_tile below); M pixels, K -> N channels, 1x1 only
 // Measured (profiles/r05_ab_igemm_half_tile.txt): stand-alone the 128 x 128 form wins wherever the 256-row form leaves half of
 // the chip idle (<= 128 blocks: the 1024 -> 256 launch of a 4-image batch 71 -> 53 us in split planes, 38 -> 32 us in fp16) and
@@ -118,6 +128,15 @@ __device__ __forceinline__ void ig_lds_read4(ig_bf16x8 (&f)[4][2], unsigned addr
     f[1][0] = ig_lds_read<2048>(addr);     f[1][1] = ig_lds_read<2048>(addr ^ 64u);
     f[2][0] = ig_lds_read<4096>(addr);     f[2][1] = ig_lds_read<4096>(addr ^ 64u);
     f[3][0] = ig_lds_read<6144>(addr);     f[3][1] = ig_lds_read<6144>(addr ^ 64u);
+}
+__device__ __forceinline__ void ig_lds_read_b(ig_bf16x8 (&f)[2], unsigned addr, int b)  // B: 16-row tile b (a constant after unrolling)
+{
+    switch (b) {
+    case 1: f[0] = ig_lds_read<2048>(addr); f[1] = ig_lds_read<2048>(addr ^ 64u); break;
+    case 2: f[0] = ig_lds_read<4096>(addr); f[1] = ig_lds_read<4096>(addr ^ 64u); break;
+    case 3: f[0] = ig_lds_read<6144>(addr); f[1] = ig_lds_read<6144>(addr ^ 64u); break;
+    default: f[0] = ig_lds_read<0>(addr); f[1] = ig_lds_read<0>(addr ^ 64u); break;
+    }
 }
 __device__ __forceinline__ void ig_lds_read_a(ig_bf16x8 (&f)[2], unsigned addr, int a)  // A: 16-row tile a (a is a constant
 {                                                                                        // after unrolling)
@@ -214,6 +233,7 @@ __global__ __launch_bounds__(BM * 2) void igemm_bn_act_kernel(
     // two k-steps ahead, the weight rows (L2 hits, the same for every block) one.
     constexpr int NSA = 3, NSB = 2;
     constexpr int LDS_BYTES = NSA * A_BYTES + NSB * B_BYTES;
+    constexpr bool EB = IG_EARLY_BARRIER(PL, TAPS) != 0;   // the early-barrier k-loop (below)
     constexpr int BG = BN / 8 / NWV;                    // 8-row B groups per wave (4 | 2 | 1)
     constexpr int EP = 68;                              // padded row of a wave's private epilogue tile (floats)
     static_assert(LDS_BYTES >= NWV * 32 * EP * 4, "epilogue staging must fit in the tile buffers");
@@ -382,6 +402,143 @@ __global__ __launch_bounds__(BM * 2) void igemm_bn_act_kernel(
     unsigned stamp_acc[5] = {0, 0, 0, 0, 0};
     const unsigned stamp_begin = ig_now();
 #endif
+    constexpr int NAe = 2 * TM;
+    auto mfma_tile = [&](ig_bf16x8 (&fa_)[2], ig_bf16x8 (&fb_)[2], ig_f32x4& c) {
+        if (PL == 2) {      // lo*hi + hi*lo + hi*hi
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_[1], fb_[0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_[0], fb_[1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_[0], fb_[0], c, 0, 0, 0);
+        } else {
+            c = HT::mfma16(fa_[0], fb_[0], c);
+            c = HT::mfma16(fa_[1], fb_[1], c);
+        }
+    };
+    if (EB) {
+        // ---- EARLY-BARRIER k-loop (round 5).  In the loop below every k-step starts with a barrier behind which ALL waves issue
+        // their first fragment reads and wait an LDS latency: ~540 (16-bit) / ~810 (split planes) cycles per k-step in which no
+        // wave of the CU issues an MFMA (in-kernel stamps: profiles/r05_igemm_stamps.txt).  Here the barrier of a k-step sits in
+        // the MIDDLE of the previous one: behind it stage kt + 1 is known to have landed, so the LAST tile iteration of step kt
+        // reads the first A tile of step kt + 1 through the A ring and refills each B fragment right after its last use — a step
+        // begins with its operands in registers.  Stage lifetimes: the B fragments of a step are all in registers before the
+        // step starts, so its LDS stage is dead at the next mid-step barrier and two B stages carry a prefetch distance of TWO
+        // steps; A(kt + 2) goes into the stage step kt - 1 read, free at mid-step kt.  Everything a wave issues (second half of
+        // a step) has to be landed by the next mid-step barrier: vmcnt(0), no counting.
+        // The loop is ROTATED: its back edge sits behind the fragment wait of the mid-step tile, where no LDS read is in flight —
+        // the fragment registers are loop-carried, and a register copy the compiler places on a back edge must never see a
+        // register whose asm-issued load has not landed (the first form of this loop kept the prefetch in flight across the
+        // edge: correct in most instantiations, stale fragments in the 64-column one).
+        constexpr int NH = NAe / 2;
+#pragma unroll
+        for (int g = 0; g < BG; ++g) dma_b(1, 1, g, nk > 1);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        ig_bf16x8 fb[4][2], fa[2][2];
+        fa[0][0] = ig_lds_read<0>(fa0);
+        fa[0][1] = ig_lds_read<0>(fa0 ^ 64u);
+        ig_lds_read4(fb, fb0);
+        // tiles 0 .. NH - 1 of the step whose A stage is `st` (its operands' first fragments are in registers / in flight)
+        auto half1 = [&](int st) __attribute__((always_inline)) {
+            const unsigned ca = fa0 + (unsigned)(st * A_BYTES);
+            if (NWV == 8) {
+                if (wave < 4) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
+#pragma unroll
+            for (int a = 0; a < NH; ++a) {
+                const int cur = a & 1;
+                if (a == 0) ig_lds_wait_n<6>(fa[0], fb[0]);     // outstanding: B tiles 1..3 (issue order: A tile 0, B tiles 0..3)
+                else ig_lds_wait_n<0>(fa[cur]);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_tile(fa[cur], fb[0], acc4[a][0]);
+                __builtin_amdgcn_sched_barrier(0);
+                ig_lds_read_a(fa[cur ^ 1], ca, a + 1);          // (a + 1 <= NH < NAe)
+                if (a == 0) ig_lds_wait_n<6>(fb[1]);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_tile(fa[cur], fb[1], acc4[a][1]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (a == 0) ig_lds_wait_n<4>(fb[2]);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_tile(fa[cur], fb[2], acc4[a][2]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (a == 0) ig_lds_wait_n<2>(fb[3]);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_tile(fa[cur], fb[3], acc4[a][3]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // mid-step of step kt: this wave's pieces of stage kt + 1 (issued in the second half of step kt - 1) have landed, then
+        // everyone's; everyone has finished step kt - 1: its A stage and the B stage of step kt are free.  Then the fragment
+        // wait of tile NH: behind it nothing is in flight (the back edge)
+        auto mid = [&](int kt) __attribute__((always_inline)) {
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if (HOIST && kt == nk - 1) {
+#pragma unroll
+                for (int r = 0; r < (RD < TM ? RD : TM); ++r) load_res(r);
+            }
+            if (HOIST_HI && kt == nk - 1) load_res(0, 1);
+            if (NH == 0) ig_lds_wait_n<6>(fa[0], fb[0]);
+            else ig_lds_wait_n<0>(fa[NH & 1]);
+        };
+        // tiles NH .. NAe - 1 of step kt (A stage st): the DMA of step kt + 2, and in the last tile the first fragments of step kt + 1
+        auto half2 = [&](int kt, int st) __attribute__((always_inline)) {
+            const int sb = kt & 1;
+            const int st1 = st == 2 ? 0 : st + 1, st2 = st == 0 ? 2 : st - 1;      // A stages of steps kt + 1, kt + 2
+            const bool more = kt + 2 < nk;
+            const unsigned ca = fa0 + (unsigned)(st * A_BYTES), ca1 = fa0 + (unsigned)(st1 * A_BYTES);
+            const unsigned cb1 = fb0 + (unsigned)((sb ^ 1) * B_BYTES);
+            if (NWV == 8) {
+                if (wave < 4) __builtin_amdgcn_s_setprio(0);
+                else __builtin_amdgcn_s_setprio(1);
+            }
+#pragma unroll
+            for (int a = NH; a < NAe; ++a) {
+                const int cur = a & 1;
+                const bool last = a == NAe - 1;
+                if (a != NH) ig_lds_wait_n<0>(fa[cur]);         // (tile NH: waited for in mid())
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_tile(fa[cur], fb[0], acc4[a][0]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!last) ig_lds_read_a(fa[cur ^ 1], ca, a + 1);
+                else {                                          // first A tile and first B tile of the NEXT step
+                    ig_lds_read_a(fa[cur ^ 1], ca1, 0);
+                    ig_lds_read_b(fb[0], cb1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_tile(fa[cur], fb[1], acc4[a][1]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (last) ig_lds_read_b(fb[1], cb1, 1);
+#ifndef IG_ABL_NODMA
+#pragma unroll
+                for (int p = 0; p < NPIECE; ++p) {
+                    if (NH + p * (NAe - NH) / NPIECE != a) continue;
+                    if (p < BG) dma_b(kt + 2, sb, p, more);
+                    else dma_a(kt + 2, st2, p - BG, more);
+                }
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_tile(fa[cur], fb[2], acc4[a][2]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (last) ig_lds_read_b(fb[2], cb1, 2);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_tile(fa[cur], fb[3], acc4[a][3]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (last) ig_lds_read_b(fb[3], cb1, 3);
+            }
+        };
+        static_assert(NH >= 1, "a wave tile has at least two 16-row tiles");
+        half1(0);
+        mid(0);
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            half2(kt, sa);
+            sa = sa == 2 ? 0 : sa + 1;
+            half1(sa);
+            mid(kt + 1);
+        }
+        half2(nk - 1, sa);
+        // the prefetch of the step behind the last one is in flight into registers the epilogue is about to reuse
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fb[0][0]), "+v"(fb[0][1]),
+                       "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[2][0]), "+v"(fb[2][1]), "+v"(fb[3][0]), "+v"(fb[3][1]));
+    } else
     for (int kt = 0; kt < nk; ++kt) {
         const int sb = kt & 1;
         IG_T(t0);
