@@ -137,7 +137,11 @@ __global__ __launch_bounds__(512) void xconv2_kernel(const unsigned short* __res
     // requested ONE PANEL AHEAD (ring of two): a panel is only ~0.7 us of matrix work, less than an HBM round trip
     const int nslab = N >> 5;
     auto slab_off = [&](int m) { return ((size_t)(m < M ? m : 0) * nslab + (n0 >> 5)) * 64 + g * 8; };
-    uint4 rh[2][2], rl[2][2];
+#ifndef X2_RR
+#define X2_RR 2           // depth of the residual register ring: rows are requested X2_RR - 1 panels ahead (-DX2_RR=3, round 5:
+                          // 249 VGPRs, 154.5-157.7 against 155.6-161.5 us stand-alone — the request distance is not the limiter)
+#endif
+    uint4 rh[X2_RR][2], rl[X2_RR][2];
     auto load_res = [&](int p, int buf) {
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
@@ -155,7 +159,10 @@ __global__ __launch_bounds__(512) void xconv2_kernel(const unsigned short* __res
     auto valid = [&](int p) { return p < plast; };
     issue(valid(pfirst) ? pfirst : npanel, 0);
     issue(valid(pfirst + pstep) ? pfirst + pstep : npanel, 1);
-    if (RES) load_res(valid(pfirst) ? pfirst : 0, 0);
+    if (RES) {
+#pragma unroll
+        for (int r = 0; r + 1 < X2_RR; ++r) load_res(valid(pfirst + r * pstep) ? pfirst + r * pstep : 0, r);
+    }
     __syncthreads();                                     // s_sc / s_sh
 
     // One panel.  CUR (compile time: the residual ring must not be indexed at run time, or the compiler moves it out of
@@ -170,10 +177,11 @@ __global__ __launch_bounds__(512) void xconv2_kernel(const unsigned short* __res
         // No scratch traffic may hide in this count (the Makefile fails the build on spills).
         // A BARE s_barrier: behind __syncthreads() the compiler emits `s_waitcnt vmcnt(4)` here (it wants every LDS-DMA it
         // knows of landed), i.e. the DMA of panel p + 1 would have to land before panel p is touched.
-        if (it == 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 + (RES ? 4 : 0)) : "memory");
+        if (it == 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 + (RES ? 4 * (X2_RR - 1) : 0)) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(8 + (RES ? 4 : 0)) : "memory");     // everyone's has landed;
                                                                                // everyone left the stage of panel p - 1
-        if (RES) load_res(valid(p + pstep) ? p + pstep : 0, CUR ^ 1);         // residual of the NEXT panel of this stream
+        if (RES)          // residual of the panel X2_RR - 1 ahead on this stream
+            load_res(valid(p + (X2_RR - 1) * pstep) ? p + (X2_RR - 1) * pstep : 0, (CUR + X2_RR - 1) % X2_RR);
         issue(valid(p + 2 * pstep) ? p + 2 * pstep : npanel, (it + 2) % X2_STAGES);
 
         h_f32x4 acc[2][2];
@@ -258,10 +266,18 @@ __global__ __launch_bounds__(512) void xconv2_kernel(const unsigned short* __res
         }
     };
     int it = 0;
+#if X2_RR == 2
     for (int p = pfirst; valid(p); p += 2 * pstep, it += 2) {            // two panels per trip: ring entries 0, 1
         panel(p, it, std::integral_constant<int, 0>());
         if (valid(p + pstep)) panel(p + pstep, it + 1, std::integral_constant<int, 1>());
     }
+#else
+    for (int p = pfirst; valid(p); p += 3 * pstep, it += 3) {            // three panels per trip: ring entries 0, 1, 2
+        panel(p, it, std::integral_constant<int, 0>());
+        if (valid(p + pstep)) panel(p + pstep, it + 1, std::integral_constant<int, 1>());
+        if (valid(p + 2 * pstep)) panel(p + 2 * pstep, it + 2, std::integral_constant<int, 2>());
+    }
+#endif
 }
 
 static int x2_blocks(int64_t M, int N)
