@@ -246,3 +246,68 @@ def test_graphed_training_step_gradients_bit_equal_to_the_eager_step(tmp_path_fa
     assert not torch.equal(e3[1]["seg_model.backbone.layer3.0.conv2.weight"], e2[1]["seg_model.backbone.layer3.0.conv2.weight"])
     same(e3, g3, "replay after an optimiser step")
     del gsaved
+
+
+# ------------------------------------------------------------------------------------------------ the 128 x 128 tile form
+@pytest.mark.parametrize("shape", [(1, 64, 64, 256, 128), (2, 50, 41, 512, 256), (1, 64, 64, 1024, 256), (1, 72, 64, 128, 512)])
+@pytest.mark.parametrize("fmt_name", ["split", "fp16"])
+def test_tile_kernel_half_tile_form_equals_the_256_row_form(K, shape, fmt_name, monkeypatch):
+    """igemm_kernel.h with BM = 128 (two 4-wave blocks per CU; automatic for 1x1 launches of <= 64 blocks, HIAST_IGEMM_HALF=1 forces
+    it): every launch variant the step uses against the 256-row form on the same operands — outputs bit-equal (the same k order
+    per element), the per-block statistics equal after their reduction — and against float64 for the fused BN + ReLU form;
+    ragged M"""
+    B, H, W, Cin, Cout = shape
+    assert B * H * W >= 4096
+    x = synth.normal_f32(5300, (B, H, W, Cin))
+    w = synth.normal_f32(5301, (Cout, Cin, 1, 1), (2.0 / Cin) ** 0.5)
+    res = synth.normal_f32(5302, (B, H, W, Cout))
+    bn, bnref = _mk_bn(5303, Cout)
+    if fmt_name == "split":
+        PL = 2
+        xp = K.split_planes(dev(x).view(-1, Cin)).view(B, H, W, 2 * Cin)
+        rp = K.split_planes(dev(res).view(-1, Cout)).view(B, H, W, 2 * Cout)
+        wp = K.pack_conv_weight(dev(w), 2)
+        xv, wv = sum(_planes_ref(x)), sum(_planes_ref(w))
+    else:
+        PL = 1
+        xp, rp = dev(x).half(), dev(res).half()
+        wp = K.pack_conv_weight(dev(w), K.FMT_FP16)
+        xv, wv = _r16(x, torch.float16), _r16(w, torch.float16)
+
+    def run(half):
+        monkeypatch.setenv("HIAST_IGEMM_HALF", half)
+        monkeypatch.setenv("HIAST_XCONV", "0")              # (keep the expanding shapes on the tile kernel)
+        monkeypatch.setenv("HIAST_XCONV2", "0")
+        out = {"bn_relu": K.igemm_bn_act(xp, wp, PL, bn, None, True), "bn_res_relu": K.igemm_bn_act(xp, wp, PL, bn, rp, True)}
+        if PL == 1:
+            out["plain"] = K.igemm_bn_act(xp, wp, 1, None, None, False)
+            y, part = K.igemm_bn_act(xp, wp, 1, None, None, False, want_stats=True)
+            out["stats_y"], out["stats"] = y, K.bn_nhwc_stats_from_partial(part)
+            bx = dev(res).half()
+            sm, si = dev(0.1 * synth.normal_f32(5304, (Cout,))), dev(np.abs(synth.normal_f32(5305, (Cout,))) + 0.5)
+            da, bpart = K.igemm_dgrad_bn_stats(xp, wp, 1, bx, None, None, sm, si)
+            out["dgrad"], out["dgrad_sums"] = da, K.bn_nhwc_stats_from_partial(bpart)
+            out["rows"] = (part.shape[0], bpart.shape[0])
+        torch.cuda.synchronize()
+        return out
+
+    full, half = run("0"), run("1")
+    M = B * H * W
+    if PL == 1:
+        assert full["rows"] == ((M + 255) // 256,) * 2 and half["rows"] == ((M + 127) // 128,) * 2
+    for k in full:
+        if k == "rows":
+            continue
+        if k in ("stats", "dgrad_sums"):        # another blocking of the same sums
+            a, b = full[k].double(), half[k].double()
+            assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(a.abs().max())), k
+        else:
+            assert torch.equal(full[k], half[k]), k
+    got = half["bn_relu"]
+    got = (K.merge_planes(got.view(-1, 2 * Cout)) if PL == 2 else got.float()).view(B, H, W, Cout).cpu().numpy()
+    want = _igemm_ref(xv, wv, bnref, None, True, 1, 1, 1)
+    err = np.abs(got - want)
+    if PL == 2:
+        assert float(err.max()) <= 3e-5 * max(1.0, float(np.abs(want).max()))
+    else:
+        assert bool((err <= 2.0 ** -10 * np.abs(want) + 3e-5 * np.abs(want).max()).all())
