@@ -68,7 +68,8 @@ constexpr int IG_BM = 256;
 // the quarter-chip launches only (<= 64 blocks): the pseudo-label generator at the reference's batch size 2 runs 247 -> 271
 // images/s end to end with it.
 #ifndef IG_HALF_AUTO
-#define IG_HALF_AUTO(M, K, N) ((((M) + 255) / 256) * (((N) % 256 == 0) ? (N) / 256 : (N) / 128) <= 64)
+#define IG_HALF_BLOCKS(M, N) ((((M) + 255) / 256) * (((N) % 256 == 0) ? (N) / 256 : (N) / 128))
+#define IG_HALF_AUTO(M, K, N) (IG_HALF_BLOCKS(M, N) <= 64 || ((M) <= 16384 && IG_HALF_BLOCKS(M, N) <= 128))
 #endif
 
 #ifdef IG_STAMP       // diagnostic build (tools/igemm_stamps.py): cycles a wave spends in the parts of a k-step, summed over the loop
@@ -858,6 +859,15 @@ static inline int ig_half_tile(int64_t M, int K, int N, int taps, int out_f32)
     if (const char* e = getenv("HIAST_IGEMM_HALF")) return atoi(e) != 0;
     return IG_HALF_AUTO(M, K, N);
 }
+// ... and the split-plane 3x3 + BN + ReLU launch of the pseudo-label forward in the same form when its 256-row form fills at most a
+// quarter of the chip (the generator at the reference's batch size 2: 64 tiles): stand-alone 144 -> 103 us already at 4 images
+// (profiles/r05_ab_igemm_half_tile.txt); on full-chip launches the form is 20-25 % slower, so never there.
+static inline int ig_half_tile9(int64_t M, int N, int PL, bool bn_relu_only)
+{
+    if (PL != 2 || !bn_relu_only || N % 128 != 0 || M < 4096) return 0;
+    if (const char* e = getenv("HIAST_IGEMM_HALF")) return atoi(e) != 0;
+    return IG_HALF_AUTO(M, 0, N);
+}
 static inline int ig_block_rows(int64_t M, int K, int N, int taps, int out_f32)
 {
     return ig_half_tile(M, K, N, taps, out_f32) ? 128 : hiast::IG_BM;
@@ -880,7 +890,9 @@ static int launch_igemm_t(const void* x, const void* wp, const float* gamma, con
         const int v = atoi(env);
         if ((v == 64 || v == 128 || v == 256) && N % v == 0) BN = v;
     }
-    const bool half = geo.stride >= 0 && ig_half_tile(M, K, N, taps, OUTF32 ? 1 : 0) != 0;
+    const bool half9 = taps == 9 && !OUTF32 && geo.stride == 1 &&
+                       ig_half_tile9(M, N, PL, mean && relu && !res && !stats && !res_gate && stats_mode == 0) != 0;
+    const bool half = half9 || (geo.stride >= 0 && ig_half_tile(M, K, N, taps, OUTF32 ? 1 : 0) != 0);
     if (half) BN = 128;
     const int BMr = half ? 128 : hiast::IG_BM;
     dim3 grid((unsigned)((M + BMr - 1) / BMr), (N + BN - 1) / BN);
@@ -923,7 +935,9 @@ static int launch_igemm_t(const void* x, const void* wp, const float* gamma, con
     } else if (relu) LK(BNV, T, false, true, 0, 0, BMV);                                \
     else if (!stats) LK(BNV, T, false, false, 0, 0, BMV);                               \
     else { LS(BNV, T, BMV) }
-    if (half) {
+    if (half9) {
+        if constexpr (!OUTF32 && PL == 2) LK(128, 9, false, true, 0, 0, 128);
+    } else if (half) {
         if constexpr (!OUTF32) { LL(128, 1, 128) }
     } else if (taps == 1) {
         if (BN == 256) { LL(256, 1, 256) } else if (BN == 128) { LL(128, 1, 256) } else { LL(64, 1, 256) }

@@ -311,3 +311,29 @@ def test_tile_kernel_half_tile_form_equals_the_256_row_form(K, shape, fmt_name, 
         assert float(err.max()) <= 3e-5 * max(1.0, float(np.abs(want).max()))
     else:
         assert bool((err <= 2.0 ** -10 * np.abs(want) + 3e-5 * np.abs(want).max()).all())
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 128, 256, 2), (1, 72, 70, 256, 1), (1, 64, 64, 512, 4), (2, 48, 96, 128, 1)])
+def test_split_plane_3x3_half_tile_form(K, shape, monkeypatch):
+    """the split-plane 3x3 + BN + ReLU launch as 128 x 128 tiles (two blocks per CU; automatic when the 256-row form fills at most a
+    quarter of the chip: the generator at batch 2) — with the early-barrier k-loop in a 4-wave block — bit-equal to the 256-row
+    form and <= 3e-5 of max against float64; ragged M, dilations"""
+    B, H, W, C, dil = shape
+    x = np.maximum(synth.normal_f32(5400, (B, H, W, C)), 0)
+    w = synth.normal_f32(5401, (C, C, 3, 3), (2.0 / (9 * C)) ** 0.5)
+    bn, bnref = _mk_bn(5402, C)
+    xp = K.split_planes(dev(x).view(-1, C)).view(B, H, W, 2 * C)
+    wp = K.pack_conv_weight(dev(w), 2)
+    monkeypatch.setenv("HIAST_IGEMM_HALF", "0")
+    full = K.igemm_bn_act(xp, wp, 2, bn, None, True, 1, dil)
+    monkeypatch.setenv("HIAST_IGEMM_HALF", "1")
+    half = K.igemm_bn_act(xp, wp, 2, bn, None, True, 1, dil)
+    for _ in range(2):
+        assert torch.equal(K.igemm_bn_act(xp, wp, 2, bn, None, True, 1, dil), half)
+    assert torch.equal(full, half)
+    monkeypatch.delenv("HIAST_IGEMM_HALF")
+    auto = K.igemm_bn_act(xp, wp, 2, bn, None, True, 1, dil)          # (whichever form the rule picks)
+    assert torch.equal(auto, full)
+    got = K.merge_planes(half.view(-1, 2 * C)).view(B, H, W, C).cpu().numpy()
+    want = _igemm_ref(sum(_planes_ref(x)), sum(_planes_ref(w)), bnref, None, True, 1, dil, 9)
+    assert float(np.abs(got - want).max()) <= 3e-5 * max(1.0, float(np.abs(want).max()))
