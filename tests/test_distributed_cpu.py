@@ -234,6 +234,17 @@ def _comm_worker(rank, world, port, out):
     ok = ok and bool(torch.equal(s[:, 0], torch.full((7,), float(tri), dtype=torch.float64)))
     ok = ok and bool(torch.equal(s2, s * world))
     ok = ok and bool(torch.equal(h, torch.arange(19 * 11, dtype=torch.int32).view(19, 11) * tri))
+    # counted collectives (round 5): comm.all_reduce reduces on the named communicator and counts per communicator — the
+    # per-step invariant bench.py prints at N > 1 (6 buckets / 208 statistics reduces / 3 auxiliary reduces) is built on this
+    before = dict(comm.COUNTS)
+    a = torch.full((4,), float(rank + 1), dtype=torch.float64)
+    b = torch.full((4,), float(rank + 1), dtype=torch.float64)
+    hnd = comm.all_reduce(a, "stat", async_op=True)
+    comm.all_reduce(b, "aux")
+    comm.all_reduce(b, "aux")
+    hnd.wait()
+    ok = ok and bool((a == tri).all()) and bool((b == tri * world).all())
+    ok = ok and comm.COUNTS["stat"] - before["stat"] == 1 and comm.COUNTS["aux"] - before["aux"] == 2
     # HIAST_COMM_GROUPS=0: everything on the default group (group=None)
     os.environ["HIAST_COMM_GROUPS"] = "0"
     ok = ok and comm.stat_group() is None and comm.aux_group() is None
