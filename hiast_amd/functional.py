@@ -562,14 +562,9 @@ def wgroup_weights(convs, x):
     # ranges: 265 against 300 us) and the 3x3 keeps its own launch (36 tiles x 7 ranges).
     tiles = [(c.in_channels // 256) * (c.out_channels // 256) * c.kernel_size[0] ** 2 for c in convs]
 
-    M = int(x.shape[0] * x.shape[2] * x.shape[3])                      # pixels of the (stride-1) block
-
-    def fill(idx):      # fraction of the 256 CUs one round of (tiles x pixel ranges) blocks occupies — with the cap the plan
-        t = sum(tiles[i] for i in idx)      # itself applies (hiast_conv_wgrad_group_nhwc: at least 512 pixels per range, at
-        if not 0 < t <= 256:                # most 64 ranges): on small maps fewer ranges than 256 // tiles exist
-            return 0.0
-        smax = max(1, min(64, M // 512))
-        return t * min(256 // t, smax) / 256.0
+    def fill(idx):      # fraction of the 256 CUs one round of (tiles x pixel ranges) blocks occupies
+        t = sum(tiles[i] for i in idx)
+        return t * (256 // t) / 256.0 if 0 < t <= 256 else 0.0
     member = list(range(len(convs)))
     if fill(member) < 0.9:
         member = [i for i in member if convs[i].kernel_size[0] == 1]
