@@ -446,8 +446,11 @@ __global__ __launch_bounds__(BM * 2) void igemm_bn_act_kernel(
 #pragma unroll
             for (int a = 0; a < NH; ++a) {
                 const int cur = a & 1;
+                IG_T(h0_);
                 if (a == 0) ig_lds_wait_n<6>(fa[0], fb[0]);     // outstanding: B tiles 1..3 (issue order: A tile 0, B tiles 0..3)
                 else ig_lds_wait_n<0>(fa[cur]);
+                IG_T(h1_);
+                if (a == 0) { IG_ACC(2, h0_, h1_); }            // (diagnostic build: cycles waiting for the prefetched first fragments)
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_tile(fa[cur], fb[0], acc4[a][0]);
                 __builtin_amdgcn_sched_barrier(0);
@@ -470,7 +473,10 @@ __global__ __launch_bounds__(BM * 2) void igemm_bn_act_kernel(
         // everyone's; everyone has finished step kt - 1: its A stage and the B stage of step kt are free.  Then the fragment
         // wait of tile NH: behind it nothing is in flight (the back edge)
         auto mid = [&](int kt) __attribute__((always_inline)) {
+            IG_T(m0_);
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            IG_T(m1_);
+            IG_ACC(0, m0_, m1_);                            // (diagnostic build: cycles in the mid-step wait + barrier)
             if (HOIST && kt == nk - 1) {
 #pragma unroll
                 for (int r = 0; r < (RD < TM ? RD : TM); ++r) load_res(r);
