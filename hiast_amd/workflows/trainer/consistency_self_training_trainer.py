@@ -75,8 +75,16 @@ class GraphedTrainStep:
             tr.g_optimizer.zero_grad(set_to_none=True)        # the graph's backward allocates the (from now on static) gradients
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                losses = self._run(self.s_weak, self.s_strong, self.s_plbl)
+            try:
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    losses = self._run(self.s_weak, self.s_strong, self.s_plbl)
+            except Exception as e:      # a capture that cannot be made (an op that synchronises, a foreign stream): say so ONCE
+                import warnings         # and keep training — the same launches, issued eagerly from here on
+                warnings.warn("GraphedTrainStep: capture failed (%r); the iterations stay eager" % (e,))
+                tr._graph_train = False
+                torch.cuda.synchronize()
+                tr.g_optimizer.zero_grad(set_to_none=True)
+                return self._run(weak, strong, plbl)
             self.graph = g
             self.losses = {k: v.detach() for k, v in losses.items()}
         else:
