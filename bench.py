@@ -160,7 +160,7 @@ def roofline_of(key, avg_ms, n, steps):
         partial = 2.0 * tiles * (256 // tiles) * 256 * 256 * 4        # written by the blocks, read by the reduction
         ach = flop / (avg_ms * 1e-3) / 1e12
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r04_pmc_igemm.json")
+        pmc = os.path.join(ROOT, "profiles", "r05_pmc_igemm.json")
         if os.path.exists(pmc) and sorted(tuple(j) for j in key[1:]) == sorted([((8, 64, 128, 1024), 256, 1),
                                                                                  ((8, 64, 128, 256), 256, 3),
                                                                                  ((8, 64, 128, 256), 1024, 1)]):
@@ -210,7 +210,7 @@ def roofline_of(key, avg_ms, n, steps):
     peak = 2500.0 / 3.0 if PL == 2 else 2500.0
     alg_bytes = (B * Hh * Ww * CC + Cout * taps * CC) * 2 + M * Cout * (4 if out_f32 else 2 * PL) * (2 if has_res else 1)
     traffic = traffic_source = None
-    for pmc in ("r04_pmc_igemm.json", "r03_pmc_igemm.json", "r02_pmc_igemm.json"):       # (the newest collection that has this launch shape)
+    for pmc in ("r05_pmc_igemm.json", "r04_pmc_igemm.json", "r03_pmc_igemm.json", "r02_pmc_igemm.json"):       # (the newest collection that has this launch shape)
         path = os.path.join(ROOT, "profiles", pmc)
         if traffic is None and os.path.exists(path):
             for ent in json.load(open(path)).get("kernels", []):
