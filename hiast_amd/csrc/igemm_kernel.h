@@ -69,7 +69,9 @@ constexpr int IG_BM = 256;
 // images/s end to end with it.
 #ifndef IG_HALF_AUTO
 #define IG_HALF_BLOCKS(M, N) ((((M) + 255) / 256) * (((N) % 256 == 0) ? (N) / 256 : (N) / 128))
-#define IG_HALF_AUTO(M, K, N) (IG_HALF_BLOCKS(M, N) <= 64 || ((M) <= 16384 && IG_HALF_BLOCKS(M, N) <= 128))
+// (half-chip launches too — unless the caller runs two launch sequences side by side: HIAST_IGEMM_COSCHED=1, set by
+// functional.eval_forward_split around its sub-batches; two half-chip launches on two streams already fill the chip)
+#define IG_HALF_AUTO(M, K, N) (IG_HALF_BLOCKS(M, N) <= 64 || (IG_HALF_BLOCKS(M, N) <= 128 && !ig_cosched()))
 #endif
 
 #ifdef IG_STAMP       // diagnostic build (tools/igemm_stamps.py): cycles a wave spends in the parts of a k-step, summed over the loop
@@ -857,6 +859,11 @@ __global__ __launch_bounds__(BM * 2) void igemm_bn_act_kernel(
 // callers that size the per-block statistics buffers (hiast_igemm_stats_rows, hiast_igemm_dgrad_bn_stats_rows).
 // HIAST_IGEMM_HALF=0 / 1: never / every 1x1 launch with N % 128 == 0 (A/B and tests); unset: the HBM-bound shapes measured faster
 // (profiles/r05_ab_igemm_half_tile.txt).
+static inline int ig_cosched()
+{
+    const char* e = getenv("HIAST_IGEMM_COSCHED");
+    return e && atoi(e) != 0;
+}
 static inline int ig_half_tile(int64_t M, int K, int N, int taps, int out_f32)
 {
     // (1x1 only: on the 3x3 launches the form was measured 20-25 % slower wherever the 256-row form fills the chip — twice the

@@ -674,11 +674,21 @@ def eval_forward_split(model, x, parts=None):
         side = _eval_streams[key] = [torch.cuda.Stream(device=x.device) for _ in range(parts - 1)]
     sub = B // parts
     outs = [None] * parts
-    for i, st in enumerate(side):
-        st.wait_stream(main)
-        with torch.cuda.stream(st):
-            outs[i + 1] = model(x[(i + 1) * sub:(i + 2) * sub], lowres=True)
-    outs[0] = model(x[:sub], lowres=True)
+    # the sub-batch launches run side by side: tell the tile kernel's launcher (it would otherwise give a half-chip launch the
+    # 128 x 128 / two-blocks-per-CU form, which wins on a launch that runs ALONE: igemm_kernel.h, IG_HALF_AUTO)
+    prev = os.environ.get("HIAST_IGEMM_COSCHED")
+    os.environ["HIAST_IGEMM_COSCHED"] = "1"
+    try:
+        for i, st in enumerate(side):
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                outs[i + 1] = model(x[(i + 1) * sub:(i + 2) * sub], lowres=True)
+        outs[0] = model(x[:sub], lowres=True)
+    finally:
+        if prev is None:
+            del os.environ["HIAST_IGEMM_COSCHED"]
+        else:
+            os.environ["HIAST_IGEMM_COSCHED"] = prev
     for i, st in enumerate(side):
         main.wait_stream(st)
         outs[i + 1]["logits_lowres"].record_stream(main)
