@@ -337,3 +337,28 @@ def test_split_plane_3x3_half_tile_form(K, shape, monkeypatch):
     got = K.merge_planes(half.view(-1, 2 * C)).view(B, H, W, C).cpu().numpy()
     want = _igemm_ref(sum(_planes_ref(x)), sum(_planes_ref(w)), bnref, None, True, 1, dil, 9)
     assert float(np.abs(got - want).max()) <= 3e-5 * max(1.0, float(np.abs(want).max()))
+
+
+# ------------------------------------------------------------------------------------------------ the early-barrier k-loop
+@pytest.mark.parametrize("shape", [(8, 64, 128, 256, 2), (2, 37, 53, 512, 4), (1, 64, 64, 128, 1), (3, 24, 40, 64, 1)])
+def test_early_barrier_loop_is_repeatable_and_exact(K, shape):
+    """the split-plane 3x3 launches run the early-barrier k-loop (igemm_kernel.h: the barrier of a k-step in the middle of the
+    previous one, first fragments prefetched through the fragment rings, two-step B prefetch on two stages): 40 back-to-back
+    launches per shape — full-chip, ragged, 128- and 64-column tiles — give one bit pattern (a stage overwritten early or read
+    before it landed would not), and that pattern is within 3e-5 of max of float64"""
+    B, H, W, C, dil = shape
+    x = np.maximum(synth.normal_f32(5500, (B, H, W, C)), 0)
+    w = synth.normal_f32(5501, (C, C, 3, 3), (2.0 / (9 * C)) ** 0.5)
+    bn, bnref = _mk_bn(5502, C)
+    xp = K.split_planes(dev(x).view(-1, C)).view(B, H, W, 2 * C)
+    wp = K.pack_conv_weight(dev(w), 2)
+    first = K.igemm_bn_act(xp, wp, 2, bn, None, True, 1, dil)
+    other = torch.randn(1 << 22, device="cuda")            # (different kernels in between: LDS and caches do not stay warm)
+    for i in range(40):
+        if i % 8 == 0:
+            other = other * 1.0001
+        assert torch.equal(K.igemm_bn_act(xp, wp, 2, bn, None, True, 1, dil), first), i
+    if B * H * W <= 16384:
+        got = K.merge_planes(first.view(-1, 2 * C)).view(B, H, W, C).cpu().numpy()
+        want = _igemm_ref(sum(_planes_ref(x)), sum(_planes_ref(w)), bnref, None, True, 1, dil, 9)
+        assert float(np.abs(got - want).max()) <= 3e-5 * max(1.0, float(np.abs(want).max()))
