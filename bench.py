@@ -59,6 +59,10 @@ def parse():
     p.add_argument("--amp-dtype", default=os.environ.get("HIAST_BENCH_AMP", "fp16"), choices=["bf16", "fp16"],
                    help="16-bit type of the mixed-precision training step: fp16 = the reference's apex-O1 arithmetic (dynamic "
                         "loss scaling, handled on the device), bf16 = no loss scaling; both run on the same hand-written kernels")
+    p.add_argument("--watchdog-s", type=float, default=float(os.environ.get("HIAST_BENCH_WATCHDOG_S", "300")),
+                   help="seconds without progress (a finished stage / step) after which a rank prints a diagnostic JSON line "
+                        "(rank 0: on stdout, in place of the result) and exits with code 3 — a hung collective must not burn a "
+                        "whole GPU lease and return nothing; 0 = off")
     p.add_argument("--trainer", default="ConsistencySelfTrainingTrainer",
                    choices=["ConsistencySelfTrainingTrainer", "SelfTrainingTrainer"])
     return p.parse_args()
@@ -210,16 +214,23 @@ def roofline_of(key, avg_ms, n, steps):
     peak = 2500.0 / 3.0 if PL == 2 else 2500.0
     alg_bytes = (B * Hh * Ww * CC + Cout * taps * CC) * 2 + M * Cout * (4 if out_f32 else 2 * PL) * (2 if has_res else 1)
     traffic = traffic_source = None
-    for pmc in ("r05_pmc_igemm.json", "r04_pmc_igemm.json", "r03_pmc_igemm.json", "r02_pmc_igemm.json"):       # (the newest collection that has this launch shape)
+    traffic_stale = None
+    for pmc in ("r06_pmc_igemm.json", "r05_pmc_igemm.json", "r04_pmc_igemm.json", "r03_pmc_igemm.json", "r02_pmc_igemm.json"):       # (the newest collection that has this launch shape)
         path = os.path.join(ROOT, "profiles", pmc)
         if traffic is None and os.path.exists(path):
-            for ent in json.load(open(path)).get("kernels", []):
+            doc = json.load(open(path))
+            for ent in doc.get("kernels", []):
                 if ent.get("key") == [B, Hh, Ww, Cin, Cout, taps, PL, dil]:
                     traffic = ent["hbm_bytes_per_launch"]
+                    # collected on THESE kernel sources?  (files of earlier rounds carry no fingerprint: another build)
+                    from hiast_amd import _lib as _L
+                    traffic_stale = doc.get("kernel_sources_sha16") != _L.kernel_sources_sha16()
                     # NOT measured in this run: PMC counters need their own rocprofv3 --pmc passes (tools/pmc_igemm.sh)
                     traffic_source = ("profiles/%s (round %s: separate rocprofv3 --pmc passes over this launch shape, "
                                       "(2*FETCH_SIZE + WRITE_SIZE)*1024 per dispatch; read from the file, not collected by "
-                                      "this bench run)" % (pmc, pmc[2]))
+                                      "this bench run%s)" % (pmc, pmc[2], "; STALE: collected on a build of other kernel "
+                                                             "sources than the running library" if traffic_stale else
+                                                             "; same kernel sources as the running library"))
     is_xconv = (PL == 1 and taps == 1 and Cin == 256 and Cout % 512 == 0 and not out_f32 and M >= 4096
                 and os.environ.get("HIAST_XCONV", "1") != "0" and not (has_bn and has_res and not relu))
     is_xconv2 = (PL == 2 and taps == 1 and Cin == 256 and Cout % 256 == 0 and not out_f32 and M >= 4096 and has_bn
@@ -244,7 +255,7 @@ def roofline_of(key, avg_ms, n, steps):
     # both conventions, side by side: issued MFMA flops (3 per algorithmic flop on split planes) and algorithmic flops, each
     # against the plain dense 16-bit peak of 2500 TFLOP/s
     fracs = {"frac_issued": ach * (3.0 if PL == 2 else 1.0) / 2500.0, "frac_algorithmic_vs_dense": ach / 2500.0,
-             "traffic_source": traffic_source}
+             "traffic_source": traffic_source, "traffic_stale": traffic_stale}
     if f_hbm > f_mfma:
         return {"kernel": name, "bound": "hbm", "achieved": hbm_tbs * 1e3, "peak": 8000.0, "unit": "GB/s", "frac": f_hbm,
                 **fracs, "traffic": traffic, "avg_launch_ms": avg_ms, "launches_per_step": n / steps,
@@ -256,6 +267,48 @@ def roofline_of(key, avg_ms, n, steps):
             **fracs, "traffic": traffic, "avg_launch_ms": avg_ms, "launches_per_step": n / steps,
             "note": "algorithmic %.1f GFLOP per launch (%s); %s; algorithmic HBM bytes per launch %.0f MB -> %.2f TB/s = "
                     "%.0f%% of the 8 TB/s HBM roof" % (flop / 1e9, shape, flavour, alg_bytes / 1e6, hbm_tbs, 100.0 * f_hbm)}
+
+
+def step_fractions(groups, ms_per_step, serial_step_ms):
+    """step-level figures that travel with the line: matrix-pipe and HBM use of the WHOLE step.
+    Flops: counted live from the convolution launches the first timed step observed (every igemm / xconv / grouped weight-
+    gradient / ASPP launch with its shape: 3 issued bf16 products per algorithmic flop on split planes) — the stems, the
+    small-channel weight gradients and the loss are not hooked (< 2 % of the step's flops).  HBM bytes and the serial kernel
+    time need their own profiler passes (tools/pmc_bench.sh, tools/prof_bench.sh): read from profiles/r06_step_totals.json when it
+    was collected on these kernel sources, else null."""
+    alg = iss = 0.0
+    for key, _avg, n, _tot in groups:
+        if key[0] == "igemm":
+            B, Hh, Ww, CC = key[1]
+            Cout, taps, _ = key[2]
+            PL, stride = key[3], key[4]
+            Ho, Wo = (Hh, Ww) if taps == 1 else ((Hh - 1) // stride + 1, (Ww - 1) // stride + 1)
+            f = 2.0 * B * Ho * Wo * taps * (CC // PL) * Cout * n
+            alg += f
+            iss += f * (3.0 if PL == 2 else 1.0)
+        elif key[0] == "wgrad_group":
+            f = sum(2.0 * j[0][0] * j[0][1] * j[0][2] * j[0][3] * j[1] * j[2] ** 2 for j in key[1:]) * n
+            alg += f
+            iss += f
+        # ("aspp2_fwd": its tap GEMM is an igemm launch and counted there; "aspp_fwd": the exact-fp32 head is not on the step)
+    out = {"step_tflop_algorithmic_counted": alg / 1e12, "step_tflop_issued_counted": iss / 1e12,
+           "step_frac_mfma_issued": iss / (ms_per_step * 1e-3) / 2.5e15,
+           "step_frac_mfma_algorithmic": alg / (ms_per_step * 1e-3) / 2.5e15,
+           "serial_step_ms": serial_step_ms,
+           "step_frac_hbm": None, "serial_kernel_ms": None, "dispatches_per_step": None, "step_totals_source": None}
+    path = os.path.join(ROOT, "profiles", "r06_step_totals.json")
+    if os.path.exists(path):
+        from hiast_amd import _lib as _L
+        doc = json.load(open(path))
+        stale = doc.get("kernel_sources_sha16") != _L.kernel_sources_sha16()
+        out["step_frac_hbm"] = doc["hbm_gb_per_step"] * 1e9 / (ms_per_step * 1e-3) / 8e12
+        out["step_hbm_gb"] = doc["hbm_gb_per_step"]
+        out["serial_kernel_ms"] = doc.get("serial_kernel_ms")
+        out["dispatches_per_step"] = doc.get("dispatches_per_step")
+        out["step_totals_source"] = "profiles/r06_step_totals.json (%s)%s" % (
+            doc.get("source", "?"), "; STALE: collected on other kernel sources" if stale else "; same kernel sources")
+        out["step_totals_stale"] = stale
+    return out
 
 
 class HotPath:
@@ -282,7 +335,8 @@ class HotPath:
             for p in self.ema.parameters():
                 p.requires_grad = False
             self.ema_updater = utils.EmaUpdater()
-            self.side = torch.cuda.Stream(device=device)
+            from hiast_amd import functional as HF
+            self.side = HF.new_stream(device)
         self.use_side = True
         from hiast_amd import functional as HF
         HF.enable_wgrad_overlap(True)       # train_step() joins the side stream before the optimiser step
@@ -400,7 +454,8 @@ class HotPath:
         if not (self.pipelined and self.use_side and os.environ.get("HIAST_BENCH_PL_STREAM", "1") != "0"):
             return self.plabel_begin()
         if not hasattr(self, "_pl_stream"):
-            self._pl_stream = torch.cuda.Stream(device=self.device)
+            from hiast_amd import functional as HF
+            self._pl_stream = HF.new_stream(self.device)
         self._pl_stream.wait_stream(torch.cuda.current_stream())
         self._pl_on_side = True
         try:
@@ -630,6 +685,56 @@ def cpu_baseline(cfg, size, threads, batch=2, reps=3):
                          info["cores_per_socket"], info["usable"])}
 
 
+class Watchdog:
+    """A daemon THREAD of this rank (never a re-exec: the process has touched the GPU): `beat(stage)` after every finished
+    stage / step; `limit` seconds without a beat -> every rank says on stderr where it stands (stage, step, collectives issued
+    so far per communicator against the expected 6 / 208 / 3 per step), rank 0 writes ONE diagnostic JSON line to the stdout
+    descriptor (value null, "error") and the process ends with exit code 3 (os._exit: a main thread parked inside a collective
+    cannot be unwound).  torch.distributed.run then takes the other ranks down."""
+
+    def __init__(self, limit, rank, world, json_out, args):
+        import threading
+        self.limit, self.rank, self.world, self.json_out, self.args = limit, rank, world, json_out, args
+        self.stage, self.t_beat, self.t0, self.done = "start", time.monotonic(), time.monotonic(), False
+        self.extra = {}
+        if limit > 0:
+            threading.Thread(target=self._run, name="hiast-bench-watchdog", daemon=True).start()
+
+    def beat(self, stage, **extra):
+        self.stage, self.t_beat = stage, time.monotonic()
+        self.extra.update(extra)
+
+    def stop(self):
+        self.done = True
+
+    def diagnostic(self):
+        from hiast_amd.utils import comm
+        return {"metric": "self-training images/sec (fwd+bwd+pseudo-label) at 1024x512", "value": None, "unit": "images/s",
+                "n_gpus": self.world, "steps": self.args.steps, "warmup": self.args.warmup, "ms_per_step": None,
+                "higher_is_better": True, "error": "watchdog: no progress for %.0f s" % (time.monotonic() - self.t_beat),
+                "watchdog": {"rank": self.rank, "stage": self.stage, "seconds_since_start": time.monotonic() - self.t0,
+                             "limit_s": self.limit, "backend": self.args.backend,
+                             "collectives_issued": dict(comm.COUNTS), "collective_host_s": dict(comm.HOST_S),
+                             "expected_per_step": {"gradient_buckets": 6, "syncbn_stat_all_reduces": 208,
+                                                   "pseudo_label_aux_all_reduces": 3},
+                             "dist_timeout_s": comm.timeout().total_seconds(), **self.extra}}
+
+    def _run(self):
+        while not self.done:
+            time.sleep(1.0)
+            if self.done or time.monotonic() - self.t_beat < self.limit:
+                continue
+            d = self.diagnostic()
+            print("[bench watchdog] rank %d: %s" % (self.rank, json.dumps(d["watchdog"])), file=sys.stderr, flush=True)
+            if self.rank == 0:
+                try:
+                    self.json_out.write(json.dumps(d) + "\n")
+                    self.json_out.flush()
+                except Exception:
+                    pass
+            os._exit(3)
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (the reference's train.py does the
     same with mp.spawn, code/train.py:52-59,82) as ONE torch.distributed.run child — before this process has made any
@@ -673,12 +778,17 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    dog = Watchdog(args.watchdog_s, rank, world, json_out, args)
+    from hiast_amd.utils import comm
     if world > 1:
         # (no device_id: communicators are then created lazily by ncclCommInitRank at the first collective of each group —
         # the oldest and most exercised path of torch's RCCL backend — instead of eagerly + ncclCommSplit for new groups)
-        dist.init_process_group(backend=args.backend)
-        from hiast_amd.utils import comm
-        comm.setup()        # SyncBN sums and the histogram exchange get communicators of their own, beside DDP's
+        # timeout = HIAST_DIST_TIMEOUT_S (180 s): a collective one rank never joins raises instead of hanging for 10-30 minutes;
+        # SyncBN sums and the histogram exchange get communicators of their own, beside DDP's (comm.setup inside)
+        comm.init_process_group(args.backend)
+        dog.beat("process group up")
+    # HIAST_RESERVE_CUS=n (N > 1; HIAST_RESERVE_CUS_FORCE=1: also here): the main stream and every side stream leave n CUs alone
+    cu_reserve = comm.apply_cu_reserve(world, device)
     torch.backends.cudnn.benchmark = bool(int(os.environ.get("HIAST_MIOPEN_FIND", "0")))
 
     cfg = make_cfg(world, args.trainer, args.amp_dtype)
@@ -687,6 +797,7 @@ def main():
         from hiast_amd.utils import utils as _u
         _u.limit_cpu_threads()      # (N ranks per node: N OpenMP pools sized for the whole machine otherwise)
         hp = HotPath(cfg, device, rank, world, args.batch)   # must not precede the ONE JSON line on stdout
+    dog.beat("model built")
     timer = KernelTimer()
     timer.install()
 
@@ -706,6 +817,9 @@ def main():
         hp.use_side = not serial
         HF.enable_wgrad_overlap(not serial)
         hp.step()
+        if world > 1 or it == 0:
+            torch.cuda.synchronize()        # (the first step of a rank compiles nothing but loads ~200 code objects; at N > 1
+        dog.beat("warm-up step %d of %d" % (it + 1, args.warmup))      # every warm-up step is a checkpoint of the watchdog)
     hp.use_side = True
     HF.enable_wgrad_overlap(True)
     sync()
@@ -717,6 +831,7 @@ def main():
         while settle < 40 and clean < 6:        # until six consecutive steps have been applied at the current scale
             before = hp.opt.applied_steps()
             hp.step()
+            dog.beat("loss-scale settle step %d" % (settle + 1))
             settle += 1
             clean = clean + 1 if hp.opt.applied_steps() == before + 1 else 0
         sync()
@@ -732,7 +847,7 @@ def main():
     marker()
     timer.on = True
     from hiast_amd.utils import comm as _comm
-    coll_before = dict(_comm.COUNTS)
+    coll_before, coll_host_before = dict(_comm.COUNTS), dict(_comm.HOST_S)
     # phases are timed with HIP events on the launch stream: no host synchronisation inside the timed region (the only
     # blocking point is the histogram read-back the IAS threshold update needs), so consecutive steps pipeline
     marks, host_parts = [], []
@@ -749,7 +864,9 @@ def main():
         marks.append(e)
         if not timer.on:
             host_parts.append([1e3 * (hp.host_marks[i + 1] - hp.host_marks[i]) for i in range(4)])
+        dog.beat("timed step %d of %d enqueued" % (it + 1, args.steps))
     sync()
+    dog.beat("timed region done")
     elapsed = time.perf_counter() - t0
     # collectives issued per step and communicator inside the timed region (host-side counters; the reducer's own bucket count)
     collectives = None
@@ -757,6 +874,11 @@ def main():
         collectives = {"syncbn_stat_all_reduces": (_comm.COUNTS["stat"] - coll_before["stat"]) / float(args.steps),
                        "pseudo_label_aux_all_reduces": (_comm.COUNTS["aux"] - coll_before["aux"]) / float(args.steps),
                        "gradient_buckets": None,
+                       # host time inside the all_reduce / wait calls of each communicator (DESIGN §7 budgets 208 x 20-40 us on
+                       # the statistics group); DDP's bucket reduces are issued by the reducer's C++ hooks: not timed here
+                       "host_ms_per_step": {k: 1e3 * (_comm.HOST_S[k] - coll_host_before[k]) / float(args.steps)
+                                            for k in ("stat", "aux")},
+                       "cu_reserve": cu_reserve,
                        "expected": {"syncbn_stat_all_reduces": 2 * sum(1 for m in hp.model.modules()
                                                                        if isinstance(m, torch.nn.SyncBatchNorm)),
                                     "pseudo_label_aux_all_reduces": 3}}
@@ -826,7 +948,7 @@ def main():
                        "images_per_gpu_per_step": args.batch, "num_classes": C,
                        "batch_semantics": ("reference_bs%d: global batch split over the ranks + SyncBN (code/train.py:52-53)"
                                            % args.global_batch if args.global_batch else "per-GPU batch (weak scaling)"),
-                       "parallelism": "dp%d" % world if world > 1 else "single"},
+                       "parallelism": "dp%d" % world if world > 1 else "single", "cu_reserve": cu_reserve},
             "phases_ms": {"pseudo_label": 1e3 * t_pl / args.steps, "train_step": 1e3 * t_tr / args.steps,
                           "note": "of the first timed step, which runs every part in order on one stream (per-launch "
                                   "events); the other steps overlap the parts on four streams"},
@@ -842,6 +964,7 @@ def main():
                                         [float(v) for v in np.mean(np.array(host_parts), axis=0)])) if host_parts else None,
         }
         groups = timer.summary()
+        groups_all = list(groups)
         if groups:
             sampled = 1                                  # steps on which launches were timed
             aspp = [g for g in groups if g[0][0] == "aspp2_fwd"]
@@ -854,7 +977,9 @@ def main():
                                                             "frac_algorithmic_vs_dense", "traffic", "traffic_source",
                                                             "avg_launch_ms", "launches_per_step", "note") if kk in o}
                                      for o in others]
+        out.update(step_fractions(groups_all, 1e3 * elapsed / args.steps, 1e3 * (t_pl + t_tr) / args.steps))
         if not args.no_cpu_baseline and world == 1:
+            dog.stop()          # (the CPU baseline reports its own progress on stderr)
             try:
                 with contextlib.redirect_stdout(sys.stderr):
                     out["cpu_baseline"] = cpu_baseline(cfg, tuple(args.cpu_size), args.cpu_threads, reps=args.cpu_reps)
@@ -862,6 +987,7 @@ def main():
                 out["cpu_baseline"] = {"error": repr(e)}
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
+    dog.stop()
     if world > 1:
         dist.barrier(device_ids=[local]) if args.backend == "nccl" else dist.barrier()
         dist.destroy_process_group()

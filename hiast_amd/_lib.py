@@ -51,11 +51,16 @@ SIGNATURES = {
     "hiast_bn_act_bwd_apply": (c_int, [c_vp] * 7 + [c_int, ctypes.c_double, c_int, c_vp, c_vp, c_vp, c_vp,
                                        c_int, c_int, c_i64, c_int, c_vp]),
     "hiast_bn_act_nhwc_infer": (c_int, [c_vp] * 6 + [c_f32, c_int, c_i64, c_int, c_int, c_vp]),
-    "hiast_igemm_bn_act": (c_int, [c_vp] * 6 + [c_f32, c_vp, c_int, c_vp] + [c_int] * 10 + [c_vp, c_vp, c_int, c_vp]),
-    "hiast_bottleneck_tail_ok": (c_int, [c_int] * 7),
-    "hiast_bottleneck_tail": (c_int, [c_vp] * 6 + [c_f32] + [c_vp] * 5 + [c_f32, c_vp, c_vp] + [c_int] * 7 + [c_vp]),
+    "hiast_igemm_bn_act": (c_int, [c_vp] * 6 + [c_f32, c_vp, c_int, c_vp] + [c_int] * 10 + [c_vp, c_int, c_vp, c_int, c_vp]),
+    "hiast_igemm_set_cosched": (c_int, [c_int]),
+    "hiast_igemm_set_half": (c_int, [c_int]),
+    "hiast_device_cus": (c_int, []),
+    "hiast_set_reserve_cus": (c_int, [c_int]),
+    "hiast_get_reserve_cus": (c_int, []),
+    "hiast_stream_create_reserved": (c_int, [c_vp, c_int]),
+    "hiast_stream_destroy": (c_int, [c_vp]),
     "hiast_igemm_stats_rows": (c_int, [c_i64, c_int, c_int, c_int, c_int]),
-    "hiast_igemm_dgrad_bn_stats": (c_int, [c_vp, c_vp, c_vp] + [c_int] * 7 + [c_vp] * 6 + [c_int, c_vp]),
+    "hiast_igemm_dgrad_bn_stats": (c_int, [c_vp, c_vp, c_vp] + [c_int] * 7 + [c_vp] * 6 + [c_int, c_int, c_vp]),
     "hiast_xconv_dgrad_gated_bn_stats_rows": (c_int, [c_i64, c_int, c_int]),
     "hiast_xconv_dgrad_gated_bn_stats": (c_int, [c_vp] * 10 + [c_i64, c_int, c_int, c_int, c_vp]),
     "hiast_igemm_dgrad_s2": (c_int, [c_vp, c_vp, c_vp] + [c_int] * 6 + [c_vp]),
@@ -131,10 +136,25 @@ def load():
             raise HiastLibraryError("libhiast_hip.so does not export %s" % name) from e
         fn.restype = res
         fn.argtypes = args
-    if lib.hiast_version() != 5:
+    if lib.hiast_version() != 6:
         raise HiastLibraryError("libhiast_hip.so ABI version mismatch")
     _lib = lib
     return lib
+
+
+def kernel_sources_sha16():
+    """fingerprint of the kernel sources the library is built from (hiast_amd/csrc/*.hip, *.h + the ABI header): what a
+    counter collection (tools/pmc_to_json.py) records, and what bench.py compares before it quotes bytes measured on
+    another build (`roofline.traffic` read from a file of an earlier tree)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")))
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "hiast_hip.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def check(code, what):

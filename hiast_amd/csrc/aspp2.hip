@@ -25,7 +25,7 @@ int hiast_gemm_nt_launch(const void* x, const float* w, void* y, int64_t M, int 
 int hiast_igemm_launch(const void* x, const void* wp, const float* gamma, const float* beta, const float* mean,
                        const float* var, float eps, const void* res, int relu, void* y, int64_t M, int K, int N,
                        int taps, int H, int W, int stride, int dil, int planes, int out_f32, hipStream_t st,
-                       float* stats, const void* res_gate, int gate_mask);
+                       float* stats, const void* res_gate, int gate_mask, int stats_rows);
 
 namespace hiast {
 
@@ -407,7 +407,7 @@ extern "C" int hiast_aspp2_fwd(const void* x_nhwc, int dtype, const void* wt, co
         e = hiast_gemm_nt_launch(x_nhwc, (const float*)wt, T, M, Cin, NP, 0, st);
     else                 // bf16 rows (1) / split planes (2) / fp16 rows (3), weights packed by hiast_pack_conv_weight: LDS-DMA kernel
         e = hiast_igemm_launch(x_nhwc, wt, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, 0, T, M, Cin, NP, 1, 0, 0,
-                               1, 1, dtype, t16 ? 0 : 1, st, nullptr, nullptr, 0);
+                               1, 1, dtype, t16 ? 0 : 1, st, nullptr, nullptr, 0, 0);
     if (e) return e;
     const hiast::Taps2 taps = hiast::make_taps2(dil);
     const dim3 grid((h * w + 63) / 64, B);
@@ -451,7 +451,7 @@ extern "C" int hiast_aspp2_bwd(const void* x_nhwc, const float* dy, const void* 
     if (dx_nhwc) {
         // dX[M][Cin] = G[M][NP] * wd[Cin][NP]^T, wd packed bf16 (hiast_pack_conv_weight, planes = 1)
         e = hiast_igemm_launch(G, wd, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, 0, dx_nhwc, M, NP, Cin, 1, 0, 0, 1,
-                               1, fmt, 0, st, nullptr, nullptr, 0);
+                               1, fmt, 0, st, nullptr, nullptr, 0, 0);
         if (e) return e;
     }
     if (want_w) {

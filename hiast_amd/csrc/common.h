@@ -24,6 +24,13 @@
 static inline int hiast_fmt_planes(int fmt) { return fmt == HIAST_FMT_SPLIT_BF16 ? 2 : 1; }
 static inline int hiast_fmt_ok(int fmt) { return fmt == HIAST_FMT_BF16 || fmt == HIAST_FMT_SPLIT_BF16 || fmt == HIAST_FMT_FP16; }
 
+// ---- device geometry (host; misc.hip).  hiast_cu_count(): compute units of the CURRENT device (hipDeviceGetAttribute, cached per
+// device; 256 on MI355X).  hiast_grid_cus(): what the one-block-per-CU and persistent launches size their grids (and their
+// one-round work splits) to = CU count - hiast_set_reserve_cus(): with n CUs reserved a collective's kernel (RCCL) always finds a
+// CU that no block of ours holds for 60-160 us.  Both never return less than 8.
+int hiast_cu_count();
+int hiast_grid_cus();
+
 namespace hiast {
 
 // ---- the two 16-bit storage types of the mixed-precision path (operand format HIAST_FMT_BF16 / HIAST_FMT_FP16) ----------

@@ -186,6 +186,39 @@ __global__ __launch_bounds__(256) void from_planes_kernel(const unsigned short* 
 
 }  // namespace hiast
 
+// tuning variables of the tile kernel, read once per process; the co-scheduling hint of the calling thread (igemm_kernel.h)
+const IgEnv& hiast_ig_env()
+{
+    static const IgEnv env = [] {
+        IgEnv e;
+        const char* v = getenv("HIAST_IGEMM_HALF");
+        e.half = v ? (atoi(v) != 0) : -1;
+        v = getenv("HIAST_IGEMM_BN");
+        const int bn = v ? atoi(v) : 0;
+        e.bn = (bn == 64 || bn == 128 || bn == 256) ? bn : 0;
+        e.ragged_off = getenv("HIAST_IGEMM_RAGGED") != nullptr;
+        v = getenv("HIAST_IGEMM_COSCHED");
+        e.cosched0 = v && atoi(v) != 0;
+        return e;
+    }();
+    return env;
+}
+static thread_local int ig_cosched_tls = -1, ig_half_tls = -1;
+int hiast_ig_cosched_tls_get() { return ig_cosched_tls; }
+int hiast_ig_half_tls_get() { return ig_half_tls; }
+extern "C" int hiast_igemm_set_half(int v)
+{
+    const int prev = ig_half_tls;
+    ig_half_tls = v < 0 ? -1 : (v != 0);
+    return prev;
+}
+extern "C" int hiast_igemm_set_cosched(int on)
+{
+    const int prev = ig_cosched_tls;
+    ig_cosched_tls = on < 0 ? -1 : (on != 0);
+    return prev;
+}
+
 // K9e (xconv.hip): register-resident-weight kernel for the HBM-bound expanding 1x1 shapes
 int hiast_xconv_ok(int64_t M, int K, int N, int planes, int taps, int out_f32, int has_bn, int has_res, int relu,
                    int has_gate, int gate_mask, int has_stats);
@@ -202,14 +235,14 @@ int hiast_xconv2_launch(const void* x, const void* wp, const float* gamma, const
 int hiast_igemm_launch_f16(const void* x, const void* wp, const float* gamma, const float* beta, const float* mean,
                            const float* var, float eps, const void* res, int relu, void* y, int64_t M, int K, int N, int taps,
                            hiast::IGeo geo, float* stats, const void* res_gate, int gate_mask, hipStream_t st, int stats_mode,
-                           int out_f32);
+                           int out_f32, int stats_rows);
 
 // stats_mode: 0 none, 1 forward BatchNorm sums of the output (stats), 2 backward BatchNorm sums of the activation whose
 // gradient the output is (data-gradient launches: res = that BN's input x, mean / var = its batch mean / invstd)
 static int igemm_launch_mode(const void* x, const void* wp, const float* gamma, const float* beta, const float* mean,
                              const float* var, float eps, const void* res, int relu, void* y, int64_t M, int K, int N,
                              int taps, int H, int W, int stride, int dil, int fmt, int out_f32, hipStream_t st,
-                             float* stats, const void* res_gate, int gate_mask, int stats_mode)
+                             float* stats, const void* res_gate, int gate_mask, int stats_mode, int stats_rows)
 {
     if (!hiast_fmt_ok(fmt)) return HIAST_E_RANGE;
     const int planes = hiast_fmt_planes(fmt), f16 = fmt == HIAST_FMT_FP16;
@@ -247,30 +280,32 @@ static int igemm_launch_mode(const void* x, const void* wp, const float* gamma, 
     if (in_pix * planes * K * 2 >= (1ull << 31) || (size_t)N * taps * planes * K * 2 >= (1ull << 31)) return HIAST_E_RANGE;
     if (stats_mode != 2 &&
         hiast_xconv_ok(M, K, N, planes, taps, out_f32, mean != nullptr, res != nullptr, relu, res_gate != nullptr, gate_mask,
-                       stats != nullptr))
+                       stats != nullptr)) {
+        if (stats && stats_rows != hiast_xconv_stats_rows(M, N)) return HIAST_E_ARG;
         return hiast_xconv_launch(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, stats, res_gate, f16, st);
+    }
     if (stats_mode == 0 && !f16 &&
         hiast_xconv2_ok(M, K, N, planes, taps, out_f32, mean != nullptr, res != nullptr, relu, res_gate != nullptr, stats != nullptr))
         return hiast_xconv2_launch(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, N, st);
     if (f16)
         return hiast_igemm_launch_f16(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, stats, res_gate,
-                                      gate_mask, st, stats_mode, out_f32);
+                                      gate_mask, st, stats_mode, out_f32, stats_rows);
     if (planes == 2) {
-        if (out_f32) return launch_igemm_t<2, true>(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, stats, res_gate, gate_mask, st, stats_mode);
-        return launch_igemm_t<2, false>(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, stats, res_gate, gate_mask, st, stats_mode);
+        if (out_f32) return launch_igemm_t<2, true>(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, stats, res_gate, gate_mask, st, stats_mode, stats_rows);
+        return launch_igemm_t<2, false>(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, stats, res_gate, gate_mask, st, stats_mode, stats_rows);
     }
-    if (out_f32) return launch_igemm_t<1, true>(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, stats, res_gate, gate_mask, st, stats_mode);
-    return launch_igemm_t<1, false>(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, stats, res_gate, gate_mask, st, stats_mode);
+    if (out_f32) return launch_igemm_t<1, true>(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, stats, res_gate, gate_mask, st, stats_mode, stats_rows);
+    return launch_igemm_t<1, false>(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, stats, res_gate, gate_mask, st, stats_mode, stats_rows);
 }
 
 // shared launcher (also used by aspp2.hip for the ASPP tap GEMM)
 int hiast_igemm_launch(const void* x, const void* wp, const float* gamma, const float* beta, const float* mean,
                        const float* var, float eps, const void* res, int relu, void* y, int64_t M, int K, int N,
                        int taps, int H, int W, int stride, int dil, int fmt, int out_f32, hipStream_t st,
-                       float* stats, const void* res_gate, int gate_mask)
+                       float* stats, const void* res_gate, int gate_mask, int stats_rows)
 {
     return igemm_launch_mode(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, H, W, stride, dil, fmt,
-                             out_f32, st, stats, res_gate, gate_mask, stats ? 1 : 0);
+                             out_f32, st, stats, res_gate, gate_mask, stats ? 1 : 0, stats_rows);
 }
 
 // Data gradient of a stride-1 trunk convolution (dy x the adjoint weight, hiast_pack_conv_weight transpose) whose output
@@ -279,15 +314,15 @@ int hiast_igemm_launch(const void* x, const void* wp, const float* gamma, const 
 // hiast_bn_nhwc_bwd_apply takes (reference: autograd of conv -> bn -> relu in Bottleneck.forward, resnet.py:78-98).
 extern "C" int hiast_igemm_dgrad_bn_stats(const void* dy, const void* wpt, void* da, int B, int H, int W, int Cin, int Cout,
                                           int taps, int dil, const void* bn_x, const float* gamma, const float* beta,
-                                          const float* save_mean, const float* save_invstd, float* partial, int fmt,
-                                          hiast_stream_t stream)
+                                          const float* save_mean, const float* save_invstd, float* partial, int partial_rows,
+                                          int fmt, hiast_stream_t stream)
 {
     if (fmt != HIAST_FMT_BF16 && fmt != HIAST_FMT_FP16) return HIAST_E_RANGE;
     if (B <= 0 || H <= 0 || W <= 0) return HIAST_E_ARG;
     if (!bn_x || !save_mean || !save_invstd || !partial) return HIAST_E_ARG;
     if ((((uintptr_t)save_mean) | ((uintptr_t)save_invstd) | ((uintptr_t)gamma) | ((uintptr_t)beta)) & 15) return HIAST_E_RANGE;
     return igemm_launch_mode(dy, wpt, gamma, beta, save_mean, save_invstd, 0.0f, bn_x, 0, da, (int64_t)B * H * W, Cin, Cout,
-                             taps, H, W, 1, dil, fmt, 0, (hipStream_t)stream, partial, nullptr, 0, 2);
+                             taps, H, W, 1, dil, fmt, 0, (hipStream_t)stream, partial, nullptr, 0, 2, partial_rows);
 }
 
 // Data gradient of a 3x3 / stride-2 / padding-1 trunk convolution (layer2.0.conv2; autograd of that nn.Conv2d in
@@ -299,7 +334,7 @@ extern "C" int hiast_igemm_dgrad_s2(const void* dy, const void* wpt, void* dx, i
     if (fmt != HIAST_FMT_BF16 && fmt != HIAST_FMT_FP16) return HIAST_E_RANGE;
     if (B <= 0 || H <= 0 || W <= 0) return HIAST_E_ARG;
     return igemm_launch_mode(dy, wpt, nullptr, nullptr, nullptr, nullptr, 0.0f, nullptr, 0, dx, (int64_t)B * H * W, Cout, Cin, 9,
-                             H, W, -2, 1, fmt, 0, (hipStream_t)stream, nullptr, nullptr, 0, 0);
+                             H, W, -2, 1, fmt, 0, (hipStream_t)stream, nullptr, nullptr, 0, 0, 0);
 }
 
 // rows of the partial-sum buffer of hiast_igemm_dgrad_bn_stats: one per block row of the tile form the launch takes
@@ -313,13 +348,14 @@ extern "C" int hiast_igemm_dgrad_bn_stats_rows(int64_t M, int Cin, int Cout, int
 extern "C" int hiast_igemm_bn_act(const void* x, const void* wp, const float* gamma, const float* beta,
                                   const float* mean, const float* var, float eps, const void* res, int relu, void* y,
                                   int B, int H, int W, int Cin, int Cout, int taps, int stride, int dil, int fmt,
-                                  int out_f32, float* stats, const void* res_gate, int gate_mask, hiast_stream_t stream)
+                                  int out_f32, float* stats, int stats_rows, const void* res_gate, int gate_mask,
+                                  hiast_stream_t stream)
 {
     if (B <= 0 || H <= 0 || W <= 0) return HIAST_E_ARG;
     if (taps == 1 && stride != 1) return HIAST_E_RANGE;       // strided 1x1: subsample the input first
     const int Ho = taps == 1 ? H : (H - 1) / stride + 1, Wo = taps == 1 ? W : (W - 1) / stride + 1;
     return hiast_igemm_launch(x, wp, gamma, beta, mean, var, eps, res, relu, y, (int64_t)B * Ho * Wo, Cin, Cout, taps, H,
-                              W, stride, dil, fmt, out_f32, (hipStream_t)stream, stats, res_gate, gate_mask);
+                              W, stride, dil, fmt, out_f32, (hipStream_t)stream, stats, res_gate, gate_mask, stats_rows);
 }
 
 #ifdef IG_STAMP

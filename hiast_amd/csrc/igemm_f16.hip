@@ -7,11 +7,11 @@
 int hiast_igemm_launch_f16(const void* x, const void* wp, const float* gamma, const float* beta, const float* mean,
                            const float* var, float eps, const void* res, int relu, void* y, int64_t M, int K, int N, int taps,
                            hiast::IGeo geo, float* stats, const void* res_gate, int gate_mask, hipStream_t st, int stats_mode,
-                           int out_f32)
+                           int out_f32, int stats_rows)
 {
     if (out_f32)
         return launch_igemm_t<1, true, true>(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, stats,
-                                             res_gate, gate_mask, st, stats_mode);
+                                             res_gate, gate_mask, st, stats_mode, stats_rows);
     return launch_igemm_t<1, false, true>(x, wp, gamma, beta, mean, var, eps, res, relu, y, M, K, N, taps, geo, stats,
-                                          res_gate, gate_mask, st, stats_mode);
+                                          res_gate, gate_mask, st, stats_mode, stats_rows);
 }

@@ -856,20 +856,40 @@ __global__ __launch_bounds__(BM * 2) void igemm_bn_act_kernel(
 }  // namespace hiast
 
 // host: does this launch run on 128 x 128 tiles, two 4-wave blocks per CU (BM = 128 above)?  ONE rule for the launch and for the
-// callers that size the per-block statistics buffers (hiast_igemm_stats_rows, hiast_igemm_dgrad_bn_stats_rows).
+// callers that size the per-block statistics buffers (hiast_igemm_stats_rows, hiast_igemm_dgrad_bn_stats_rows); the launch checks
+// the caller's row count against the form it takes (HIAST_E_ARG on a mismatch).
 // HIAST_IGEMM_HALF=0 / 1: never / every 1x1 launch with N % 128 == 0 (A/B and tests); unset: the HBM-bound shapes measured faster
-// (profiles/r05_ab_igemm_half_tile.txt).
+// (profiles/r05_ab_igemm_half_tile.txt).  The tuning variables are read ONCE per process (ig_env below): a value that changes
+// between the row-count call and the launch would size `partial` for one tile form and run the other.
+struct IgEnv {
+    int half;        // HIAST_IGEMM_HALF: -1 unset | 0 | 1
+    int bn;          // HIAST_IGEMM_BN: 0 unset | 64 | 128 | 256
+    int ragged_off;  // HIAST_IGEMM_RAGGED set: no ragged 256-column tiles for the plain N = 640 GEMM
+    int cosched0;    // HIAST_IGEMM_COSCHED: the process default of the co-scheduling hint
+};
+const IgEnv& hiast_ig_env();                             // igemm.hip
+// The co-scheduling hint (hiast_igemm_set_cosched, include/hiast_hip.h): "this thread runs two launch sequences side by side" —
+// two half-chip launches on two streams already fill the chip, so they keep the 256-row form.  THREAD-LOCAL state of the calling
+// thread (-1 = the process default above), never the environment: setenv / unsetenv around every forward raced with getenv in
+// other threads.
+int hiast_ig_cosched_tls_get();                          // igemm.hip
+int hiast_ig_half_tls_get();                             // igemm.hip: hiast_igemm_set_half of the calling thread (-1 = HIAST_IGEMM_HALF / automatic)
+static inline int ig_half_forced()
+{
+    const int t = hiast_ig_half_tls_get();
+    return t >= 0 ? t : hiast_ig_env().half;
+}
 static inline int ig_cosched()
 {
-    const char* e = getenv("HIAST_IGEMM_COSCHED");
-    return e && atoi(e) != 0;
+    const int t = hiast_ig_cosched_tls_get();
+    return t >= 0 ? t : hiast_ig_env().cosched0;
 }
 static inline int ig_half_tile(int64_t M, int K, int N, int taps, int out_f32)
 {
     // (1x1 only: on the 3x3 launches the form was measured 20-25 % slower wherever the 256-row form fills the chip — twice the
     // L2 -> LDS bytes and a third more fragment reads per flop in an MFMA-bound loop — profiles/r05_ab_igemm_half_tile.txt)
     if (taps != 1 || out_f32 || N % 128 != 0 || M < 4096) return 0;
-    if (const char* e = getenv("HIAST_IGEMM_HALF")) return atoi(e) != 0;
+    if (ig_half_forced() >= 0) return ig_half_forced();
     return IG_HALF_AUTO(M, K, N);
 }
 // ... and the split-plane 3x3 + BN + ReLU launch of the pseudo-label forward in the same form when its 256-row form fills at most a
@@ -878,7 +898,7 @@ static inline int ig_half_tile(int64_t M, int K, int N, int taps, int out_f32)
 static inline int ig_half_tile9(int64_t M, int N, int PL, bool bn_relu_only)
 {
     if (PL != 2 || !bn_relu_only || N % 128 != 0 || M < 4096) return 0;
-    if (const char* e = getenv("HIAST_IGEMM_HALF")) return atoi(e) != 0;
+    if (ig_half_forced() >= 0) return ig_half_forced();
     return IG_HALF_AUTO(M, 0, N);
 }
 static inline int ig_block_rows(int64_t M, int K, int N, int taps, int out_f32)
@@ -890,7 +910,7 @@ template <int PL, bool OUTF32, bool F16 = false>
 static int launch_igemm_t(const void* x, const void* wp, const float* gamma, const float* beta, const float* mean,
                           const float* var, float eps, const void* res, int relu, void* y, int64_t M, int K, int N,
                           int taps, hiast::IGeo geo, float* stats, const void* res_gate, int gate_mask, hipStream_t st,
-                          int stats_mode)
+                          int stats_mode, int stats_rows)
 {
     int BN = (N % 256 == 0) ? 256 : ((N % 128 == 0) ? 128 : 64);
     // a plain GEMM (no BN / residual / ReLU / gate / statistics) of N = 2.5, 3.5, ... tiles of 256 runs on 256-column tiles
@@ -898,10 +918,9 @@ static int launch_igemm_t(const void* x, const void* wp, const float* gamma, con
     // output — 0.170 against 0.181 ms on five 128-column tiles although a fifth of the last tile's MFMAs multiply zeros (with
     // fp32 output the 128-column tiles win: 0.187 against 0.197)
     const bool plain = !mean && !gamma && !res && !relu && !stats && !res_gate && stats_mode == 0;
-    if (plain && !OUTF32 && BN == 128 && N > 512 && getenv("HIAST_IGEMM_RAGGED") == nullptr) BN = 256;
-    if (const char* env = getenv("HIAST_IGEMM_BN")) {          // tuning override
-        const int v = atoi(env);
-        if ((v == 64 || v == 128 || v == 256) && N % v == 0) BN = v;
+    if (plain && !OUTF32 && BN == 128 && N > 512 && !hiast_ig_env().ragged_off) BN = 256;
+    if (const int v = hiast_ig_env().bn) {                      // tuning override (HIAST_IGEMM_BN)
+        if (N % v == 0) BN = v;
     }
     const bool half9 = taps == 9 && !OUTF32 && geo.stride == 1 &&
                        ig_half_tile9(M, N, PL, mean && relu && !res && !stats && !res_gate && stats_mode == 0) != 0;
@@ -910,6 +929,8 @@ static int launch_igemm_t(const void* x, const void* wp, const float* gamma, con
     const int BMr = half ? 128 : hiast::IG_BM;
     dim3 grid((unsigned)((M + BMr - 1) / BMr), (N + BN - 1) / BN);
     const dim3 block((unsigned)(BMr * 2));
+    // the statistics epilogues write one row of sums per block row of THIS tile form: the caller's buffer has to be that long
+    if (stats && stats_rows != (int)grid.x) return HIAST_E_ARG;
     const int gate = !res_gate ? 0 : (gate_mask ? 2 : 1);
     if (geo.stride < 0) {                                   // transposed stride-2 3x3 (UPS): plain 16-bit launches only
         if constexpr (PL == 1 && !OUTF32) {

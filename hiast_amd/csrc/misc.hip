@@ -1,6 +1,8 @@
 // Version / error strings, K11 (EMA teacher update) and K12 (IoU area histograms).
 #include <hip/hip_bf16.h>
 
+#include <atomic>
+
 #include "common.h"
 
 namespace hiast {
@@ -176,6 +178,67 @@ __global__ __launch_bounds__(256) void confusion_kernel(const int64_t* __restric
 }  // namespace hiast
 
 extern "C" int hiast_version(void) { return HIAST_ABI_VERSION; }
+
+// ---- device geometry and the CU reserve (common.h) --------------------------------------------------------------------
+static std::atomic<int> g_reserve_cus{0};
+static int query_cus()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    static std::atomic<int> cache[64];
+    if (dev >= 0 && dev < 64 && cache[dev].load(std::memory_order_relaxed) > 0) return cache[dev].load(std::memory_order_relaxed);
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (dev >= 0 && dev < 64 && n > 0) cache[dev].store(n, std::memory_order_relaxed);
+    return n;
+}
+int hiast_cu_count()
+{
+    const int n = query_cus();
+    return n >= 8 ? n : 256;            // (no device visible: the gfx950 figure, so that the host-side planners stay usable)
+}
+int hiast_grid_cus()
+{
+    const int n = hiast_cu_count() - g_reserve_cus.load(std::memory_order_relaxed);
+    return n >= 8 ? n : 8;
+}
+extern "C" int hiast_device_cus(void) { return query_cus(); }
+extern "C" int hiast_get_reserve_cus(void) { return g_reserve_cus.load(std::memory_order_relaxed); }
+extern "C" int hiast_set_reserve_cus(int n)
+{
+    if (n < 0) return HIAST_E_ARG;
+    const int cus = hiast_cu_count();
+    n = (n + 7) / 8 * 8;                // whole rounds of the 8 XCDs: every XCD gives up n / 8 CUs
+    if (n > cus / 2) return HIAST_E_RANGE;
+    return g_reserve_cus.exchange(n);
+}
+// A stream whose kernels cannot be placed on the `reserve` highest-numbered CUs of the queue's CU mask.  KFD maps mask bit i of
+// a multi-XCC device to XCC (i % 8), then to shader engines and CUs inside it, so clearing the top `reserve` bits (a multiple
+// of 8) takes reserve / 8 CUs from every XCD.  Unlike a smaller grid this also holds for kernels that are not ours.
+extern "C" int hiast_stream_create_reserved(hiast_stream_t* out, int reserve)
+{
+    if (!out || reserve < 0) return HIAST_E_ARG;
+    const int cus = query_cus();
+    if (cus <= 0) return (int)hipErrorNoDevice;
+    reserve = (reserve + 7) / 8 * 8;
+    if (reserve > cus / 2) return HIAST_E_RANGE;
+    const int words = (cus + 31) / 32;
+    uint32_t mask[32] = {0};
+    if (words > 32) return HIAST_E_RANGE;
+    for (int i = 0; i < cus - reserve; ++i) mask[i >> 5] |= 1u << (i & 31);
+    hipStream_t st = nullptr;
+    hipError_t e = hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask);
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
+    *out = (hiast_stream_t)st;
+    return 0;
+}
+extern "C" int hiast_stream_destroy(hiast_stream_t s)
+{
+    if (!s) return HIAST_E_ARG;
+    const hipError_t e = hipStreamDestroy((hipStream_t)s);
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
+    return 0;
+}
 
 extern "C" const char* hiast_error_string(int code)
 {

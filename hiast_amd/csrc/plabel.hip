@@ -198,7 +198,8 @@ static int launch_pass1(const float* logits, int B, int h, int w, int H, int W, 
     if (ws && chunk >= 1 && items < (1ll << 30)) {
         const hipError_t e0 = hipMemsetAsync(ws, 0, (size_t)256 * C * HIST_PLANE * sizeof(uint32_t), st);
         if (e0 != hipSuccess) return (int)e0;
-        const int blocks = (int)(items / 4 < 256 ? (items + 3) / 4 : 256);
+        const int cus = hiast_grid_cus();                 // persistent: one 1024-thread block per CU
+        const int blocks = (int)(items / 4 < cus ? (items + 3) / 4 : cus);
         hipLaunchKernelGGL(plabel_pass1_persistent_kernel<C>, dim3(blocks), dim3(1024), 0, st, logits, h, w, H, W, sh, sw,
                            maxprob, argmax, ws, nx, (int)items, chunk);
         HIAST_CHECK_LAUNCH();

@@ -294,7 +294,7 @@ extern "C" int hiast_stem_eval(const float* x, const float* w, const float* gamm
     const long long ntiles = (long long)B * g.tiles_x * g.tiles_y;
     if (ntiles >= (1ll << 30)) return HIAST_E_RANGE;
     // persistent blocks: two per CU in the 16-bit formats (76 KiB of LDS each), one with split planes (116 KiB)
-    const long long cap = fmt == HIAST_FMT_SPLIT_BF16 ? 256 : 512;
+    const long long cap = (fmt == HIAST_FMT_SPLIT_BF16 ? 1 : 2) * hiast_grid_cus();
     const unsigned blocks = (unsigned)(ntiles < cap ? ntiles : cap);
     hipStream_t st = (hipStream_t)stream;
     if (fmt == HIAST_FMT_SPLIT_BF16)

@@ -356,7 +356,8 @@ extern "C" int hiast_stem_train_blocks(int B, int H, int W)
     hiast::StemTGeo g;
     long long ntiles;
     if (hiast::stem_train_geo(B, H, W, g, ntiles)) return 0;
-    return (int)(ntiles < 768 ? ntiles : 768);             // persistent: three blocks per CU (42 KiB of LDS each)
+    const long long cap = 3ll * hiast_grid_cus();          // persistent: three blocks per CU (42 KiB of LDS each)
+    return (int)(ntiles < cap ? ntiles : cap);
 }
 
 // x fp32 [B,3,H,W] (NCHW, contiguous), w fp32 [64,3,7,7] -> y [B,Hc,Wc,64] rows in format fmt (HIAST_FMT_BF16 | _FP16),
@@ -381,7 +382,11 @@ extern "C" int hiast_stem_train_fwd(const float* x, const float* w, void* y, flo
     return 0;
 }
 
-static int stem_wgrad_blocks(long long ntiles) { return (int)(ntiles < 512 ? ntiles : 512); }    // two per CU (50 KiB of LDS)
+static int stem_wgrad_blocks(long long ntiles)            // two per CU (50 KiB of LDS)
+{
+    const long long cap = 2ll * hiast_grid_cus();
+    return (int)(ntiles < cap ? ntiles : cap);
+}
 
 extern "C" size_t hiast_stem_wgrad_workspace_bytes(int B, int H, int W)
 {

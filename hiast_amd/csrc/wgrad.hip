@@ -453,7 +453,7 @@ static int wgrad_nsplit(long long M, int tiles, int taps)
     // one block per CU at a time (128 KiB of LDS each) and every block costs a 256 KiB partial tile written here and read
     // again by the reduction: ONE round of <= 256 blocks (two rounds doubled the partial traffic — 129 MB against 67 MB
     // of operands on the layer3 3x3 — for the same MFMA time per CU); at least 8 k-steps (512 pixels) per block
-    long long s = 256 / tiles;
+    long long s = hiast_grid_cus() / tiles;
     const long long smax = M / 512 > 0 ? M / 512 : 1;
     s = s < 1 ? 1 : (s > smax ? smax : s);
     s = s > 64 ? 64 : s;
@@ -543,13 +543,14 @@ static int wgrad_group_plan(const hiast_wgrad_job* jobs, int njobs, hiast::WGrou
         if (f4 >= (1ll << 31)) return HIAST_E_RANGE;
         mmin = (mmin < 0 || M < mmin) ? M : mmin;
     }
-    if (tiles > hiast::WG_MAXBLOCKS) return HIAST_E_RANGE;
+    if (tiles > hiast::WG_MAXBLOCKS || tiles > hiast_grid_cus()) return HIAST_E_RANGE;
     // ONE round of <= 256 blocks (see wgrad_nsplit), at least 16 k-steps per block.  Uniform split first; when the launch
     // mixes 1x1 and 3x3 jobs, the 1x1 jobs get `ratio` times shorter pixel ranges (their blocks take about that much longer
     // per pixel: HBM-streamed rows against L2-fed ones; HIAST_WGROUP_RATIO, percent, tuning): the pair (s1, s9) with
     // tiles1 * s1 + tiles9 * s9 <= 256 that minimises max(ratio / s1, 1 / s9)
     const long long smax = mmin / 512 > 0 ? (mmin / 512 > 64 ? 64 : mmin / 512) : 1;
-    long long s1 = 256 / tiles, s9;
+    const int cus = hiast_grid_cus() < hiast::WG_MAXBLOCKS ? hiast_grid_cus() : hiast::WG_MAXBLOCKS;   // one round of blocks
+    long long s1 = cus / tiles, s9;
     s1 = s1 < 1 ? 1 : (s1 > smax ? smax : s1);
     s9 = s1;
     static const int ratio_pct = [] { const char* e = getenv("HIAST_WGROUP_RATIO"); const int v = e ? atoi(e) : 100; return v >= 25 && v <= 400 ? v : 100; }();
@@ -557,7 +558,7 @@ static int wgrad_group_plan(const hiast_wgrad_job* jobs, int njobs, hiast::WGrou
         double best = (double)ratio_pct / 100.0 / (double)s1;
         if (1.0 / (double)s9 > best) best = 1.0 / (double)s9;
         for (long long a = 1; a <= smax; ++a) {
-            const long long left = 256 - (long long)tiles1 * a;
+            const long long left = cus - (long long)tiles1 * a;
             if (left < tiles9) break;
             long long b = left / tiles9;
             b = b > smax ? smax : b;

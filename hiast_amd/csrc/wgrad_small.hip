@@ -257,7 +257,7 @@ static WSPlan ws_plan(int B, int H, int W, int Cin, int Cout, int taps)   // H, 
     p.nj = CJ >= 128 ? taps * (CJ / 128) : (taps == 9 ? 5 : 1);
     const long long tiles = (long long)p.ni * p.nj;
     const size_t tile_bytes = (size_t)p.TI * 128 * 4;
-    long long s = 512 / tiles;                                             // 2 blocks of 256 threads per CU (64 KiB of LDS each)
+    long long s = 2 * hiast_grid_cus() / tiles;                                             // 2 blocks of 256 threads per CU (64 KiB of LDS each)
     const long long cap = (long long)((48ull << 20) / (tiles * tile_bytes));   // partial tiles: at most 48 MiB
     s = s > cap ? cap : s;
     const long long smax = M / 512 > 0 ? M / 512 : 1;                     // at least 8 k-steps per block

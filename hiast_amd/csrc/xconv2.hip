@@ -284,10 +284,11 @@ static int x2_blocks(int64_t M, int N)
 {
     const int NG = N / X2_COLS;
     const long long npanel = (M + X2_PANEL - 1) / X2_PANEL;
-    static const int cus = [] { const char* e = getenv("HIAST_XCONV_CUS"); const int v = e ? atoi(e) : 256; return v >= 8 && v <= 256 ? v : 256; }();
-    long long streams = cus / NG;                   // one block per CU (HIAST_XCONV_CUS: experiment, part of the chip)
-    if (streams > npanel) streams = npanel;
-    streams = (streams + 7) / 8 * 8;                // the (slot, xcd) numbering wants whole rounds of the 8 XCDs
+    static const int env_cus = [] { const char* e = getenv("HIAST_XCONV_CUS"); const int v = e ? atoi(e) : 0; return v >= 8 && v <= 256 ? v : 0; }();
+    const int cus = env_cus ? env_cus : hiast_grid_cus();   // one block per CU (HIAST_XCONV_CUS: experiment, part of the chip)
+    long long streams = cus / NG / 8 * 8;           // the (slot, xcd) numbering wants whole rounds of the 8 XCDs
+    if (streams < 8) streams = 8;
+    if (streams > npanel) streams = (npanel + 7) / 8 * 8;
     return (int)(streams * NG);
 }
 

@@ -256,9 +256,9 @@ static int xb_blocks(int64_t M, int N)
 {
     const int NG = N / XB_COLS;
     const long long npanel = (M + XB_PANEL - 1) / XB_PANEL;
-    long long streams = 256 / NG;                   // one block per CU
-    if (streams > npanel) streams = npanel;
-    streams = (streams + 7) / 8 * 8;                // the (slot, xcd) numbering wants whole rounds of the 8 XCDs
+    long long streams = hiast_grid_cus() / NG / 8 * 8;   // one block per CU; the (slot, xcd) numbering wants whole rounds of the 8 XCDs
+    if (streams < 8) streams = 8;
+    if (streams > npanel) streams = (npanel + 7) / 8 * 8;
     return (int)(streams * NG);
 }
 

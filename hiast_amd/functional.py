@@ -197,6 +197,12 @@ def _stat_all_reduce(t, async_op=False):
     return comm.all_reduce(t, "stat", async_op=async_op)
 
 
+def _stat_wait(work):
+    """wait for an async SyncBN exchange (host-timed on the statistics communicator: utils/comm.HOST_S)"""
+    from hiast_amd.utils import comm
+    comm.wait(work, "stat")
+
+
 class _BnActFn(torch.autograd.Function):
     """y = relu?(BN(x) (+ res)) in two streaming kernels (stats, apply) forward and two backward;
     SyncBN = one all-reduce of the [C,2] double sums between them (same exchange as the reference's SyncBN)."""
@@ -283,7 +289,7 @@ class _BnActNhwcFn(torch.autograd.Function):
             # while the consuming convolution's backward had already started the exchange: finish it, drop the sums
             left = stat_box.pop("bwd_sums", None)
             if left is not None:
-                left[1].wait()
+                _stat_wait(left[1])
             stat_box.pop("bwd_partial", None)
         if stat_box is not None and ctx.gate == 2:
             stat_box["bn"] = (x.detach(), sm, si, gamma, beta)
@@ -307,7 +313,7 @@ class _BnActNhwcFn(torch.autograd.Function):
         early = ctx.stat_box.pop("bwd_sums", None) if ctx.stat_box is not None else None
         if early is not None:          # SyncBN: the consuming convolution's backward has reduced its epilogue sums and started
             sums, work = early         # the all-reduce BEFORE its weight gradient: the exchange ran beside that kernel
-            work.wait()
+            _stat_wait(work)
         else:
             if fused is not None:      # per-block sums from the epilogue of the consuming convolution's data gradient
                 sums = K.bn_nhwc_stats_from_partial(fused)
@@ -562,9 +568,11 @@ def wgroup_weights(convs, x):
     # ranges: 265 against 300 us) and the 3x3 keeps its own launch (36 tiles x 7 ranges).
     tiles = [(c.in_channels // 256) * (c.out_channels // 256) * c.kernel_size[0] ** 2 for c in convs]
 
-    def fill(idx):      # fraction of the 256 CUs one round of (tiles x pixel ranges) blocks occupies
+    cus = K.grid_cus()   # (hiast_device_cus - the CU reserve: the number the library's planner splits the pixel ranges for)
+
+    def fill(idx):      # fraction of those CUs one round of (tiles x pixel ranges) blocks occupies
         t = sum(tiles[i] for i in idx)
-        return t * (256 // t) / 256.0 if 0 < t <= 256 else 0.0
+        return t * (cus // t) / float(cus) if 0 < t <= cus else 0.0
     member = list(range(len(convs)))
     if fill(member) < 0.9:
         member = [i for i in member if convs[i].kernel_size[0] == 1]
@@ -629,6 +637,14 @@ def stem_conv_train(x, conv):
 _wgrad_streams = {}
 _wgrad_overlap = [False]
 _eval_streams = {}
+
+
+def new_stream(device):
+    """a side stream for `device`: a plain torch stream — or, while a CU reserve is in effect (comm.apply_cu_reserve: N > 1
+    with HIAST_RESERVE_CUS=n), a stream whose kernels cannot be placed on the reserved CUs (K.reserved_stream), so that the
+    pseudo-label / teacher / weight-gradient sequences leave a collective's kernel a CU"""
+    n = K.reserve_cus() if torch.device(device).type == "cuda" else 0
+    return K.reserved_stream(n, device) if n > 0 else torch.cuda.Stream(device=device)
 _eval_trunks = {}
 
 
@@ -671,24 +687,19 @@ def eval_forward_split(model, x, parts=None):
     key = (x.device, parts)
     side = _eval_streams.get(key)
     if side is None:
-        side = _eval_streams[key] = [torch.cuda.Stream(device=x.device) for _ in range(parts - 1)]
+        side = _eval_streams[key] = [new_stream(x.device) for _ in range(parts - 1)]
     sub = B // parts
     outs = [None] * parts
     # the sub-batch launches run side by side: tell the tile kernel's launcher (it would otherwise give a half-chip launch the
     # 128 x 128 / two-blocks-per-CU form, which wins on a launch that runs ALONE: igemm_kernel.h, IG_HALF_AUTO)
-    prev = os.environ.get("HIAST_IGEMM_COSCHED")
-    os.environ["HIAST_IGEMM_COSCHED"] = "1"
-    try:
+    # The hint is state of THIS thread inside the library (hiast_igemm_set_cosched), passed with every launch this thread makes
+    # and with the statistics-row counts alike — not an environment variable toggled under other threads' getenv.
+    with K.cosched():
         for i, st in enumerate(side):
             st.wait_stream(main)
             with torch.cuda.stream(st):
                 outs[i + 1] = model(x[(i + 1) * sub:(i + 2) * sub], lowres=True)
         outs[0] = model(x[:sub], lowres=True)
-    finally:
-        if prev is None:
-            del os.environ["HIAST_IGEMM_COSCHED"]
-        else:
-            os.environ["HIAST_IGEMM_COSCHED"] = prev
     for i, st in enumerate(side):
         main.wait_stream(st)
         outs[i + 1]["logits_lowres"].record_stream(main)
@@ -795,7 +806,7 @@ def wgrad_side_stream(device):
         return None
     st = _wgrad_streams.get(device)
     if st is None:
-        st = torch.cuda.Stream(device=device)
+        st = new_stream(device)
         _wgrad_streams[device] = st
     return st
 

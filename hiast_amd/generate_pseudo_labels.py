@@ -42,7 +42,9 @@ def main(argv=None):
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group(backend="nccl")
+        from hiast_amd.utils import comm
+        dist.init_process_group(backend="nccl", timeout=comm.timeout())
+        comm.apply_cu_reserve()
     PSEUDO_POLICY[c.pseudo_policy.type](c).run()
 
 

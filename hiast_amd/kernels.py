@@ -49,6 +49,78 @@ def _req(t, dtype, ndim=None, name="tensor"):
     return t
 
 
+# ------------------------------------------------------------------------------- launch hints and device geometry
+class cosched:
+    """`with K.cosched():` — the calling THREAD runs two launch sequences side by side on two streams: half-chip tile-kernel
+    launches keep their 256-row form (hiast_igemm_set_cosched; thread-local in the library, never the environment)."""
+
+    def __init__(self, on=True):
+        self.on = 1 if on else 0
+
+    def __enter__(self):
+        self.prev = _lib.load().hiast_igemm_set_cosched(self.on)
+        return self
+
+    def __exit__(self, *exc):
+        _lib.load().hiast_igemm_set_cosched(self.prev)
+        return False
+
+
+class force_half_tile:
+    """`with K.force_half_tile(v):` (A/B and tests) — v = 1: the 128 x 128 / two-blocks-per-CU tile form wherever it exists,
+    0: never, None: automatic (hiast_igemm_set_half; thread-local)."""
+
+    def __init__(self, v):
+        self.v = -1 if v is None else int(bool(v))
+
+    def __enter__(self):
+        self.prev = _lib.load().hiast_igemm_set_half(self.v)
+        return self
+
+    def __exit__(self, *exc):
+        _lib.load().hiast_igemm_set_half(self.prev)
+        return False
+
+
+def device_cus():
+    """compute units of the current device (hipDeviceGetAttribute through the C ABI; 256 on MI355X)"""
+    n = _lib.load().hiast_device_cus()
+    if n <= 0:
+        raise _lib.HiastLibraryError("hiast_device_cus: no HIP device visible")
+    return n
+
+
+def reserve_cus(n=None):
+    """n given: size every one-block-per-CU / persistent launch to (CUs - n) from now on (rounded up to a multiple of 8;
+    hiast_set_reserve_cus) -> the previous value; n None: the current reserve."""
+    lib = _lib.load()
+    if n is None:
+        return lib.hiast_get_reserve_cus()
+    prev = lib.hiast_set_reserve_cus(int(n))
+    if prev < 0:
+        check(prev, "hiast_set_reserve_cus")
+    return prev
+
+
+def grid_cus():
+    """CUs the persistent launches fill = device_cus() - reserve_cus()"""
+    return max(8, device_cus() - reserve_cus())
+
+
+_reserved_streams = []          # (handle, torch.cuda.ExternalStream): kept alive for the life of the process
+
+
+def reserved_stream(reserve, device=None):
+    """a torch stream on which no kernel can be placed on `reserve` of the CUs (hiast_stream_create_reserved: queue CU mask,
+    reserve / 8 CUs of every XCD) — the non-persistent tile kernels cannot size a grid below their tile count"""
+    h = ctypes.c_void_p(0)
+    check(_lib.load().hiast_stream_create_reserved(ctypes.byref(h), int(reserve)), "hiast_stream_create_reserved")
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    st = torch.cuda.ExternalStream(h.value, device=dev)
+    _reserved_streams.append((h, st))
+    return st
+
+
 # ------------------------------------------------------------------------------- K2 upsample
 def upsample_bilinear_ac_fwd(x, H, W):
     _req(x, torch.float32, 4, "x")
@@ -994,47 +1066,16 @@ def igemm_bn_act(x, wp, planes, bn, res, relu, stride=1, dil=1, out_f32=False, w
         g = b = mu = var = ctypes.c_void_p(0)
         eps = 0.0
     partial = None
+    rows = 0
     if want_stats:
         assert PL == 1 and not out_f32
         rows = _lib.load().hiast_igemm_stats_rows(B * Ho * Wo, Cin, N, taps, fmt)    # one row per block of the kernel
         partial = torch.empty((rows, N, 2), dtype=torch.float32, device=x.device)
+    # (the launch checks `rows` against the tile form it takes: HIAST_E_ARG instead of an overrun if the two ever disagree)
     check(_lib.load().hiast_igemm_bn_act(_ptr(x), _ptr(wp), g, b, mu, var, eps, _ptr(res), int(bool(relu)), _ptr(y),
                                          B, H, W, Cin, N, taps, int(stride), int(dil), fmt, int(bool(out_f32)),
-                                         _ptr(partial), _ptr(res_gate), gate_mask, _stream()), "hiast_igemm_bn_act")
+                                         _ptr(partial), rows, _ptr(res_gate), gate_mask, _stream()), "hiast_igemm_bn_act")
     return (y, partial) if want_stats else y
-
-
-def bottleneck_tail_ok(x, planes, conv2, conv3):
-    """does hiast_bottleneck_tail take conv2 -> bn2 -> relu -> conv3 -> bn3 -> (+res) -> relu of this block on x?"""
-    PL = 2 if int(planes) == 2 else 1
-    B, H, W, CC = x.shape
-    if (conv2.kernel_size != (3, 3) or conv2.stride != (1, 1) or conv2.padding != conv2.dilation or conv2.groups != 1
-            or conv3.kernel_size != (1, 1) or CC != PL * conv2.in_channels or conv2.out_channels != conv2.in_channels):
-        return False
-    return bool(_lib.load().hiast_bottleneck_tail_ok(B, H, W, conv2.out_channels, conv3.out_channels, 1, fmt_of(x, PL)))
-
-
-def bottleneck_tail(x, w2p, bn2, w3p, bn3, res, planes, dil):
-    """relu(bn3(conv3(relu(bn2(conv2(x))))) + res) in one launch (K9m): x [B,H,W,planes*256], w2p / w3p from pack_conv_weight
-    ([256,9,planes*256], [Cout,1,planes*256]), bn2 / bn3 in eval mode, res like the output [B,H,W,planes*Cout]"""
-    _req16(x, 4, "x")
-    PL = 2 if int(planes) == 2 else 1
-    fmt = fmt_of(x, PL)
-    _req(w2p, x.dtype, 3, "w2p")
-    _req(w3p, x.dtype, 3, "w3p")
-    B, H, W, CC = x.shape
-    Cmid = CC // PL
-    N = w3p.shape[0]
-    assert tuple(w2p.shape) == (Cmid, 9, PL * Cmid) and tuple(w3p.shape) == (N, 1, PL * Cmid), (tuple(w2p.shape), tuple(w3p.shape))
-    _req(res, x.dtype, 4, "res")
-    assert tuple(res.shape) == (B, H, W, PL * N), (tuple(res.shape), (B, H, W, PL * N))
-    y = torch.empty((B, H, W, PL * N), dtype=x.dtype, device=x.device)
-    g2, b2, mu2, var2, eps2 = _bn_params(bn2)
-    g3, b3, mu3, var3, eps3 = _bn_params(bn3)
-    check(_lib.load().hiast_bottleneck_tail(_ptr(x), _ptr(w2p), g2, b2, mu2, var2, eps2, _ptr(w3p), g3, b3, mu3, var3, eps3,
-                                            _ptr(res), _ptr(y), B, H, W, Cmid, N, int(dil), fmt, _stream()),
-          "hiast_bottleneck_tail")
-    return y
 
 
 def igemm_dgrad_bn_stats(dy, wpt, dil, bn_x, gamma, beta, save_mean, save_invstd):
@@ -1056,7 +1097,7 @@ def igemm_dgrad_bn_stats(dy, wpt, dil, bn_x, gamma, beta, save_mean, save_invstd
     partial = torch.empty((rows, N, 2), dtype=torch.float32, device=dy.device)
     check(lib.hiast_igemm_dgrad_bn_stats(_ptr(dy), _ptr(wpt), _ptr(da), B, H, W, Cin, N, taps, int(dil), _ptr(bn_x),
                                          _ptr(gamma), _ptr(beta), _ptr(save_mean), _ptr(save_invstd), _ptr(partial),
-                                         fmt_of(dy), _stream()), "hiast_igemm_dgrad_bn_stats")
+                                         rows, fmt_of(dy), _stream()), "hiast_igemm_dgrad_bn_stats")
     return da, partial
 
 

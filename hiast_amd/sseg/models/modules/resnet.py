@@ -129,11 +129,6 @@ class Bottleneck(nn.Module):
             dconv, dbn = self.downsample[0], self.downsample[1]
             xs = x if dconv.stride == (1, 1) else x[:, ::dconv.stride[0], ::dconv.stride[1]].contiguous()
             idt = K.igemm_bn_act(xs, packed_weight(dconv, fmt), PL, dbn, None, False)
-        if K.bottleneck_tail_ok(o, PL, self.conv2, self.conv3):
-            # layer3 (256 mid channels): conv2 -> bn2 -> ReLU -> conv3 -> bn3 -> + identity -> ReLU in ONE kernel (K9m,
-            # hiast_bottleneck_tail): the 256-channel activation between the two convolutions never reaches HBM
-            return K.bottleneck_tail(o, packed_weight(self.conv2, fmt), self.bn2, packed_weight(self.conv3, fmt), self.bn3,
-                                     idt, PL, self.conv2.dilation[0])
         o = K.igemm_bn_act(o, packed_weight(self.conv2, fmt), PL, self.bn2, None, True, self.conv2.stride[0],
                            self.conv2.dilation[0])
         return K.igemm_bn_act(o, packed_weight(self.conv3, fmt), PL, self.bn3, idt, True)

@@ -17,7 +17,9 @@ Every rank must create the groups at the same point of its program: `setup()` is
 init_process_group by the trainers / generator / bench.py; the getters create lazily otherwise (first use is at the
 same program point on every rank as well).  HIAST_COMM_GROUPS=0 routes everything through the default group.
 """
+import datetime
 import os
+import time
 
 import torch.distributed as dist
 
@@ -35,7 +37,7 @@ def _get(name):
     ent = _groups.get(name)
     if ent is None or ent[0] is not dist.distributed_c10d._get_default_group():
         # (a re-initialised default group — tests start several process groups in one interpreter — invalidates ours)
-        ent = _groups[name] = (dist.distributed_c10d._get_default_group(), dist.new_group())
+        ent = _groups[name] = (dist.distributed_c10d._get_default_group(), dist.new_group(timeout=timeout()))
     return ent[1]
 
 
@@ -65,12 +67,60 @@ def reset():
 # (ResNet-101: 208), 3 on the auxiliary group (histogram + the two class sums), DDP's gradient buckets on the default group
 # (43.8 M fp32 parameters in 32 MB buckets: 6; counted by the reducer itself, `_get_ddp_logging_data()`).
 COUNTS = {"stat": 0, "aux": 0}
+# ... and the HOST time spent inside those calls (issue + whatever the backend blocks for; `wait` adds the handle waits of the
+# async form): what a first SCALE record is read against — 208 x 20-40 us budgeted for the statistics communicator
+HOST_S = {"stat": 0.0, "aux": 0.0}
 
 
 def all_reduce(t, which, async_op=False, **kw):
-    """dist.all_reduce on the `which` ('stat' | 'aux') communicator, counted"""
+    """dist.all_reduce on the `which` ('stat' | 'aux') communicator, counted and host-timed"""
     COUNTS[which] += 1
-    return dist.all_reduce(t, group=stat_group() if which == "stat" else aux_group(), async_op=async_op, **kw)
+    t0 = time.perf_counter()
+    h = dist.all_reduce(t, group=stat_group() if which == "stat" else aux_group(), async_op=async_op, **kw)
+    HOST_S[which] += time.perf_counter() - t0
+    return h
+
+
+def wait(handle, which):
+    """handle.wait() of an async all_reduce of the `which` communicator, host-timed"""
+    t0 = time.perf_counter()
+    handle.wait()
+    HOST_S[which] += time.perf_counter() - t0
+
+
+def timeout():
+    """timeout of every process group this package creates (HIAST_DIST_TIMEOUT_S, default 180 s): a collective that one rank
+    never joins ends in an exception on the others instead of the backend's 10 / 30 minute default — the first RCCL hang would
+    otherwise burn a whole GPU lease and return nothing (reference: dist.init_process_group in code/train.py:52-59 runs on
+    torch's default)"""
+    return datetime.timedelta(seconds=float(os.environ.get("HIAST_DIST_TIMEOUT_S", "180")))
+
+
+def init_process_group(backend, **kw):
+    """dist.init_process_group(backend, timeout=timeout(), ...) + setup() of the statistics / auxiliary communicators"""
+    kw.setdefault("timeout", timeout())
+    dist.init_process_group(backend=backend, **kw)
+    setup()
+
+
+def apply_cu_reserve(world=None, device=None):
+    """HIAST_RESERVE_CUS=n (default 0 = off), honoured when the process group has more than one rank
+    (HIAST_RESERVE_CUS_FORCE=1: also in a single process — measuring what the reserve costs): the library sizes every persistent
+    / one-block-per-CU launch to CUs - n (hiast_set_reserve_cus) and the CURRENT stream of this thread becomes a stream whose
+    kernels cannot be placed on those n CUs (hiast_stream_create_reserved; side streams: functional.new_stream) — a collective's
+    kernel then always finds a CU no 60-160 us tile-kernel block holds (design risk at N > 1).  Call it once, after
+    torch.cuda.set_device and before the first launch.  -> the reserve in effect"""
+    import torch
+    n = int(os.environ.get("HIAST_RESERVE_CUS", "0") or 0)
+    if world is None:
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    if n <= 0 or (world <= 1 and os.environ.get("HIAST_RESERVE_CUS_FORCE", "0") != "1"):
+        return 0
+    from hiast_amd import kernels as K
+    K.reserve_cus(n)
+    n = K.reserve_cus()
+    torch.cuda.set_stream(K.reserved_stream(n, device))
+    return n
 
 
 def usable_cpus():

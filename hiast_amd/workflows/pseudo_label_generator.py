@@ -23,6 +23,7 @@ import torch.distributed as dist
 from PIL import Image
 from torch.utils.data import DataLoader, Sampler
 
+from hiast_amd import functional as HF
 from hiast_amd.utils import comm, utils
 from hiast_amd.utils.registry.registries import DATASET, PSEUDO_POLICY
 from hiast_amd.workflows import ias_math
@@ -91,7 +92,7 @@ class HipPlabelEngine:
     def post_stream(self):
         """the stream of everything behind pass 1 (context manager target)"""
         if getattr(self, "_post", None) is None:
-            self._post = torch.cuda.Stream(device=self.device)
+            self._post = HF.new_stream(self.device)
         return self._post
 
     @torch.no_grad()

@@ -122,12 +122,13 @@ class BaseTrainer:
             os.makedirs(self.checkpoint_dir_path, exist_ok=True)
         use_cuda = torch.cuda.is_available()
         if self.world > 1 and not dist.is_initialized():
+            # (timeout=comm.timeout(): a collective one rank never joins raises after HIAST_DIST_TIMEOUT_S instead of hanging)
             if "MASTER_ADDR" in os.environ and "RANK" in os.environ:
-                dist.init_process_group(backend="nccl" if use_cuda else "gloo")
+                dist.init_process_group(backend="nccl" if use_cuda else "gloo", timeout=comm.timeout())
             else:
                 dist.init_process_group(backend="nccl" if use_cuda else "gloo",
                                         init_method="tcp://127.0.0.1:{}".format(self.cfg.train.port),
-                                        world_size=self.world, rank=self.gpu_index)
+                                        world_size=self.world, rank=self.gpu_index, timeout=comm.timeout())
         if self.world > 1:
             comm.setup()        # communicators of the SyncBN sums and of the small exchanges, beside DDP's (utils/comm.py)
         if use_cuda:
@@ -135,6 +136,7 @@ class BaseTrainer:
             self.device_index = 0 if os.environ.get("HIAST_SAME_DEVICE", "0") == "1" else self.gpu_index
             torch.cuda.set_device(self.device_index)
             self.device = torch.device("cuda", self.device_index)
+            comm.apply_cu_reserve(self.world, self.device)     # HIAST_RESERVE_CUS=n at N > 1: a CU for the collectives' kernels
         else:
             raise RuntimeError("training runs on the HIP device; no GPU is visible and there is no CPU fallback")
 
@@ -242,7 +244,7 @@ class BaseTrainer:
         there is a 'D_loss', the discriminator step.  fp16 (amp_dtype) goes through the dynamic loss scaler like
         apex's amp.scale_loss (:129-131); bf16 autocast needs no loss scaling."""
         scaler = getattr(self, "scaler", None)
-        if self.__dict__.pop("_backward_done", False):
+        if getattr(losses, "backward_done", False):
             pass        # train() already ran forward AND backward (GraphedTrainStep: one captured HIP graph); the gradients
                         # are in place — and static: they must not be set to None
         else:

@@ -17,6 +17,13 @@ from hiast_amd.utils.result_recorder import ResultRecorder
 from hiast_amd.workflows.trainer.base_trainer import BaseTrainer
 
 
+class StepLosses(dict):
+    """the losses of an iteration whose backward pass has ALREADY run (GraphedTrainStep): `update_model` reads the marker from
+    the object it is handed, so a `train()` without a following `update_model()` (tools, tests, an exception in between) leaves
+    nothing behind that a later, unrelated `update_model()` could mistake for its own backward pass."""
+    backward_done = True
+
+
 class GraphedTrainStep:
     """train_on() + the backward pass of one HIAST iteration as ONE captured HIP graph (round 5).
 
@@ -29,7 +36,9 @@ class GraphedTrainStep:
     (the learning rate is a launch ARGUMENT of the optimiser kernel), validation, checkpoints.  Static shapes: a change of the
     batch's shape re-captures.  The first WARM iterations of a shape run eagerly (allocator, lazy initialisations).
     Gradients are bit-equal to the eager step's (tests/test_gpu_round5.py): same kernels, same order, same streams.
-    Single process only — under DDP the reducer's hooks have to run, the step stays eager."""
+    Single process only — under DDP the reducer's hooks have to run, the step stays eager.
+    Memory: the graph's private pool holds one iteration's activations for the life of the trainer; the blocks of the WARM eager
+    iterations are handed back to the device (`empty_cache`) before the capture, so the process keeps one such set, not two."""
     WARM = 3
 
     def __init__(self, trainer):
@@ -66,7 +75,7 @@ class GraphedTrainStep:
             self.seen += 1
             if self.seen <= self.WARM:                        # eager iterations of this shape
                 tr.g_optimizer.zero_grad(set_to_none=True)
-                return self._run(weak, strong, plbl)
+                return StepLosses(self._run(weak, strong, plbl))
             self.s_weak = weak.clone()
             self.s_strong = self.s_weak if strong is weak else strong.clone()
             self.s_plbl = plbl.clone()
@@ -74,6 +83,7 @@ class GraphedTrainStep:
                 plan.versions = None              # the re-pack launches must be IN the graph whatever moved last
             tr.g_optimizer.zero_grad(set_to_none=True)        # the graph's backward allocates the (from now on static) gradients
             torch.cuda.synchronize()
+            torch.cuda.empty_cache()            # the eager warm-up's activation blocks: the graph allocates from a pool of its own
             g = torch.cuda.CUDAGraph()
             try:
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
@@ -83,10 +93,16 @@ class GraphedTrainStep:
                 warnings.warn("GraphedTrainStep: capture failed (%r); the iterations stay eager" % (e,))
                 tr._graph_train = False
                 torch.cuda.synchronize()
+                # the failed capture RECORDED the re-pack launches without running them, yet marked every plan as up to date
+                # (PackPlan.refresh) and published its buffers: the eager rerun must pack again, or this iteration would read the
+                # packed weights from before the last optimiser / EMA step
+                for plan in self._plans():
+                    plan.versions = None
+                    plan.published = False
                 tr.g_optimizer.zero_grad(set_to_none=True)
-                return self._run(weak, strong, plbl)
+                return StepLosses(self._run(weak, strong, plbl))
             self.graph = g
-            self.losses = {k: v.detach() for k, v in losses.items()}
+            self.losses = StepLosses((k, v.detach()) for k, v in losses.items())
         else:
             self.s_weak.copy_(weak, non_blocking=True)
             if self.s_strong is not self.s_weak:
@@ -143,7 +159,7 @@ class ConsistencySelfTrainingTrainer(BaseTrainer):
         # the student forward; the loss waits for both
         main = torch.cuda.current_stream()
         if getattr(self, "_side_stream", None) is None:
-            self._side_stream = torch.cuda.Stream(device=t_weak_img.device)
+            self._side_stream = HF.new_stream(t_weak_img.device)
         side = self._side_stream
         side.wait_stream(main)
         if getattr(self, "_teacher_fwd", None) is None or self._teacher_fwd.model is not self.ema_model:
@@ -175,9 +191,7 @@ class ConsistencySelfTrainingTrainer(BaseTrainer):
             # forward + backward from a captured HIP graph (GraphedTrainStep): update_model() finds the gradients in place
             if getattr(self, "_graphed_step", None) is None:
                 self._graphed_step = GraphedTrainStep(self)
-            losses = self._graphed_step(weak, strong, plbl)
-            self._backward_done = True
-            return losses
+            return self._graphed_step(weak, strong, plbl)      # (StepLosses: carries the "backward has run" marker)
         return self.train_on(weak, strong, plbl)
 
     def graph_train_enabled(self):

@@ -11,7 +11,8 @@
  *   - calls only ENQUEUE work on `stream` (a hipStream_t passed as void*); they never
  *     synchronise the device, so a caller's DDP/compute overlap is preserved;
  *   - return value: 0 = ok, <0 = argument error (HIAST_E_*), >0 = a hipError_t;
- *   - thread-safe for distinct streams; no global state.
+ *   - thread-safe for distinct streams; the only state is the tuning environment (read once), the thread-local
+ *     co-scheduling hint (hiast_igemm_set_cosched) and the process-wide CU reserve (hiast_set_reserve_cus).
  *
  * Each entry point cites the reference call it stands in for (paths under
  * bupt-ai-cz/HIAST `code/`).  The reference has no native code: these replace
@@ -27,7 +28,7 @@
 extern "C" {
 #endif
 
-#define HIAST_ABI_VERSION 5
+#define HIAST_ABI_VERSION 6
 
 #define HIAST_E_ARG   (-1) /* null pointer / non-positive extent */
 #define HIAST_E_RANGE (-2) /* extent outside what the kernels are built for */
@@ -56,6 +57,24 @@ typedef void* hiast_stream_t;
 int hiast_version(void);
 /* host: static string for a negative HIAST_E_* code, "hip error" otherwise */
 const char* hiast_error_string(int code);
+
+/* ---- device geometry and the CU reserve (ABI 6; host) -------------------------------------------------------------------
+ * Stands in for nothing in the reference (apex / NCCL on NVSwitch hardware has no such knob): under DDP + SyncBN
+ * (code/workflows/trainer/base_trainer.py:43-56, code/utils/utils.py:103-105) 208 chained [C,2] all-reduces per step each need a
+ * free compute unit for RCCL's kernel while the side streams keep every CU busy with 60-160 us tile-kernel blocks.
+ * hiast_device_cus(): compute units of the current device (hipDeviceGetAttribute; 0 when no device is visible).
+ * hiast_set_reserve_cus(n): from now on every one-block-per-CU / persistent launch of this library (xconv*, stem*, pass 1,
+ *   weight-gradient work splits) sizes its grid to CUs - n (n is rounded up to a multiple of 8, one per XCD; n <= CUs / 2);
+ *   returns the previous value.  Process-wide; call it once before the first launch (work splits, i.e. partial-sum row counts
+ *   and summation orders, depend on it).
+ * hiast_stream_create_reserved(&s, n): a stream on which NO kernel (ours or torch's) can be placed on n of the CUs (queue CU
+ *   mask, hipExtStreamCreateWithCUMask; n / 8 CUs of every XCD) — what keeps the non-persistent tile kernels off them.
+ *   Destroy with hiast_stream_destroy. */
+int hiast_device_cus(void);
+int hiast_set_reserve_cus(int n);
+int hiast_get_reserve_cus(void);
+int hiast_stream_create_reserved(hiast_stream_t* out, int reserve);
+int hiast_stream_destroy(hiast_stream_t s);
 
 /* ---- K2: bilinear upsample, align_corners=True ------------------------------------
  * F.interpolate(logits, size, mode='bilinear', align_corners=True):
@@ -261,23 +280,21 @@ int hiast_igemm_bn_act(const void* x, const void* wp, const float* gamma, const 
                        const float* var, float eps, const void* res, int relu, void* y, int B, int H, int W, int Cin,
                        int Cout, int taps, int stride, int dil, int fmt /* HIAST_FMT_*: "planes" above = 2 for SPLIT_BF16, 1 otherwise;
                        FP16: everything said of planes = 1 with fp16 rows */, int out_f32, float* stats,
+                       int stats_rows /* rows of `stats` the caller allocated = hiast_igemm_stats_rows(...) (ignored when stats is
+                       NULL): the launch returns HIAST_E_ARG when the tile form it takes writes another number of rows (ABI 6;
+                       never more than ceil(M / 128) rows) */,
                        const void* res_gate, int gate_mask, hiast_stream_t stream);
-/* ---- K9m (round 5): the tail of a bottleneck in the inference forwards as ONE launch ------------------------------------
- *     y = relu( bn3( conv3_1x1( relu( bn2( conv2_3x3(x) ) ) ) ) + res )
- * (Bottleneck.forward, sseg/models/modules/resnet.py:84-98, in the eval forward of IASPseudoGenerator.run,
- * workflows/pseudo_label_generator.py:190-192, and of the EMA teacher, trainer/consistency_self_training_trainer.py:92-126.)
- * Replaces two hiast_igemm_bn_act launches; the Cmid-channel activation between the two convolutions stays in registers
- * (b2b.hip).  Operand formats and packed weights exactly as hiast_igemm_bn_act: x [B,H,W,planes*Cmid], w2p packed
- * [Cmid][9][planes*Cmid] (3x3, stride 1, padding = dilation = dil), w3p packed [Cout][1][planes*Cmid], res / y
- * [B,H,W,planes*Cout]; both BatchNorms in eval form (gamma / beta may be NULL = 1 / 0).  Same products in the same order as
- * the two launches.  Cmid == 256, Cout % 64 == 0, Cout <= 1024, B*H*W >= 4096, every tensor < 2 GiB, 16-byte aligned:
- * hiast_bottleneck_tail_ok() says whether the caller should take it: the shape limits above AND HIAST_B2B=1 in the
- * environment — the launch is opt-in: bit-equal to the two launches but measured slower in the step. */
-int hiast_bottleneck_tail_ok(int B, int H, int W, int Cmid, int Cout, int stride, int fmt);
-int hiast_bottleneck_tail(const void* x, const void* w2p, const float* gamma2, const float* beta2, const float* mean2,
-                          const float* var2, float eps2, const void* w3p, const float* gamma3, const float* beta3,
-                          const float* mean3, const float* var3, float eps3, const void* res, void* y, int B, int H, int W,
-                          int Cmid, int Cout, int dil, int fmt /* HIAST_FMT_* */, hiast_stream_t stream);
+/* host: the co-scheduling hint of the CALLING THREAD (thread-local; ABI 6, replaces the HIAST_IGEMM_COSCHED environment
+ * variable that round 5 set and unset around every forward): on != 0 = "this thread runs two launch sequences side by side
+ * on two streams" — half-chip launches then keep the 256-row tile form (two of them fill the chip) instead of the 128 x 128 /
+ * two-blocks-per-CU form.  on < 0 = back to the process default (HIAST_IGEMM_COSCHED, read once).  Returns the previous value
+ * (-1 = default).  The hint enters hiast_igemm_stats_rows / hiast_igemm_dgrad_bn_stats_rows and the launches alike; a launch
+ * checks the caller's row count against the form it takes. */
+int hiast_igemm_set_cosched(int on);
+/* host, A/B and tests: force the tile form of the calling thread's launches — 1 = the 128 x 128 form wherever it is instantiated,
+ * 0 = never, < 0 = automatic (the HIAST_IGEMM_HALF environment variable, read once, else the measured rule).  Returns the
+ * previous value. */
+int hiast_igemm_set_half(int v);
 /* host: number of partial-sum rows hiast_igemm_bn_act writes into `stats` [rows][Cout][2] for M = B*Ho*Wo output pixels
  * (one row per block of the kernel chosen for the shape) */
 int hiast_igemm_stats_rows(int64_t M, int Cin, int Cout, int taps, int fmt);
@@ -291,8 +308,9 @@ int hiast_igemm_stats_rows(int64_t M, int Cin, int Cout, int taps, int fmt);
  * data gradient + ATen batch_norm_backward reduce, each a pass of its own). */
 int hiast_igemm_dgrad_bn_stats(const void* dy, const void* wpt, void* da, int B, int H, int W, int Cin, int Cout, int taps,
                                int dil, const void* bn_x, const float* gamma, const float* beta, const float* save_mean,
-                               const float* save_invstd, float* partial, int fmt /* HIAST_FMT_BF16 | HIAST_FMT_FP16 */,
-                               hiast_stream_t stream);
+                               const float* save_invstd, float* partial, int partial_rows /* = hiast_igemm_dgrad_bn_stats_rows(...);
+                               HIAST_E_ARG on a mismatch with the tile form the launch takes (ABI 6) */,
+                               int fmt /* HIAST_FMT_BF16 | HIAST_FMT_FP16 */, hiast_stream_t stream);
 int hiast_igemm_dgrad_bn_stats_rows(int64_t M, int Cin, int Cout, int taps);
 /* Data gradient of the trunk's 3x3 / stride-2 / padding-1 convolution (layer2.0.conv2; autograd of nn.Conv2d in
  * Bottleneck.forward, resnet.py:78-98 — round 4, was the library's): dx [B,H,W,Cin] from dy [B,(H-1)/2+1,(W-1)/2+1,Cout]

@@ -55,11 +55,32 @@ def _check_collectives(out):
     assert c["gradient_buckets"] == 6, c
 
 
+_uncapped = {}
+
+
 def test_bench_two_ranks_through_spawn_ranks_gloo_same_device():
     out, err = _run_bench(["--same-device", "--backend", "gloo", "--batch", "2"])
     _check(out, 2)
     _check_collectives(out)
     assert "grad strides do not match bucket view" not in err
+    assert out["config"]["cu_reserve"] == 0
+    h = out["collectives_per_step"]["host_ms_per_step"]          # host time inside the calls of each communicator (round 6)
+    assert h["stat"] > 0 and h["aux"] > 0
+    _uncapped["losses"] = out["final_losses"]
+
+
+def test_bench_two_ranks_with_a_cu_reserve_gloo_same_device():
+    """HIAST_RESERVE_CUS=8 at N > 1: every persistent launch sized to 248 CUs, main and side streams with
+    the queue CU mask — same collectives, ranks agree, and the same losses as without the reserve (the reserve changes work
+    splits, i.e. summation orders of partial sums, nothing else)"""
+    out, err = _run_bench(["--same-device", "--backend", "gloo", "--batch", "2"], env_extra={"HIAST_RESERVE_CUS": "8"})
+    _check(out, 2)
+    _check_collectives(out)
+    assert out["config"]["cu_reserve"] == 8 and out["collectives_per_step"]["cu_reserve"] == 8
+    if "losses" not in _uncapped:
+        _uncapped["losses"] = _run_bench(["--same-device", "--backend", "gloo", "--batch", "2"])[0]["final_losses"]
+    for k, v in out["final_losses"].items():
+        assert abs(v - _uncapped["losses"][k]) <= 2e-3 * max(1.0, abs(v)), (k, v, _uncapped["losses"][k])
 
 
 def test_bench_two_ranks_through_spawn_ranks_rccl():

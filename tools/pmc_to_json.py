@@ -41,7 +41,9 @@ def main():
             if c in v:
                 ent[c] = v[c]
         kernels.append(ent)
-    out = {"source": "%s (tools/pmc_igemm.sh on the kernels of the tree at collection time)" % os.path.basename(src),
+    from hiast_amd import _lib
+    out = {"kernel_sources_sha16": _lib.kernel_sources_sha16(),      # bench.py flags `traffic` as stale on another build
+           "source": "%s (tools/pmc_igemm.sh on the kernels of the tree at collection time)" % os.path.basename(src),
            "command": "tools/pmc_igemm.sh: rocprofv3 --pmc <one counter group per pass> --output-format csv -- python3 "
                       "tools/pmc_igemm.py <shape>; means over 6 launches per shape",
            "correction": "hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024: on gfx950 FETCH_SIZE counts 128-B fabric "
