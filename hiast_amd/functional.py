@@ -721,15 +721,27 @@ class GraphedEval:
     — bench.py 61.4 (graphs) vs 60.2 ms/step (eager) on one box, the DataLoader-fed trainer unchanged.  The generator, whose
     host used to start every batch without a lead over the device, gained 10 % from it (147.6 -> 163.0 images/s) until its
     batches were pipelined (forward of batch t+1 enqueued before the histogram of batch t is awaited): 487 eager vs 473
-    replayed."""
+    replayed.
+    Round 6 — AUTOMATIC for small batches (HIAST_GRAPH_EVAL unset): a forward over at most AUTO_MAX_BATCH images is launch-bound
+    (the ~330 launches cost the host 3-4 ms whatever the batch, the device 1-2 ms at one or two images: bench.py --batch 1 ran at
+    the host's enqueue floor, the generator at the reference's batch size 2 at 339 images/s against 521 at batch 8), so it is
+    replayed; larger batches stay eager as before.  An eval forward holds no collective (BatchNorm in eval mode), so this also
+    holds under DDP, where the training step itself cannot be captured.  Inside another capture (GraphedTrainStep) the forward
+    runs eagerly — into that graph."""
     WARMUP = 2
+    AUTO_MAX_BATCH = int(os.environ.get("HIAST_GRAPH_EVAL_MAX_BATCH", "4"))
 
-    def __init__(self, model, amp_dtype=None, parts=None, graph=False):
+    def __init__(self, model, amp_dtype=None, parts=None, graph=False, auto=True):
         """parts: as eval_forward_split takes them (None = its default: two sub-batches for 8 or more images, 1 = one
-        launch sequence); graph: this caller's default; HIAST_GRAPH_EVAL=1 / 0 overrides it for every caller"""
+        launch sequence); graph: this caller's default; HIAST_GRAPH_EVAL=1 / 0 overrides it for every caller; auto=False: no
+        automatic replay of small batches either (a caller whose whole iteration is a captured graph already)"""
         self.model, self.amp_dtype, self.parts = model, amp_dtype, parts
         self.entries = {}
-        self.enabled = os.environ.get("HIAST_GRAPH_EVAL", "1" if graph else "0") == "1"
+        env = os.environ.get("HIAST_GRAPH_EVAL", "1" if graph else "")
+        self.enabled = (None if auto else False) if env == "" else env == "1"        # None: automatic (small batches)
+
+    def wants_graph(self, x):
+        return self.enabled if self.enabled is not None else x.shape[0] <= self.AUTO_MAX_BATCH
 
     def _autocast(self):
         return torch.autocast("cuda", dtype=self.amp_dtype or torch.bfloat16, enabled=self.amp_dtype is not None,
@@ -750,7 +762,8 @@ class GraphedEval:
         """parts: sub-batches for this call as eval_forward_split takes them (None = its default: 2 for 8 or more images),
         "ctor" = the constructor's; eager: no graph this time"""
         parts = self.parts if isinstance(parts, str) else parts
-        if eager or not self.enabled or not x.is_cuda or self.model.training:
+        if (eager or not x.is_cuda or self.model.training or not self.wants_graph(x)
+                or torch.cuda.is_current_stream_capturing()):
             return self._eager(x, parts)
         key = (tuple(x.shape), x.dtype, x.device, self.amp_dtype, parts)
         e = self.entries.get(key)

@@ -164,7 +164,8 @@ class ConsistencySelfTrainingTrainer(BaseTrainer):
         side.wait_stream(main)
         if getattr(self, "_teacher_fwd", None) is None or self._teacher_fwd.model is not self.ema_model:
             # no-grad eval forward under autocast(amp_dtype) (HIAST_GRAPH_EVAL=1: replayed from a captured HIP graph)
-            self._teacher_fwd = HF.GraphedEval(self.ema_model, self.amp_dtype, parts=1)
+            # (small batches are replayed automatically — unless the whole iteration is a captured graph already)
+            self._teacher_fwd = HF.GraphedEval(self.ema_model, self.amp_dtype, parts=1, auto=not self.graph_train_enabled())
         with torch.cuda.stream(side):
             teacher_lr = self._teacher_fwd(t_weak_img)
         utils.set_mode(self.model, True)

@@ -184,7 +184,7 @@ def test_graphed_inference_forward_replays_the_eager_launches(amp, monkeypatch):
     """HF.GraphedEval: two eager calls, then the forward is captured into a HIP graph and replayed.  The graph holds the
     launches of the eager forward, so its logits are the eager logits bit for bit — for a new input, after the weights
     moved (the packed copies are refreshed outside of the graph, as after an EMA step), and for the two-sub-batch form;
-    without HIAST_GRAPH_EVAL=1 nothing is captured."""
+    HIAST_GRAPH_EVAL=0: nothing is captured; unset (round 6): small batches only."""
     from hiast_amd import functional as HF
     monkeypatch.setenv("HIAST_GRAPH_EVAL", "1")
     cfg, net = _model(782)
@@ -207,11 +207,24 @@ def test_graphed_inference_forward_replays_the_eager_launches(amp, monkeypatch):
         assert len(e) == 1 and e[0]["graph"] is not None and not e[0].get("failed"), "the forward was never captured"
     assert not torch.equal(g(xs[0]).clone(), g(xs[1]))
 
-    monkeypatch.delenv("HIAST_GRAPH_EVAL")
+    monkeypatch.setenv("HIAST_GRAPH_EVAL", "0")
     g = HF.GraphedEval(net, amp)
     for x in xs[:4]:
         g(x)
     assert not g.entries
+    # unset: automatic — a forward over at most AUTO_MAX_BATCH images is launch-bound and replayed, larger batches stay eager
+    monkeypatch.delenv("HIAST_GRAPH_EVAL")
+    g = HF.GraphedEval(net, amp)
+    assert g.enabled is None and g.wants_graph(xs[0]) and not g.wants_graph(torch.empty(8, 3, 64, 128))
+    big = torch.cat([xs[0], xs[1]], 0)                      # 8 images
+    for _ in range(4):
+        g(big)
+    assert not g.entries
+    outs = [g(xs[0]).clone() for _ in range(4)]
+    e = list(g.entries.values())
+    assert len(e) == 1 and e[0]["graph"] is not None
+    ref = g(xs[0], eager=True)
+    assert all(torch.equal(o, ref) for o in outs)
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 37, 53), (1, 64, 64, 128), (3, 32, 8, 9)])

@@ -85,11 +85,12 @@ def test_eval_forward_split_sets_no_environment_variable(K, monkeypatch):
     """the sub-batch forwards pass the co-scheduling hint through the library's thread-local setter: os.environ is not touched
     (setenv / unsetenv around every forward raced with getenv in the DataLoader's and the runtime's threads)"""
     from hiast_amd import functional as HF
+    from hiast_amd.utils.default_config import get_default_cfg
     from hiast_amd.utils.registry import register  # noqa: F401
-    from hiast_amd.utils.registry.registries import SEG_MODEL
+    from hiast_amd.utils.registry.registries import MODEL
     from make_golden import seeded_state_dict
-    m = SEG_MODEL["DeepLab_V2"](19, 256)
-    m.load_state_dict(seeded_state_dict(m, 9100))
+    m = MODEL["SelfTrainingSegmentor"](get_default_cfg())
+    m.load_state_dict({"seg_model." + k: v for k, v in seeded_state_dict(m.seg_model, 9100).items()})
     m = m.cuda().eval()
     x = torch.from_numpy(synth.normal_f32(6100, (2, 3, 128, 256))).cuda()
     seen = []

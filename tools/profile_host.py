@@ -12,9 +12,10 @@ import bench  # noqa: E402
 
 
 def main():
+    batch = int(sys.argv[1]) if len(sys.argv) > 1 else 8       # python tools/profile_host.py [images per step]
     torch.cuda.set_device(0)
     cfg = bench.make_cfg(1, "ConsistencySelfTrainingTrainer")
-    hp = bench.HotPath(cfg, torch.device("cuda", 0), 0, 1, 8)
+    hp = bench.HotPath(cfg, torch.device("cuda", 0), 0, 1, batch)
     for _ in range(3):
         hp.step()
     torch.cuda.synchronize()
@@ -25,8 +26,8 @@ def main():
     pr.disable()
     torch.cuda.synchronize()
     st = pstats.Stats(pr)
-    st.sort_stats("tottime").print_stats(35)
-    st.sort_stats("cumulative").print_stats(45)
+    st.sort_stats("tottime").print_stats(60)
+    st.sort_stats("cumulative").print_stats(70)
 
 
 if __name__ == "__main__":
