@@ -722,14 +722,14 @@ class GraphedEval:
     host used to start every batch without a lead over the device, gained 10 % from it (147.6 -> 163.0 images/s) until its
     batches were pipelined (forward of batch t+1 enqueued before the histogram of batch t is awaited): 487 eager vs 473
     replayed.
-    Round 6 — AUTOMATIC for small batches (HIAST_GRAPH_EVAL unset): a forward over at most AUTO_MAX_BATCH images is launch-bound
-    (the ~330 launches cost the host 3-4 ms whatever the batch, the device 1-2 ms at one or two images: bench.py --batch 1 ran at
-    the host's enqueue floor, the generator at the reference's batch size 2 at 339 images/s against 521 at batch 8), so it is
-    replayed; larger batches stay eager as before.  An eval forward holds no collective (BatchNorm in eval mode), so this also
-    holds under DDP, where the training step itself cannot be captured.  Inside another capture (GraphedTrainStep) the forward
-    runs eagerly — into that graph."""
+    Round 6 — an automatic mode for small batches exists (HIAST_GRAPH_EVAL unset and HIAST_GRAPH_EVAL_MAX_BATCH=n: forwards over
+    at most n images are replayed) and is OFF (n = 0), by measurement (profiles/r06_ab_graph_eval_small_batch.txt): the forwards
+    of a launch-bound step ARE cheaper to replay (pseudo-label forward 1.98 -> 0.67 ms of host time at one image), but on this
+    runtime (ROCm 7.2) a replayed graph of ~330 kernel nodes slows the eager launches that follow it — bench.py --batch 1
+    28.1 -> 34.3 ms/step (the backward's enqueue time 14.6 -> 21.7 ms), --batch 2 21.8 -> 24.3, the generator at batch size 2
+    339 -> 315 images/s.  Inside another capture (GraphedTrainStep) the forward always runs eagerly — into that graph."""
     WARMUP = 2
-    AUTO_MAX_BATCH = int(os.environ.get("HIAST_GRAPH_EVAL_MAX_BATCH", "4"))
+    AUTO_MAX_BATCH = int(os.environ.get("HIAST_GRAPH_EVAL_MAX_BATCH", "0"))
 
     def __init__(self, model, amp_dtype=None, parts=None, graph=False, auto=True):
         """parts: as eval_forward_split takes them (None = its default: two sub-batches for 8 or more images, 1 = one

@@ -212,8 +212,11 @@ def test_graphed_inference_forward_replays_the_eager_launches(amp, monkeypatch):
     for x in xs[:4]:
         g(x)
     assert not g.entries
-    # unset: automatic — a forward over at most AUTO_MAX_BATCH images is launch-bound and replayed, larger batches stay eager
+    # unset + HIAST_GRAPH_EVAL_MAX_BATCH=n: automatic — forwards over at most n images are replayed, larger batches stay eager
+    # (off by default: measured slower end to end on this runtime, profiles/r06_ab_graph_eval_small_batch.txt)
     monkeypatch.delenv("HIAST_GRAPH_EVAL")
+    assert HF.GraphedEval.AUTO_MAX_BATCH == 0 and not HF.GraphedEval(net, amp).wants_graph(xs[0])
+    monkeypatch.setattr(HF.GraphedEval, "AUTO_MAX_BATCH", 4)
     g = HF.GraphedEval(net, amp)
     assert g.enabled is None and g.wants_graph(xs[0]) and not g.wants_graph(torch.empty(8, 3, 64, 128))
     big = torch.cat([xs[0], xs[1]], 0)                      # 8 images
