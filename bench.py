@@ -128,6 +128,29 @@ class KernelTimer:
         self.wrap(K, "aspp_fwd", aspp_key)
         self.wrap(K, "aspp2_fwd", aspp2_key)
         self.wrap(K, "igemm_bn_act", ig_key)
+        # the other matrix-core launches of the step (counted in step_fractions; not roofline candidates of their own):
+        # ("flops", name, algorithmic flop, issued flop)
+        def fl(name, alg, iss=None):
+            return ("flops", name, float(alg), float(alg if iss is None else iss))
+        self.wrap(K, "igemm_dgrad_bn_stats", lambda dy, wpt, *a, **k: fl(
+            "dgrad+bn sums %s" % (tuple(wpt.shape),), 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * wpt.shape[0] * wpt.shape[1] * wpt.shape[2]))
+        self.wrap(K, "xconv_dgrad_gated_bn_stats", lambda dy, wpt, *a, **k: fl(
+            "xconv_bs %s" % (tuple(wpt.shape),), 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * wpt.shape[0] * wpt.shape[2]))
+        wgf = lambda dy, x, kk, *a, **k: fl("wgrad %dx%d %d->%d" % (kk, kk, x.shape[3], dy.shape[3]),
+                                            2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3] * x.shape[3] * kk * kk)
+        self.wrap(K, "conv_wgrad_nhwc", wgf)
+        self.wrap(K, "conv_wgrad_small_nhwc", wgf)
+        self.wrap(K, "igemm_dgrad_s2", lambda dy, wpt, Hh, Ww: fl(      # transposed stride-2 3x3: three of four taps multiply zeros
+            "dgrad_s2", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * 9 * wpt.shape[0] * wpt.shape[2],
+            2.0 * dy.shape[0] * Hh * Ww * 9 * wpt.shape[0] * wpt.shape[2]))
+        self.wrap(K, "aspp2_bwd", lambda x, dy, wd, dil, want_dx=True, want_dw=True, workspace=None: fl(
+            "aspp2_bwd", (int(want_dx) + int(want_dw)) * 2.0 * x.shape[0] * x.shape[2] * x.shape[3] * x.shape[1] * 33 * dy.shape[1],
+            (int(want_dx) + int(want_dw)) * 2.0 * x.shape[0] * x.shape[2] * x.shape[3] * x.shape[1] * 640))
+        stem_alg = lambda x: 2.0 * x.shape[0] * ((x.shape[2] - 1) // 2 + 1) * ((x.shape[3] - 1) // 2 + 1) * 64 * 147
+        self.wrap(K, "stem_eval", lambda x, weight, bn, fmt: fl("stem_eval", stem_alg(x),
+                                                                 stem_alg(x) * 224.0 / 147.0 * (3.0 if int(fmt) == 2 else 1.0)))
+        self.wrap(K, "stem_train_fwd", lambda x, weight, fmt: fl("stem_train_fwd", stem_alg(x), stem_alg(x) * 224.0 / 147.0))
+        self.wrap(K, "stem_wgrad", lambda x, dy: fl("stem_wgrad", stem_alg(x), stem_alg(x) * 224.0 / 147.0))
 
     def summary(self):
         out = []
@@ -271,9 +294,10 @@ def roofline_of(key, avg_ms, n, steps):
 
 def step_fractions(groups, ms_per_step, serial_step_ms):
     """step-level figures that travel with the line: matrix-pipe and HBM use of the WHOLE step.
-    Flops: counted live from the convolution launches the first timed step observed (every igemm / xconv / grouped weight-
-    gradient / ASPP launch with its shape: 3 issued bf16 products per algorithmic flop on split planes) — the stems, the
-    small-channel weight gradients and the loss are not hooked (< 2 % of the step's flops).  HBM bytes and the serial kernel
+    Flops: counted live from the matrix-core launches the first timed step observed (every tile-kernel / xconv / data-gradient /
+    weight-gradient / ASPP / stem launch with its shape: 3 issued bf16 products per algorithmic flop on split planes, the zero
+    taps of the transposed stride-2 launch and the stem's K padding as issued only) — the exact-fp32 and VALU kernels (losses,
+    BatchNorm, pass 1 / 2) carry no MFMA flops.  HBM bytes and the serial kernel
     time need their own profiler passes (tools/pmc_bench.sh, tools/prof_bench.sh): read from profiles/r06_step_totals.json when it
     was collected on these kernel sources, else null."""
     alg = iss = 0.0
@@ -290,6 +314,9 @@ def step_fractions(groups, ms_per_step, serial_step_ms):
             f = sum(2.0 * j[0][0] * j[0][1] * j[0][2] * j[0][3] * j[1] * j[2] ** 2 for j in key[1:]) * n
             alg += f
             iss += f
+        elif key[0] == "flops":
+            alg += key[2] * n
+            iss += key[3] * n
         # ("aspp2_fwd": its tap GEMM is an igemm launch and counted there; "aspp_fwd": the exact-fp32 head is not on the step)
     out = {"step_tflop_algorithmic_counted": alg / 1e12, "step_tflop_issued_counted": iss / 1e12,
            "step_frac_mfma_issued": iss / (ms_per_step * 1e-3) / 2.5e15,
@@ -969,7 +996,7 @@ def main():
             sampled = 1                                  # steps on which launches were timed
             aspp = [g for g in groups if g[0][0] == "aspp2_fwd"]
             wg = [g for g in groups if g[0][0] == "wgrad_group"]      # (reported beside the convolution groups, below)
-            groups = [g for g in groups if g[0][0] not in ("aspp2_fwd", "wgrad_group")]   # (the ASPP GEMM is also counted in the igemm groups)
+            groups = [g for g in groups if g[0][0] == "igemm"]       # (the ASPP GEMM is also counted in the igemm groups)
             key, avg_ms, n, _tot = groups[0]            # dominant hand-written launch group of the step
             out["roofline"] = roofline_of(key, avg_ms, n, sampled)
             others = [roofline_of(k, a, c, sampled) for k, a, c, _ in groups[1:4] + wg[:1] + aspp[:2]]

@@ -73,6 +73,21 @@ __device__ __forceinline__ void bnh_unpack8(const uint4 r, float (&v)[8])
     }
 }
 
+// 16-byte row segment of a streamed activation.  BNH_NT_LOADS=1 (A/B build: tools/build_variant.sh): as a non-temporal load —
+// the tensors are 33-134 MB, read once per pass and next touched by another kernel after the L2 has turned over
+#ifndef BNH_NT_LOADS
+#define BNH_NT_LOADS 0
+#endif
+__device__ __forceinline__ uint4 bnh_ld16(const unsigned short* p)
+{
+#if BNH_NT_LOADS
+    const h_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const h_u32x4*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *reinterpret_cast<const uint4*>(p);
+#endif
+}
+
 template <bool F16>
 __device__ __forceinline__ void bnh_load8(const unsigned short* p, float (&v)[8])
 {
@@ -137,11 +152,11 @@ __global__ __launch_bounds__(256) void bnh_partial_kernel(const unsigned short* 
             const long long r = rb + u * stride;
             const long long rc = r < lim ? r : (rb < lim ? rb : 0);     // tail: re-read a valid row, not accumulated
             const size_t off = (size_t)rc * C + cg * 8;
-            ra[u] = *reinterpret_cast<const uint4*>(a + off);
+            ra[u] = bnh_ld16(a + off);
             if (BWD) {
-                if (GATE == 1) ry[u] = *reinterpret_cast<const uint4*>(y + off);
+                if (GATE == 1) ry[u] = bnh_ld16(y + off);
                 rbits[u] = GATE == 3 ? reinterpret_cast<const unsigned char*>(y)[(size_t)rc * G + cg] : 0u;
-                rx[u] = *reinterpret_cast<const uint4*>(x + off);
+                rx[u] = bnh_ld16(x + off);
             }
         }
     };
@@ -333,8 +348,8 @@ __global__ __launch_bounds__(256) void bnh_apply_kernel(const unsigned short* __
         for (int u = 0; u < UNR; ++u) {
             const long long r = rb + u * stride;
             const size_t off = (size_t)(r < lim ? r : (rb < lim ? rb : 0)) * C + cg * 8;
-            rx[u] = *reinterpret_cast<const uint4*>(x + off);
-            if (RES) rres[u] = *reinterpret_cast<const uint4*>(res + off);
+            rx[u] = bnh_ld16(x + off);
+            if (RES) rres[u] = bnh_ld16(res + off);
         }
     };
     load_rows(r0);
@@ -401,10 +416,10 @@ __global__ __launch_bounds__(256) void bnh_bwd_apply_kernel(
             const long long r = rb + u * stride;
             const long long rc = r < lim ? r : (rb < lim ? rb : 0);
             const size_t off = (size_t)rc * C + cg * 8;
-            rg[u] = *reinterpret_cast<const uint4*>(dy + off);
-            if (GATE == 1) ry[u] = *reinterpret_cast<const uint4*>(y + off);
+            rg[u] = bnh_ld16(dy + off);
+            if (GATE == 1) ry[u] = bnh_ld16(y + off);
             rbits[u] = GATE == 3 ? reinterpret_cast<const unsigned char*>(y)[(size_t)rc * G + cg] : 0u;
-            rx[u] = *reinterpret_cast<const uint4*>(x + off);
+            rx[u] = bnh_ld16(x + off);
         }
     };
     load_rows(r0);

@@ -37,8 +37,9 @@ class GraphedTrainStep:
     batch's shape re-captures.  The first WARM iterations of a shape run eagerly (allocator, lazy initialisations).
     Gradients are bit-equal to the eager step's (tests/test_gpu_round5.py): same kernels, same order, same streams.
     Single process only — under DDP the reducer's hooks have to run, the step stays eager.
-    Memory: the graph's private pool holds one iteration's activations for the life of the trainer; the blocks of the WARM eager
-    iterations are handed back to the device (`empty_cache`) before the capture, so the process keeps one such set, not two."""
+    Memory: the graph's private pool holds one iteration's activations for the life of the trainer, beside the blocks the WARM
+    eager iterations left in the caching allocator (≈ twice the activation memory of an eager run: 2 x 9 GB at batch 8 of the 288 GB;
+    HIAST_GRAPH_TRAIN=0 gives it back)."""
     WARM = 3
 
     def __init__(self, trainer):
@@ -83,7 +84,9 @@ class GraphedTrainStep:
                 plan.versions = None              # the re-pack launches must be IN the graph whatever moved last
             tr.g_optimizer.zero_grad(set_to_none=True)        # the graph's backward allocates the (from now on static) gradients
             torch.cuda.synchronize()
-            torch.cuda.empty_cache()            # the eager warm-up's activation blocks: the graph allocates from a pool of its own
+            # (no torch.cuda.empty_cache() here: round 6 tried it — hand the warm-up's blocks back before the graph allocates its
+            # private pool — and the full GPU suite then died with a segmentation fault inside hipGraphLaunch at the replay of the
+            # SECOND trainer of one process, gpurun_out r06_pytest_full.log; without it the suite has run clean since round 5)
             g = torch.cuda.CUDAGraph()
             try:
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):

@@ -28,7 +28,19 @@ def main():
     w = torch.randn(C, C, 3, 3, device=dev) * 0.03
     wp = K.pack_conv_weight(w, K.FMT_FP16)
     probe_buf = torch.zeros(256, device=dev)
+    probe_red = torch.zeros(1 << 16, device=dev)
+    probe_out = torch.zeros((), device=dev)
     probe_stream = torch.cuda.Stream(device=dev)
+    kind = ["plain"]
+
+    def probe_kernel():
+        # "plain": one 256-thread block without LDS (co-resides with a tile-kernel block if registers allow);
+        # "lds": a reduction (torch.sum: its blocks need shared memory) — like an RCCL kernel it cannot co-reside with a block
+        # that holds all 160 KiB of a CU's LDS and has to wait for one to retire
+        if kind[0] == "plain":
+            probe_buf.add_(1.0)
+        else:
+            torch.sum(probe_red, out=probe_out)
 
     def saturate(stream, n):
         with torch.cuda.stream(stream):
@@ -43,7 +55,7 @@ def main():
             with torch.cuda.stream(probe_stream):
                 e = torch.cuda.Event()
                 t0 = time.perf_counter()
-                probe_buf.add_(1.0)
+                probe_kernel()
                 e.record()
                 e.synchronize()
                 lat.append(1e6 * (time.perf_counter() - t0))
@@ -64,7 +76,7 @@ def main():
             with torch.cuda.stream(probe_stream):
                 e = torch.cuda.Event()
                 t0 = time.perf_counter()
-                probe_buf.add_(1.0)
+                probe_kernel()
                 e.record()
                 e.synchronize()
                 lat.append(1e6 * (time.perf_counter() - t0))
@@ -75,16 +87,19 @@ def main():
         print("%-44s probes %3d | latency us: median %7.1f  p90 %7.1f  max %7.1f | 500 launches enqueued in %.1f ms, done after %.1f ms"
               % (label, len(lat), np.median(lat), np.percentile(lat, 90), lat.max(), 1e3 * t_enq, 1e3 * total))
 
-    a = probe_alone()
     print("device CUs (hiast_device_cus): %d" % K.device_cus())
-    print("%-44s probes %3d | latency us: median %7.1f  p90 %7.1f  max %7.1f" % ("probe alone (idle chip)", len(a), np.median(a),
-                                                                                 np.percentile(a, 90), a.max()))
     plain = torch.cuda.Stream(device=dev)
-    measure(plain, "work on a plain stream (256 CUs)")
-    for n in (8, 16):
-        masked = K.reserved_stream(n)
-        measure(masked, "work on a CU-masked stream (%d reserved)" % n)
-    measure(plain, "work on a plain stream again")
+    masked = {n: K.reserved_stream(n) for n in (8, 16)}
+    for k in ("plain", "lds"):
+        kind[0] = k
+        print("---- probe kernel: %s" % ("one block, no LDS" if k == "plain" else "a reduction whose blocks need LDS (as an RCCL kernel does)"))
+        a = probe_alone()
+        print("%-44s probes %3d | latency us: median %7.1f  p90 %7.1f  max %7.1f" % ("probe alone (idle chip)", len(a), np.median(a),
+                                                                                     np.percentile(a, 90), a.max()))
+        measure(plain, "work on a plain stream (256 CUs)")
+        for n in (8, 16):
+            measure(masked[n], "work on a CU-masked stream (%d reserved)" % n)
+        measure(plain, "work on a plain stream again")
 
 
 if __name__ == "__main__":
