@@ -73,19 +73,25 @@ __device__ __forceinline__ void bnh_unpack8(const uint4 r, float (&v)[8])
     }
 }
 
-// 16-byte row segment of a streamed activation.  BNH_NT_LOADS=1 (A/B build: tools/build_variant.sh): as a non-temporal load —
-// the tensors are 33-134 MB, read once per pass and next touched by another kernel after the L2 has turned over
+// 16-byte row segment of a streamed activation as a NON-TEMPORAL load: the tensors are 33-134 MB, read once per pass and next
+// touched by another kernel much later — read with the default policy they push the lines the NEXT kernel wants (this pass's
+// output, the weights) out of the L2 / Infinity Cache.  BNH_NT_LOADS: bit 0 = the statistics passes (bnh_partial), bit 1 = the
+// forward apply pass, bit 2 = the backward apply pass (A/B builds: tools/build_variant.sh ... -DBNH_NT_LOADS=<mask>).  Round 6,
+// in the bench step on one box, two runs each (profiles/r06_ab_nt_loads.txt): mask 0 54.67 / 54.67 ms, 1: 54.67 / 54.63, 5: 54.50 /
+// 54.59, 7: 54.32 / 54.30 — stand-alone the apply passes measure 3-11 us SLOWER with it (tools/ab_bn.py): the gain is the next
+// kernel's.  The same policy on the residual rows of xconv / xconv2 / xconv_bs (+0.26 ms) and on the once-read A operand of the
+// 1x1 tile-kernel launches (+0.07 ms) lost: those stay on the default policy.
 #ifndef BNH_NT_LOADS
-#define BNH_NT_LOADS 0
+#define BNH_NT_LOADS 7
 #endif
+template <int WHICH>
 __device__ __forceinline__ uint4 bnh_ld16(const unsigned short* p)
 {
-#if BNH_NT_LOADS
-    const h_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const h_u32x4*>(p));
-    return make_uint4(v.x, v.y, v.z, v.w);
-#else
+    if ((BNH_NT_LOADS >> WHICH) & 1) {
+        const h_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const h_u32x4*>(p));
+        return make_uint4(v.x, v.y, v.z, v.w);
+    }
     return *reinterpret_cast<const uint4*>(p);
-#endif
 }
 
 template <bool F16>
@@ -152,11 +158,11 @@ __global__ __launch_bounds__(256) void bnh_partial_kernel(const unsigned short* 
             const long long r = rb + u * stride;
             const long long rc = r < lim ? r : (rb < lim ? rb : 0);     // tail: re-read a valid row, not accumulated
             const size_t off = (size_t)rc * C + cg * 8;
-            ra[u] = bnh_ld16(a + off);
+            ra[u] = bnh_ld16<0>(a + off);
             if (BWD) {
-                if (GATE == 1) ry[u] = bnh_ld16(y + off);
+                if (GATE == 1) ry[u] = bnh_ld16<0>(y + off);
                 rbits[u] = GATE == 3 ? reinterpret_cast<const unsigned char*>(y)[(size_t)rc * G + cg] : 0u;
-                rx[u] = bnh_ld16(x + off);
+                rx[u] = bnh_ld16<0>(x + off);
             }
         }
     };
@@ -348,8 +354,8 @@ __global__ __launch_bounds__(256) void bnh_apply_kernel(const unsigned short* __
         for (int u = 0; u < UNR; ++u) {
             const long long r = rb + u * stride;
             const size_t off = (size_t)(r < lim ? r : (rb < lim ? rb : 0)) * C + cg * 8;
-            rx[u] = bnh_ld16(x + off);
-            if (RES) rres[u] = bnh_ld16(res + off);
+            rx[u] = bnh_ld16<1>(x + off);
+            if (RES) rres[u] = bnh_ld16<1>(res + off);
         }
     };
     load_rows(r0);
@@ -416,10 +422,10 @@ __global__ __launch_bounds__(256) void bnh_bwd_apply_kernel(
             const long long r = rb + u * stride;
             const long long rc = r < lim ? r : (rb < lim ? rb : 0);
             const size_t off = (size_t)rc * C + cg * 8;
-            rg[u] = bnh_ld16(dy + off);
-            if (GATE == 1) ry[u] = bnh_ld16(y + off);
+            rg[u] = bnh_ld16<2>(dy + off);
+            if (GATE == 1) ry[u] = bnh_ld16<2>(y + off);
             rbits[u] = GATE == 3 ? reinterpret_cast<const unsigned char*>(y)[(size_t)rc * G + cg] : 0u;
-            rx[u] = bnh_ld16(x + off);
+            rx[u] = bnh_ld16<2>(x + off);
         }
     };
     load_rows(r0);

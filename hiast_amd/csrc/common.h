@@ -84,6 +84,20 @@ __device__ __forceinline__ void h_store16(void* p, unsigned a, unsigned b, unsig
     *reinterpret_cast<uint4*>(p) = make_uint4(a, b, c, d);
 }
 constexpr long long H_NT_MIN_BYTES = 64ll << 20;      // outputs from 64 MiB on are streamed
+// 16-byte load of a row segment that this launch reads exactly once (residual / BatchNorm-input rows of the persistent 1x1 kernels):
+// HIAST_NT_RES=1 (A/B build of a translation unit) makes it a non-temporal load
+#ifndef HIAST_NT_RES
+#define HIAST_NT_RES 0
+#endif
+__device__ __forceinline__ uint4 h_load16_once(const void* p)
+{
+#if HIAST_NT_RES
+    const h_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const h_u32x4*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *reinterpret_cast<const uint4*>(p);
+#endif
+}
 
 template <bool F16>
 struct H16;

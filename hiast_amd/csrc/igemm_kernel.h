@@ -114,6 +114,15 @@ __device__ __forceinline__ void ig_dma16(__amdgpu_buffer_rsrc_t rs, unsigned cha
 {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (ig_lds_ptr)lds, 16, voff, soff, 0, 0);
 }
+// ... with the non-temporal cache policy (aux bit 1 = nt): the A operand of a 1x1 launch is read exactly ONCE, by one block
+// (IG_A_NT: A/B build, tools/build_variant_igemm.sh ... -DIG_A_NT=1)
+#ifndef IG_A_NT
+#define IG_A_NT 0
+#endif
+__device__ __forceinline__ void ig_dma16_nt(__amdgpu_buffer_rsrc_t rs, unsigned char* lds, int voff, int soff)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (ig_lds_ptr)lds, 16, voff, soff, 0, IG_A_NT ? 2 : 0);
+}
 
 // Fragment reads as inline asm (ds_read_b128, tile offset as the instruction's immediate) with explicit lgkmcnt waits that
 // tie the destination registers: the compiler orders every LDS load it can see behind ALL pending LDS-DMAs
@@ -325,7 +334,8 @@ __global__ __launch_bounds__(BM * 2) void igemm_bn_act_kernel(
 #ifdef IG_SLABMAJOR_A
         ig_dma16(xrs, smem + sa * A_BYTES + (4 * wave + g) * 1024, voff, TAPS == 1 ? j * (BM * 128) : j * 128);
 #else
-        ig_dma16(xrs, smem + sa * A_BYTES + (4 * wave + g) * 1024, voff, j * 128);
+        if (TAPS == 1) ig_dma16_nt(xrs, smem + sa * A_BYTES + (4 * wave + g) * 1024, voff, j * 128);
+        else ig_dma16(xrs, smem + sa * A_BYTES + (4 * wave + g) * 1024, voff, j * 128);
 #endif
     };
     auto dma_b = [&](int kt, int sb, int g, bool on) {

@@ -164,8 +164,8 @@ __global__ __launch_bounds__(512) void xconv_kernel(const unsigned short* __rest
             for (int t = 0; t < 2; ++t) {
                 const int m = p * XC_PANEL + half * 32 + t * 16 + px;
                 const size_t row = (size_t)(m < M ? m : 0) * N + n0 + g * 8;
-                rres[t][0] = *reinterpret_cast<const uint4*>(R + row);
-                rres[t][1] = *reinterpret_cast<const uint4*>(R + row + 32);
+                rres[t][0] = h_load16_once(R + row);
+                rres[t][1] = h_load16_once(R + row + 32);
                 if (GATE) {
                     const unsigned char* gp = Rg + (size_t)(m < M ? m : 0) * (N >> 3) + ((n0 + g * 8) >> 3);
                     rgate[t][0] = gp[0];

@@ -147,8 +147,8 @@ __global__ __launch_bounds__(512) void xconv2_kernel(const unsigned short* __res
         for (int a = 0; a < 2; ++a) {
             const int m = (p < npanel ? p : 0) * X2_PANEL + a * 16 + px;
             const size_t o = slab_off(m);
-            rh[buf][a] = *reinterpret_cast<const uint4*>(R + o);
-            rl[buf][a] = *reinterpret_cast<const uint4*>(R + o + 32);
+            rh[buf][a] = h_load16_once(R + o);
+            rl[buf][a] = h_load16_once(R + o + 32);
         }
     };
 

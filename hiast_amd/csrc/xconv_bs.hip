@@ -147,9 +147,9 @@ __global__ __launch_bounds__(512) void xconv_gated_bnstat_kernel(
         for (int t = 0; t < 4; ++t) {
             const int m = p * XB_PANEL + t * 16 + px;
             const size_t mr = (size_t)((p < npanel && m < M) ? m : 0);
-            r.res[t] = *reinterpret_cast<const uint4*>(R + mr * N + c0);
+            r.res[t] = h_load16_once(R + mr * N + c0);
             r.gate[t] = Rg[mr * (N >> 3) + (c0 >> 3)];
-            r.bx[t] = *reinterpret_cast<const uint4*>(BX + mr * N + c0);
+            r.bx[t] = h_load16_once(BX + mr * N + c0);
             r.bm[t] = BM[mr * (N >> 3) + (c0 >> 3)];
         }
     };
