@@ -83,7 +83,10 @@ __device__ __forceinline__ void h_store16(void* p, unsigned a, unsigned b, unsig
 #endif
     *reinterpret_cast<uint4*>(p) = make_uint4(a, b, c, d);
 }
-constexpr long long H_NT_MIN_BYTES = 64ll << 20;      // outputs from 64 MiB on are streamed
+#ifndef H_NT_MIN_MIB
+#define H_NT_MIN_MIB 64
+#endif
+constexpr long long H_NT_MIN_BYTES = (long long)H_NT_MIN_MIB << 20;      // outputs from 64 MiB on are streamed
 // 16-byte load of a row segment that this launch reads exactly once (residual / BatchNorm-input rows of the persistent 1x1 kernels):
 // HIAST_NT_RES=1 (A/B build of a translation unit) makes it a non-temporal load
 #ifndef HIAST_NT_RES

@@ -807,7 +807,10 @@ __global__ __launch_bounds__(BM * 2) void igemm_bn_act_kernel(
                         }
                     }
                     // streaming stores (common.h) — except in the split-plane 3x3 launches, which measured 3 % slower with them
-                    constexpr bool NT = !(PL == 2 && TAPS == 9);
+#ifndef IG_NT_PL2_9
+#define IG_NT_PL2_9 0
+#endif
+                    constexpr bool NT = !(PL == 2 && TAPS == 9) || IG_NT_PL2_9 != 0;
                     h_store16(Y, ph[0], ph[1], ph[2], ph[3], NT);
                     if (PL == 2) h_store16(Y + 32, pl_[0], pl_[1], pl_[2], pl_[3], NT);
                 }

@@ -134,11 +134,30 @@ __global__ __launch_bounds__(256) void adam_kernel(const hiast_adam_rec* __restr
         const float4* g4 = reinterpret_cast<const float4*>(r.g + s);
         float4* m4 = reinterpret_cast<float4*>(r.m + s);
         float4* v4 = reinterpret_cast<float4*>(r.v + s);
+        // MISC_NT=1 (A/B build): the moments and the gradient are touched once per step — non-temporal, so that the parameters
+        // (read next by the EMA update and the weight re-packing) stay in the Infinity Cache
+#ifndef MISC_NT
+#define MISC_NT 0
+#endif
+        typedef float f32x4_ __attribute__((ext_vector_type(4)));
         for (int64_t i = threadIdx.x; i < nv; i += 256) {
-            float4 p = p4[i], m = m4[i], v = v4[i];
-            const float4 g = g4[i];
+            float4 p = p4[i], m, v, g;
+            if (MISC_NT) {
+                const f32x4_ mm = __builtin_nontemporal_load(reinterpret_cast<const f32x4_*>(m4 + i));
+                const f32x4_ vv = __builtin_nontemporal_load(reinterpret_cast<const f32x4_*>(v4 + i));
+                const f32x4_ gg = __builtin_nontemporal_load(reinterpret_cast<const f32x4_*>(g4 + i));
+                m = make_float4(mm.x, mm.y, mm.z, mm.w); v = make_float4(vv.x, vv.y, vv.z, vv.w); g = make_float4(gg.x, gg.y, gg.z, gg.w);
+            } else {
+                m = m4[i]; v = v4[i]; g = g4[i];
+            }
             upd(p.x, g.x, m.x, v.x); upd(p.y, g.y, m.y, v.y); upd(p.z, g.z, m.z, v.z); upd(p.w, g.w, m.w, v.w);
-            p4[i] = p; m4[i] = m; v4[i] = v;
+            p4[i] = p;
+            if (MISC_NT) {
+                __builtin_nontemporal_store((f32x4_){m.x, m.y, m.z, m.w}, reinterpret_cast<f32x4_*>(m4 + i));
+                __builtin_nontemporal_store((f32x4_){v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4_*>(v4 + i));
+            } else {
+                m4[i] = m; v4[i] = v;
+            }
         }
         for (int64_t i = s + nv * 4 + threadIdx.x; i < e; i += 256) upd(r.p[i], r.g[i], r.m[i], r.v[i]);
     } else {
