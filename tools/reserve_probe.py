@@ -29,7 +29,7 @@ def main():
     wp = K.pack_conv_weight(w, K.FMT_FP16)
     probe_buf = torch.zeros(256, device=dev)
     probe_red = torch.zeros(1 << 16, device=dev)
-    probe_out = torch.zeros((), device=dev)
+    probe_out = torch.zeros((), device=dev)      # (sum over dim 0 of a 1-d tensor -> 0-d)
     probe_stream = torch.cuda.Stream(device=dev)
     kind = ["plain"]
 
@@ -40,7 +40,7 @@ def main():
         if kind[0] == "plain":
             probe_buf.add_(1.0)
         else:
-            torch.sum(probe_red, out=probe_out)
+            torch.sum(probe_red, dim=(0,), out=probe_out)
 
     def saturate(stream, n):
         with torch.cuda.stream(stream):
