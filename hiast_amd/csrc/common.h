@@ -87,6 +87,23 @@ __device__ __forceinline__ void h_store16(void* p, unsigned a, unsigned b, unsig
 #define H_NT_MIN_MIB 64
 #endif
 constexpr long long H_NT_MIN_BYTES = (long long)H_NT_MIN_MIB << 20;      // outputs from 64 MiB on are streamed
+// output store of the persistent 1x1 kernels / the weight-gradient partials: plain by default (stand-alone the streaming form
+// measured 3-10 % slower there); HIAST_NT_OUT=1 is the in-step A/B build
+#ifndef HIAST_NT_OUT
+#define HIAST_NT_OUT 0
+#endif
+__device__ __forceinline__ void h_store16_out(void* p, unsigned a, unsigned b, unsigned c, unsigned d)
+{
+    h_store16(p, a, b, c, d, HIAST_NT_OUT != 0);
+}
+__device__ __forceinline__ void h_store_f32_out(float* p, float v)
+{
+#if HIAST_NT_OUT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
 // 16-byte load of a row segment that this launch reads exactly once (residual / BatchNorm-input rows of the persistent 1x1 kernels):
 // HIAST_NT_RES=1 (A/B build of a translation unit) makes it a non-temporal load
 #ifndef HIAST_NT_RES

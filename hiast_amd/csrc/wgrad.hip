@@ -306,7 +306,7 @@ __device__ __forceinline__ void wgrad_tn_body(unsigned char* smem, const unsigne
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wm * 128 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                Ps[((size_t)n * TAPS + tap) * K + k] = acc[a][b][r];      // (plain stores: non-temporal ones measured 3 % slower here)
+                h_store_f32_out(Ps + ((size_t)n * TAPS + tap) * K + k, acc[a][b][r]);      // (plain stores: non-temporal ones measured 3 % slower here)
             }
         }
 }

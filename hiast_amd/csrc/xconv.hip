@@ -293,8 +293,8 @@ __global__ __launch_bounds__(512) void xconv_kernel(const unsigned short* __rest
                     }
                 }
                 if (ok) {
-                    *reinterpret_cast<uint4*>(Y + row) = make_uint4(pk[0], pk[1], pk[2], pk[3]);        // (plain: common.h)
-                    *reinterpret_cast<uint4*>(Y + row + 32) = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+                    h_store16_out(Y + row, pk[0], pk[1], pk[2], pk[3]);        // (plain: common.h)
+                    h_store16_out(Y + row + 32, pk[4], pk[5], pk[6], pk[7]);
                 }
             }
         }

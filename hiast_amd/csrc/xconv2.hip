@@ -260,8 +260,8 @@ __global__ __launch_bounds__(512) void xconv2_kernel(const unsigned short* __res
             // ragged tail only occurs in the LAST panel, after which no block takes another counted wait)
             if (m < M) {
                 unsigned short* y = Y + slab_off(m);
-                *reinterpret_cast<uint4*>(y) = make_uint4(ph[0], ph[1], ph[2], ph[3]);        // (plain stores: common.h)
-                *reinterpret_cast<uint4*>(y + 32) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+                h_store16_out(y, ph[0], ph[1], ph[2], ph[3]);        // (plain stores: common.h)
+                h_store16_out(y + 32, pl[0], pl[1], pl[2], pl[3]);
             }
         }
     };

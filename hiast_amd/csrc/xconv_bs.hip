@@ -219,7 +219,7 @@ __global__ __launch_bounds__(512) void xconv_gated_bnstat_kernel(
                 }
                 // (rows beyond M are not stored: a ragged tail only occurs in a block's LAST panel, after which it takes no
                 // counted wait)
-                if (ok) *reinterpret_cast<uint4*>(Y + (size_t)m * N + c0) = make_uint4(pk[0], pk[1], pk[2], pk[3]);   // (streaming store: no change)
+                if (ok) h_store16_out(Y + (size_t)m * N + c0, pk[0], pk[1], pk[2], pk[3]);   // (streaming store: no change stand-alone)
             }
         }
     };
