@@ -60,9 +60,45 @@ class HipPlabelEngine:
             raise RuntimeError("HipPlabelEngine runs on the HIP device only (no CPU path); got %r" % (device,))
         self.model, self.device, self.C = model, device, num_classes
 
+    def lanes(self, batch_size):
+        """how many batches the pipelined generators keep in flight on forward streams of their own.  A forward over fewer than
+        8 images leaves most of the chip idle (a layer3 launch at batch 2 has 64 tiles of 256 rows, 128 as half tiles, for 256
+        CUs: 2.85 ms per image against 1.92 at batch 8, profiles/r06_generator_bs2_kernel_stats.csv) and pass 1 of a batch does
+        not depend on the thresholds of the batch before it — only pass 2 does — so the forwards of batch t + 1 and t + 2 run
+        SIDE BY SIDE on two streams (round 6; HIAST_GEN_LANES=1: one after the other as before).  Batches of 8 or more images
+        already run as two sub-batches on two streams (functional.eval_forward_split)."""
+        n = int(os.environ.get("HIAST_GEN_LANES", "2"))
+        return max(1, n) if batch_size < 8 else 1
+
+    def _lane_stream(self, lane):
+        ls = self.__dict__.setdefault("_lanes", {})
+        if lane not in ls:
+            ls[lane] = HF.new_stream(self.device)
+        return ls[lane]
+
     @torch.no_grad()
-    def begin(self, imgs):
-        """forward + pass 1 of one batch, enqueued on the current stream; nothing waits.  -> state for hist_host() / finish().
+    def begin(self, imgs, lane=None):
+        """forward + pass 1 of one batch, enqueued on the current stream (lane None) or on forward stream `lane`; nothing waits.
+        -> state for hist_host() / finish()."""
+        if lane is None or imgs is None or imgs.shape[0] == 0:
+            return self._begin(imgs, False)
+        # the kernel-format weight copies are packed ONCE, here on the calling stream, before any lane reads them (the model does
+        # not change during generation); a lane waits for that event at its first use only — waiting for the calling stream every
+        # time would put the lanes back in single file
+        if getattr(self, "_packed_ev", None) is None:
+            HF.prepack_eval_trunks(self.model, torch.empty((1, 3, 8, 8), dtype=torch.float32, device=self.device))
+            self._packed_ev = torch.cuda.Event()
+            self._packed_ev.record()
+            self._lane_seen = set()
+        s = self._lane_stream(lane)
+        if lane not in self._lane_seen:
+            s.wait_event(self._packed_ev)
+            self._lane_seen.add(lane)
+        with torch.cuda.stream(s):
+            return self._begin(imgs, True)
+
+    def _begin(self, imgs, side_by_side):
+        """forward + pass 1 of one batch on the current stream.
         The generators keep the device busy with the NEXT batch's begin() while the host turns this batch's histogram into
         thresholds and its label maps into PNG files; everything that follows pass 1 of a batch (histogram exchange and
         read-back, pass 2, read-back of the maps) runs on a second stream behind the state's event, so it does not queue up
@@ -84,7 +120,12 @@ class HipPlabelEngine:
                 # pipelined: 473 vs 487 images/s)
                 self._fwd = HF.GraphedEval(self.model, None)
             H, W = imgs.shape[2:]
-            st["mp"], st["am"], st["hist"] = K.plabel_pass1(self._fwd(imgs).contiguous(), H, W)
+            import contextlib
+            # (two forwards side by side: half-chip launches keep their 256-row tile form, as for the sub-batches of
+            # eval_forward_split — the thread-local hint of the library)
+            with (K.cosched() if side_by_side else contextlib.nullcontext()):
+                logits = self._fwd(imgs).contiguous()
+            st["mp"], st["am"], st["hist"] = K.plabel_pass1(logits, H, W)
         st["ev"] = torch.cuda.Event()
         st["ev"].record()
         return st
@@ -289,16 +330,32 @@ class BasePseudoGenerator:
                 yield data["images"], list(data["image_paths"])
 
     def _pipelined_states(self):
-        """(image paths, HipPlabelEngine.begin() state) per batch, with forward + pass 1 of the NEXT batch already enqueued
-        when a batch is handed out: the device works on batch t+1 while the host finishes batch t"""
+        """(image paths, HipPlabelEngine.begin() state) per batch, with forward + pass 1 of the NEXT batch(es) already enqueued
+        when a batch is handed out: the device works on batch t+1 (small batches: t+1 and t+2 side by side on two forward
+        streams, HipPlabelEngine.lanes) while the host finishes batch t.  The order in which batches are handed out — and with it
+        the threshold recursion and every artefact — is the loader's, whatever the depth."""
+        from collections import deque
         batches = iter(self._batches())
-        cur = next(batches, None)
-        st = self.engine.begin(cur[0]) if cur is not None else None
-        while cur is not None:
+        depth = self.engine.lanes(self.cfg.pseudo_policy.batch_size) if hasattr(self.engine, "lanes") else 1
+        q = deque()
+        n = 0
+
+        def enqueue():
+            nonlocal n
             nxt = next(batches, None)
-            st_next = self.engine.begin(nxt[0]) if nxt is not None else None
-            yield cur[1], st
-            cur, st = nxt, st_next
+            if nxt is None:
+                return False
+            st = self.engine.begin(nxt[0], lane=n % depth) if depth > 1 else self.engine.begin(nxt[0])
+            q.append((nxt[1], st))
+            n += 1
+            return True
+        for _ in range(depth):
+            if not enqueue():
+                break
+        while q:
+            paths, st = q.popleft()
+            enqueue()
+            yield paths, st
 
     def _exists(self):
         """rank 0 looks at the directory; every rank takes ITS decision (a rank that went on alone into the
