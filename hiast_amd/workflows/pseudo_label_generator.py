@@ -70,6 +70,75 @@ class HipPlabelEngine:
         n = int(os.environ.get("HIAST_GEN_LANES", "2"))
         return max(1, n) if batch_size < 8 else 1
 
+    def group(self, batch_size):
+        """how many CONSECUTIVE loader batches share one forward (round 6).  An inference forward treats every image alone
+        (BatchNorm in eval mode) and pass 1 of a batch does not depend on the thresholds of the batch before it, so the trunk runs
+        ONCE over the images of several small batches (a layer3 launch over two images fills a quarter of the chip: 2.85 ms per
+        image against 1.92 at batch 8) and pass 1 runs per original batch on its slice of the logits: every batch keeps its own
+        histogram, the threshold recursion advances batch by batch exactly as before, label maps and statistics are bit for bit
+        those of the one-batch-at-a-time loop (the tile kernels' outputs do not depend on the launch size: same products in the
+        same order per element).  HIAST_GEN_GROUP=1: one forward per loader batch."""
+        env = os.environ.get("HIAST_GEN_GROUP", "")
+        # measured (profiles/r06_generator_lanes.txt): forwards over 4 images, two of them side by side (lanes), beat forwards
+        # over 6 or 8 images at every small batch size — the smallest group that reaches 4 images
+        g = int(env) if env else -(-int(os.environ.get("HIAST_GEN_GROUP_IMAGES", "4")) // max(1, int(batch_size)))
+        return max(1, min(g, 8))
+
+    @torch.no_grad()
+    def begin_group(self, batches, lane=None):
+        """begin() for several consecutive loader batches with ONE forward over their images -> one state per batch (in order)"""
+        if len(batches) == 1:
+            return [self.begin(batches[0], lane)]
+        live = [b for b in batches if b is not None and b.shape[0] > 0]
+        if len(live) <= 1 or len({tuple(b.shape[1:]) for b in live}) != 1 or len({b.dtype for b in live}) != 1:
+            return [self.begin(b, lane) for b in batches]          # (ragged image sizes: no shared launch)
+        if lane is None:
+            return self._begin_group(batches, live, False)
+        self._lane_ready(lane)
+        with torch.cuda.stream(self._lane_stream(lane)):
+            return self._begin_group(batches, live, True)
+
+    def _begin_group(self, batches, live, side_by_side):
+        import contextlib
+        from hiast_amd import kernels as K
+        imgs = torch.cat([b.to(self.device, non_blocking=True) for b in live], 0)
+        if imgs.dtype == torch.uint8:
+            from hiast_amd.sseg.datasets.utils import MEAN, STD
+            imgs = K.normalize_u8(imgs, MEAN, STD)
+        if getattr(self, "_fwd", None) is None or self._fwd.model is not self.model:
+            self._fwd = HF.GraphedEval(self.model, None)
+        H, W = imgs.shape[2:]
+        with (K.cosched() if side_by_side else contextlib.nullcontext()):
+            logits = self._fwd(imgs).contiguous()
+        states, i0 = [], 0
+        for b in batches:
+            st = {"mp": None, "am": None}
+            if b is None or b.shape[0] == 0:
+                st["hist"] = torch.zeros((self.C, ias_math.NBINS), dtype=torch.int32, device=self.device)
+            else:
+                n = b.shape[0]
+                st["mp"], st["am"], st["hist"] = K.plabel_pass1(logits[i0:i0 + n], H, W)     # this batch's own histogram
+                i0 += n
+            states.append(st)
+        ev = torch.cuda.Event()
+        ev.record()
+        for st in states:
+            st["ev"] = ev
+        return states
+
+    def _lane_ready(self, lane):
+        # the kernel-format weight copies are packed ONCE, on the calling stream, before any lane reads them (the model does not
+        # change during generation); a lane waits for that event at its first use only — waiting for the calling stream every time
+        # would put the lanes back in single file
+        if getattr(self, "_packed_ev", None) is None:
+            HF.prepack_eval_trunks(self.model, torch.empty((1, 3, 8, 8), dtype=torch.float32, device=self.device))
+            self._packed_ev = torch.cuda.Event()
+            self._packed_ev.record()
+            self._lane_seen = set()
+        if lane not in self._lane_seen:
+            self._lane_stream(lane).wait_event(self._packed_ev)
+            self._lane_seen.add(lane)
+
     def _lane_stream(self, lane):
         ls = self.__dict__.setdefault("_lanes", {})
         if lane not in ls:
@@ -82,19 +151,8 @@ class HipPlabelEngine:
         -> state for hist_host() / finish()."""
         if lane is None or imgs is None or imgs.shape[0] == 0:
             return self._begin(imgs, False)
-        # the kernel-format weight copies are packed ONCE, here on the calling stream, before any lane reads them (the model does
-        # not change during generation); a lane waits for that event at its first use only — waiting for the calling stream every
-        # time would put the lanes back in single file
-        if getattr(self, "_packed_ev", None) is None:
-            HF.prepack_eval_trunks(self.model, torch.empty((1, 3, 8, 8), dtype=torch.float32, device=self.device))
-            self._packed_ev = torch.cuda.Event()
-            self._packed_ev.record()
-            self._lane_seen = set()
-        s = self._lane_stream(lane)
-        if lane not in self._lane_seen:
-            s.wait_event(self._packed_ev)
-            self._lane_seen.add(lane)
-        with torch.cuda.stream(s):
+        self._lane_ready(lane)
+        with torch.cuda.stream(self._lane_stream(lane)):
             return self._begin(imgs, True)
 
     def _begin(self, imgs, side_by_side):
@@ -336,26 +394,38 @@ class BasePseudoGenerator:
         the threshold recursion and every artefact — is the loader's, whatever the depth."""
         from collections import deque
         batches = iter(self._batches())
-        depth = self.engine.lanes(self.cfg.pseudo_policy.batch_size) if hasattr(self.engine, "lanes") else 1
+        bs = int(self.cfg.pseudo_policy.batch_size)
+        grp = self.engine.group(bs) if hasattr(self.engine, "group") else 1          # loader batches per forward
+        depth = self.engine.lanes(bs * grp) if hasattr(self.engine, "lanes") else 1  # forwards in flight on streams of their own
         q = deque()
         n = 0
 
         def enqueue():
             nonlocal n
-            nxt = next(batches, None)
-            if nxt is None:
+            items = []
+            while len(items) < grp:
+                nxt = next(batches, None)
+                if nxt is None:
+                    break
+                items.append(nxt)
+            if not items:
                 return False
-            st = self.engine.begin(nxt[0], lane=n % depth) if depth > 1 else self.engine.begin(nxt[0])
-            q.append((nxt[1], st))
+            lane = n % depth if depth > 1 else None
+            if grp > 1:
+                sts = self.engine.begin_group([it[0] for it in items], lane)
+            else:
+                sts = [self.engine.begin(items[0][0], lane) if depth > 1 else self.engine.begin(items[0][0])]
+            q.append([(it[1], st) for it, st in zip(items, sts)])
             n += 1
             return True
         for _ in range(depth):
             if not enqueue():
                 break
         while q:
-            paths, st = q.popleft()
+            group = q.popleft()
             enqueue()
-            yield paths, st
+            for paths, st in group:
+                yield paths, st
 
     def _exists(self):
         """rank 0 looks at the directory; every rank takes ITS decision (a rank that went on alone into the

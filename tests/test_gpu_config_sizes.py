@@ -207,7 +207,7 @@ def test_config1_generator_500_images_1024x512(tmp_path_factory):
     assert len(recs) == N and len(by_class) == C
     means = np.load(os.path.join(pdir, "..", "class_mean_probabilities.npy"))
     assert means.shape == (C,) and bool(np.isfinite(means).all())
-    _record("r05_config1_generator_500.txt", [
+    _record("r06_config1_generator_500.txt", [
         "BASELINE configs[1] as a -m gpu test: PSEUDO_POLICY['IAS'](cfg).run() over %d synthetic %dx%d PNGs, batch size %d (the "
         "reference's), %d DataLoader workers" % (N, W, H, BS, workers),
         "run(): %.2f s = %.1f images/s end to end (PNG decode -> uint8 H2D -> normalise -> fp32-class forward -> pass 1 -> host "
