@@ -206,3 +206,71 @@ def test_bench_watchdog_prints_a_diagnostic_line_and_exits_nonzero():
     wd = d["watchdog"]
     assert wd["rank"] == 0 and wd["limit_s"] == 0.5 and wd["expected_per_step"]["syncbn_stat_all_reduces"] == 208
     assert "[bench watchdog] rank 0" in p.stderr
+
+
+# ------------------------------------------------------------------------------------------------ generator: shared forwards
+@pytest.mark.parametrize("policy", ["IAS", "CT"])
+def test_generator_grouped_forwards_write_the_same_artefacts(tmp_path, monkeypatch, policy):
+    """round 6: the pipelined generators let consecutive small loader batches share ONE forward (pass 1 and the threshold update
+    stay per batch) and keep two such forwards in flight on two streams (HipPlabelEngine.group / .lanes).  Against the round-5
+    pipeline — one forward per loader batch, one at a time (HIAST_GEN_GROUP=1, HIAST_GEN_LANES=1) — every artefact is the same
+    byte for byte: label maps, thresholds (float64 bit patterns), statistics, class means; batch sizes 1, 2 and 3 over 11 images
+    (ragged last group, ragged last batch).  Reference: workflows/pseudo_label_generator.py:181-213, :67-105."""
+    from PIL import Image
+    from hiast_amd.utils.default_config import get_default_cfg  # noqa: F401
+    from hiast_amd.utils.registry import register  # noqa: F401
+    from hiast_amd.utils.registry.registries import MODEL, PSEUDO_POLICY
+    from hiast_amd.tools import synth_data
+    from make_golden import seeded_state_dict
+    Hh, Ww = 128, 256
+    root = str(tmp_path)
+    cfg = synth_data.synthetic_cfg(root, n_train=11, n_val=1, h=Hh, w=Ww)
+    m = MODEL["SelfTrainingSegmentor"](cfg)
+    m.load_state_dict({"seg_model." + k: v for k, v in seeded_state_dict(m.seg_model, 777).items()})
+    m = m.cuda().eval()
+    ds = np.stack([synth_data.make_sample(5 + i, Hh, Ww)[0].astype(np.float32).transpose(2, 0, 1) for i in range(2)]) / 255.0
+    xs = torch.from_numpy((ds - 0.45) / 0.225).cuda()
+    synth_data.calibrate_bn(m, xs)
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        scale = 3.0 / float(m(xs[:1], lowres=True)["logits_lowres"].std())
+    for i in range(4):
+        sd["seg_model.aspp.conv2d_list.%d.weight" % i] = sd["seg_model.aspp.conv2d_list.%d.weight" % i] * scale
+        sd["seg_model.aspp.conv2d_list.%d.bias" % i] = sd["seg_model.aspp.conv2d_list.%d.bias" % i] * scale
+    del m
+    ck = os.path.join(root, "warmup.pth")
+    torch.save(sd, ck)
+
+    def run(tag, bs, env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = cfg.clone()
+        c.defrost()
+        c.pseudo_policy.type = policy
+        c.pseudo_policy.resume_from = ck
+        c.pseudo_policy.batch_size = bs
+        c.pseudo_policy.save_dir = os.path.join(root, "out_%s_%d" % (tag, bs), "pseudo_labels")
+        c.dataset.num_workers = 0
+        gen = PSEUDO_POLICY[policy](c)
+        if tag == "grouped":
+            assert gen.engine.group(bs) == -(-4 // bs) and gen.engine.lanes(bs * gen.engine.group(bs)) == 2
+        else:
+            assert gen.engine.group(bs) == 1 and gen.engine.lanes(bs) == 1
+        gen.run()
+        for k in env:
+            monkeypatch.delenv(k)
+        d = c.pseudo_policy.save_dir
+        out = {n: np.array(Image.open(os.path.join(d, n))) for n in sorted(os.listdir(d))}
+        for f in ("class_threshold.npy", "statics_class.npy", "class_mean_probabilities.npy"):
+            p = os.path.join(d, "..", f)
+            if os.path.exists(p):
+                a = np.load(p)
+                out[f] = a.view(np.uint64) if a.dtype == np.float64 else a
+        return out
+
+    for bs in (1, 2, 3):
+        ref = run("serial", bs, {"HIAST_GEN_GROUP": "1", "HIAST_GEN_LANES": "1"})
+        got = run("grouped", bs, {})
+        assert sorted(ref) == sorted(got) and len([k for k in ref if k.endswith(".png")]) == 11
+        for k in ref:
+            assert np.array_equal(ref[k], got[k]), (policy, bs, k)
