@@ -60,7 +60,12 @@ class HipPlabelEngine:
             raise RuntimeError("HipPlabelEngine runs on the HIP device only (no CPU path); got %r" % (device,))
         self.model, self.device, self.C = model, device, num_classes
 
-    def lanes(self, batch_size):
+    @staticmethod
+    def _equiv(n_images, hw):
+        """images of the bench size (1024x512) that n_images of size hw = (h, w) amount to: what fills the chip is pixels"""
+        return n_images if not hw else n_images * (float(hw[0]) * float(hw[1])) / (512.0 * 1024.0)
+
+    def lanes(self, batch_size, hw=None):
         """how many batches the pipelined generators keep in flight on forward streams of their own.  A forward over fewer than
         8 images leaves most of the chip idle (a layer3 launch at batch 2 has 64 tiles of 256 rows, 128 as half tiles, for 256
         CUs: 2.85 ms per image against 1.92 at batch 8, profiles/r06_generator_bs2_kernel_stats.csv) and pass 1 of a batch does
@@ -68,20 +73,28 @@ class HipPlabelEngine:
         SIDE BY SIDE on two streams (round 6; HIAST_GEN_LANES=1: one after the other as before).  Batches of 8 or more images
         already run as two sub-batches on two streams (functional.eval_forward_split)."""
         n = int(os.environ.get("HIAST_GEN_LANES", "2"))
-        return max(1, n) if batch_size < 8 else 1
+        return max(1, n) if (batch_size < 8 and self._equiv(batch_size, hw) < 8) else 1
 
-    def group(self, batch_size):
+    def group(self, batch_size, hw=None):
         """how many CONSECUTIVE loader batches share one forward (round 6).  An inference forward treats every image alone
         (BatchNorm in eval mode) and pass 1 of a batch does not depend on the thresholds of the batch before it, so the trunk runs
         ONCE over the images of several small batches (a layer3 launch over two images fills a quarter of the chip: 2.85 ms per
         image against 1.92 at batch 8) and pass 1 runs per original batch on its slice of the logits: every batch keeps its own
         histogram, the threshold recursion advances batch by batch exactly as before, label maps and statistics are bit for bit
-        those of the one-batch-at-a-time loop (the tile kernels' outputs do not depend on the launch size: same products in the
-        same order per element).  HIAST_GEN_GROUP=1: one forward per loader batch."""
+        those of the one-batch-at-a-time loop — the tile kernels' outputs do not depend on the launch size (same products in the
+        same order per element), PROVIDED the launch size does not change which kernel runs: the register-resident-weight kernels
+        (xconv / xconv2) take a 1x1 launch from 4096 output rows on and differ from the tile kernel in summation order (2e-5).
+        Frames whose 1/8-resolution map has fewer than 4096 pixels (below 512 x 512) would cross that gate by being grouped, so
+        they are not grouped (nor is anything when the frame size is unknown).  HIAST_GEN_GROUP=1: one forward per loader batch."""
+        if not hw or (int(hw[0]) // 8) * (int(hw[1]) // 8) < 4096:
+            return 1
         env = os.environ.get("HIAST_GEN_GROUP", "")
         # measured (profiles/r06_generator_lanes.txt): forwards over 4 images, two of them side by side (lanes), beat forwards
         # over 6 or 8 images at every small batch size — the smallest group that reaches 4 images
-        g = int(env) if env else -(-int(os.environ.get("HIAST_GEN_GROUP_IMAGES", "4")) // max(1, int(batch_size)))
+        # (images of 1024x512; larger frames count by their pixels: a 2048x1024 frame is four of them and needs no company)
+        import math
+        g = int(env) if env else int(math.ceil(float(os.environ.get("HIAST_GEN_GROUP_IMAGES", "4")) /
+                                               max(1e-9, self._equiv(int(batch_size), hw)) - 1e-9))
         return max(1, min(g, 8))
 
     @torch.no_grad()
@@ -395,8 +408,9 @@ class BasePseudoGenerator:
         from collections import deque
         batches = iter(self._batches())
         bs = int(self.cfg.pseudo_policy.batch_size)
-        grp = self.engine.group(bs) if hasattr(self.engine, "group") else 1          # loader batches per forward
-        depth = self.engine.lanes(bs * grp) if hasattr(self.engine, "lanes") else 1  # forwards in flight on streams of their own
+        hw = tuple(self.cfg.pseudo_policy.resize_size) if self.cfg.pseudo_policy.resize_size else None
+        grp = self.engine.group(bs, hw) if hasattr(self.engine, "group") else 1          # loader batches per forward
+        depth = self.engine.lanes(bs * grp, hw) if hasattr(self.engine, "lanes") else 1  # forwards in flight on streams of their own
         q = deque()
         n = 0
 

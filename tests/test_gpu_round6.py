@@ -215,14 +215,16 @@ def test_generator_grouped_forwards_write_the_same_artefacts(tmp_path, monkeypat
     stay per batch) and keep two such forwards in flight on two streams (HipPlabelEngine.group / .lanes).  Against the round-5
     pipeline — one forward per loader batch, one at a time (HIAST_GEN_GROUP=1, HIAST_GEN_LANES=1) — every artefact is the same
     byte for byte: label maps, thresholds (float64 bit patterns), statistics, class means; batch sizes 1, 2 and 3 over 11 images
-    (ragged last group, ragged last batch).  Reference: workflows/pseudo_label_generator.py:181-213, :67-105."""
+    (ragged last group, ragged last batch).  512 x 512 frames: the smallest size that is grouped at all — below it a grouped launch
+    would cross the 4096-row gate of the xconv kernels and change summation orders (HipPlabelEngine.group).
+    Reference: workflows/pseudo_label_generator.py:181-213, :67-105."""
     from PIL import Image
     from hiast_amd.utils.default_config import get_default_cfg  # noqa: F401
     from hiast_amd.utils.registry import register  # noqa: F401
     from hiast_amd.utils.registry.registries import MODEL, PSEUDO_POLICY
     from hiast_amd.tools import synth_data
     from make_golden import seeded_state_dict
-    Hh, Ww = 128, 256
+    Hh, Ww = 512, 512
     root = str(tmp_path)
     cfg = synth_data.synthetic_cfg(root, n_train=11, n_val=1, h=Hh, w=Ww)
     m = MODEL["SelfTrainingSegmentor"](cfg)
@@ -252,10 +254,18 @@ def test_generator_grouped_forwards_write_the_same_artefacts(tmp_path, monkeypat
         c.pseudo_policy.save_dir = os.path.join(root, "out_%s_%d" % (tag, bs), "pseudo_labels")
         c.dataset.num_workers = 0
         gen = PSEUDO_POLICY[policy](c)
+        hw = tuple(c.pseudo_policy.resize_size)
+        assert hw == (Hh, Ww)
         if tag == "grouped":
-            assert gen.engine.group(bs) == -(-4 // bs) and gen.engine.lanes(bs * gen.engine.group(bs)) == 2
+            # the rule counts pixels: 4 bench-size (1024 x 512) images per forward; a 512 x 512 frame is half of one
+            assert gen.engine.group(bs, hw) == min(8, -(-8 // bs)) and gen.engine.group(2, (512, 1024)) == 2
+            assert gen.engine.group(bs, (128, 256)) == 1 and gen.engine.group(bs, None) == 1      # small / unknown frames: never
+            assert gen.engine.group(1, (1024, 2048)) == 1 and gen.engine.lanes(2, (1024, 2048)) == 1
+            assert gen.engine.lanes(1, (1024, 2048)) == 2 and gen.engine.lanes(4, (512, 1024)) == 2
+        elif tag == "lanes":
+            assert gen.engine.group(bs, hw) == 2 and gen.engine.lanes(2 * bs, hw) == 2      # two batches per forward, two lanes
         else:
-            assert gen.engine.group(bs) == 1 and gen.engine.lanes(bs) == 1
+            assert gen.engine.group(bs, hw) == 1 and gen.engine.lanes(bs, hw) == 1
         gen.run()
         for k in env:
             monkeypatch.delenv(k)
@@ -270,7 +280,8 @@ def test_generator_grouped_forwards_write_the_same_artefacts(tmp_path, monkeypat
 
     for bs in (1, 2, 3):
         ref = run("serial", bs, {"HIAST_GEN_GROUP": "1", "HIAST_GEN_LANES": "1"})
-        got = run("grouped", bs, {})
-        assert sorted(ref) == sorted(got) and len([k for k in ref if k.endswith(".png")]) == 11
-        for k in ref:
-            assert np.array_equal(ref[k], got[k]), (policy, bs, k)
+        for tag, env in (("grouped", {}), ("lanes", {"HIAST_GEN_GROUP": "2"})):
+            got = run(tag, bs, env)
+            assert sorted(ref) == sorted(got) and len([k for k in ref if k.endswith(".png")]) == 11
+            for k in ref:
+                assert np.array_equal(ref[k], got[k]), (policy, bs, tag, k)
