@@ -43,8 +43,15 @@ class Validator:
         self.model = utils.load_model(self.cfg, resume_from=self.cfg.validate.resume_from).to(self.device)
         v = self.cfg.dataset.val
         ds = DATASET[v.type](self.cfg, v.json_path, v.image_dir, num_classes=self.cfg.dataset.num_classes)
-        self.v_loader = DataLoader(ds, self.cfg.validate.batch_size, num_workers=self.cfg.dataset.num_workers,
-                                   pin_memory=self.device.type == "cuda")
+        # on the HIP device the workers hand over uint8 frames and labels; ToTensor + Normalize run on the device
+        # (hiast_normalize_u8: the same bits as the host transform) — as the trainers' loaders do since round 2.  A 2048 x 1024
+        # frame is 6 + 2 MB through the worker pipes and PCIe instead of 25 + 17 MB of float32 / int64, and the workers no longer
+        # spend ~50 ms per frame on the float conversion: round 6 measured the stand-alone validator at 12 frames/s on such
+        # frames, the device idle 80 % of the time.  HIAST_HOST_TRANSFORM=1: the reference's float32 / int64 batches.
+        ds.device_transform = self.device.type == "cuda" and os.environ.get("HIAST_HOST_TRANSFORM", "0") != "1"
+        nw = self.cfg.dataset.num_workers
+        self.v_loader = DataLoader(ds, self.cfg.validate.batch_size, num_workers=nw, pin_memory=self.device.type == "cuda",
+                                   persistent_workers=nw > 0)
         d = self.cfg.validate.color_mask_dir_path
         if d is not None:
             assert not os.path.exists(d) or len(os.listdir(d)) == 0
@@ -56,13 +63,25 @@ class Validator:
         (-> argmax); no full-resolution logits or per-scale probability maps are stored"""
         from hiast_amd import kernels as K
         zs, zfs, sizes = [], [], []
+        flip = bool(self.cfg.validate.is_flip)
         for size in self.cfg.validate.resize_sizes:
             assert len(size) == 2 and size[0] <= size[1], \
                 "each resize_size is [height, width] with height <= width, such as [512, 1024]"
             x = _resample(imgs, size)
-            zs.append(self.model(x, lowres=True)["logits_lowres"].float().contiguous())
-            if self.cfg.validate.is_flip:
-                zfs.append(self.model(torch.flip(x, dims=[3]), lowres=True)["logits_lowres"].float().contiguous())
+            # the view and its mirror image in ONE forward (round 6): an inference forward treats every image alone, and one or
+            # two frames leave most of the chip idle.  Only where doubling the launch does not change which kernel runs (the
+            # xconv kernels take 1x1 launches from 4096 rows on: frames whose 1/8-resolution map has >= 4096 pixels), so the
+            # logits are bit for bit those of two forwards; HIAST_VAL_BATCH_FLIP=0: two forwards
+            if (flip and (int(size[0]) // 8) * (int(size[1]) // 8) >= 4096
+                    and os.environ.get("HIAST_VAL_BATCH_FLIP", "1") != "0"):
+                z2 = self.model(torch.cat([x, torch.flip(x, dims=[3])], 0), lowres=True)["logits_lowres"].float()
+                n = x.shape[0]
+                zs.append(z2[:n].contiguous())
+                zfs.append(z2[n:].contiguous())
+            else:
+                zs.append(self.model(x, lowres=True)["logits_lowres"].float().contiguous())
+                if flip:
+                    zfs.append(self.model(torch.flip(x, dims=[3]), lowres=True)["logits_lowres"].float().contiguous())
             sizes.append((int(size[0]), int(size[1])))
         H, W = imgs.shape[2:]
         return K.tta_fused(zs, zfs if self.cfg.validate.is_flip else None, sizes, H, W, want_probs, want_label)
@@ -117,8 +136,13 @@ class Validator:
         acc = torch.zeros(2, C, dtype=torch.int64, device=self.device)
         self.model.eval()
         for data in tqdm.tqdm(self.v_loader, desc="Validation", ncols=100):
-            imgs = data["images"].to(self.device)
-            lbls = data["labels"].to(self.device)
+            if self.device.type == "cuda":
+                from hiast_amd.sseg.datasets import utils as du
+                imgs, lbls = du.to_device_batch(data["images"], data["labels"], self.device)
+                lbls = lbls.long()
+            else:
+                imgs = data["images"].to(self.device)
+                lbls = data["labels"].to(self.device)
             if imgs.is_cuda and self._fused_tta_ok():     # fused tail: label map straight from the low-res head outputs
                 pred = self._tta_device(imgs, False, True)[1].long()
             else:

@@ -155,11 +155,15 @@ def test_validate_gpu_matches_oracle_miou(world):
     inter = np.zeros(C, np.int64)
     union = np.zeros(C, np.int64)
     torch.set_num_threads(16)
+    from hiast_amd.sseg.datasets import utils as du
     for data in v.v_loader:
+        imgs = data["images"]
+        if imgs.dtype == torch.uint8:      # the validator normalises on the device (round 6); the oracle takes the HOST transform
+            imgs = torch.stack([du._img_to_tensor(i.numpy(), du.MEAN, du.STD) for i in imgs])
         with torch.no_grad():
-            logits, _, _ = deeplab_ref.segmentor_logits(data["images"], sd)
+            logits, _, _ = deeplab_ref.segmentor_logits(imgs, sd)
         pred = torch.softmax(logits, 1).argmax(1).numpy()
-        i, u = metrics_ref.intersection_and_union(pred, data["labels"].numpy(), C)
+        i, u = metrics_ref.intersection_and_union(pred, data["labels"].numpy().astype(np.int64), C)
         inter += i
         union += u
     want, _, _ = metrics_ref.miou(inter, union)
@@ -293,11 +297,15 @@ def test_config5_synthia_source_round(tmp_path):
     miou16 = v.run()
     inter, union = np.zeros(C, np.int64), np.zeros(C, np.int64)
     torch.set_num_threads(16)
+    from hiast_amd.sseg.datasets import utils as du
     for data in v.v_loader:
+        imgs = data["images"]
+        if imgs.dtype == torch.uint8:      # the validator normalises on the device (round 6); the oracle takes the HOST transform
+            imgs = torch.stack([du._img_to_tensor(i.numpy(), du.MEAN, du.STD) for i in imgs])
         with torch.no_grad():
-            z = deeplab_ref.segmentor_logits(data["images"], sd)[1].numpy()
+            z = deeplab_ref.segmentor_logits(imgs, sd)[1].numpy()
         _, lab = cref.tta([z], None, [(H, W)], H, W, want_probs=False)
-        a, b = metrics_ref.intersection_and_union(lab.astype(np.int64), data["labels"].numpy(), C)
+        a, b = metrics_ref.intersection_and_union(lab.astype(np.int64), data["labels"].numpy().astype(np.int64), C)
         inter += a
         union += b
     w16, w13, iou = metrics_ref.miou(inter.astype(np.float64), union.astype(np.float64), synthia=True)

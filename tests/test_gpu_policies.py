@@ -206,8 +206,11 @@ def test_validator_tta_on_hip_matches_oracle(tmp_path):
     inter, union, agree, total = np.zeros(C, np.int64), np.zeros(C, np.int64), 0, 0
     torch.set_num_threads(16)
     from PIL import Image
+    from hiast_amd.sseg.datasets import utils as du
     for data in v.v_loader:
         imgs = data["images"]
+        if imgs.dtype == torch.uint8:      # the validator normalises on the device (round 6); the oracle takes the HOST transform
+            imgs = torch.stack([du._img_to_tensor(i.numpy(), du.MEAN, du.STD) for i in imgs])
         zs, zfs = [], []
         with torch.no_grad():
             for size in c.validate.resize_sizes:
@@ -215,7 +218,7 @@ def test_validator_tta_on_hip_matches_oracle(tmp_path):
                 zs.append(deeplab_ref.segmentor_logits(x, sd)[1].numpy())
                 zfs.append(deeplab_ref.segmentor_logits(torch.flip(x, dims=[3]), sd)[1].numpy())
         _, lab = cref.tta(zs, zfs, c.validate.resize_sizes, H, W, want_probs=False)
-        a, b = metrics_ref.intersection_and_union(lab.astype(np.int64), data["labels"].numpy(), C)
+        a, b = metrics_ref.intersection_and_union(lab.astype(np.int64), data["labels"].numpy().astype(np.int64), C)
         inter += a
         union += b
         for k, p in enumerate(data["image_paths"]):

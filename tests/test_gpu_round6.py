@@ -285,3 +285,44 @@ def test_generator_grouped_forwards_write_the_same_artefacts(tmp_path, monkeypat
             assert sorted(ref) == sorted(got) and len([k for k in ref if k.endswith(".png")]) == 11
             for k in ref:
                 assert np.array_equal(ref[k], got[k]), (policy, bs, tag, k)
+
+
+def test_validator_batches_a_view_with_its_mirror_image(tmp_path, monkeypatch):
+    """round 6: the TTA validator (reference: workflows/validator.py:34-55) runs a resized view and its horizontal flip in ONE
+    forward where that does not change the kernels that run (frames >= 512 x 512).  Per-class IoU and mIoU are bit for bit those of
+    two forwards (HIAST_VAL_BATCH_FLIP=0); two scales, batch sizes 1 and 2."""
+    from hiast_amd.utils.registry import register  # noqa: F401
+    from hiast_amd.utils.registry.registries import MODEL
+    from hiast_amd.tools import synth_data
+    from hiast_amd.workflows.validator import Validator
+    from make_golden import seeded_state_dict
+    Hh, Ww = 512, 512
+    root = str(tmp_path)
+    cfg = synth_data.synthetic_cfg(root, n_train=1, n_val=4, h=Hh, w=Ww)
+    m = MODEL["SelfTrainingSegmentor"](cfg)
+    m.load_state_dict({"seg_model." + k: v for k, v in seeded_state_dict(m.seg_model, 778).items()})
+    m = m.cuda().eval()
+    ds = np.stack([synth_data.make_sample(5 + i, Hh, Ww)[0].astype(np.float32).transpose(2, 0, 1) for i in range(2)]) / 255.0
+    synth_data.calibrate_bn(m, torch.from_numpy((ds - 0.45) / 0.225).cuda())
+    ck = os.path.join(root, "warmup.pth")
+    torch.save({k: v.detach().cpu().clone() for k, v in m.state_dict().items()}, ck)
+    del m
+    out = {}
+    for bs in (1, 2):
+        for tag, env in (("two", "0"), ("one", "1")):
+            monkeypatch.setenv("HIAST_VAL_BATCH_FLIP", env)
+            c = cfg.clone()
+            c.validate.resume_from = ck
+            c.validate.batch_size = bs
+            c.validate.is_flip = True
+            c.validate.resize_sizes = [[Hh, Ww], [640, 640]]
+            v = Validator(c)
+            calls = []
+            fwd = v.model.forward
+            monkeypatch.setattr(v.model, "forward", lambda *a, **k: (calls.append(a[0].shape[0]), fwd(*a, **k))[1])
+            v.run()
+            out[(bs, tag)] = (np.asarray(v.iou).copy(), v.miou, list(calls))
+        two, one = out[(bs, "two")], out[(bs, "one")]
+        assert len(one[2]) * 2 == len(two[2]) and set(one[2]) == {2 * bs} and set(two[2]) == {bs}
+        assert np.array_equal(two[0].view(np.uint64), one[0].view(np.uint64)) and two[1] == one[1], (bs, two[1], one[1])
+        assert 0.0 <= one[1] <= 1.0
