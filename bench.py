@@ -54,6 +54,11 @@ def parse():
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' only for "
                    "functional tests of the N>1 path on a single GPU")
     p.add_argument("--same-device", action="store_true", help="testing: every rank uses cuda:0")
+    p.add_argument("--rehearse-dist", action="store_true",
+                   help="with --gpus 1: a ONE-rank process group on --backend takes the whole N > 1 code path (DDP, SyncBN "
+                        "exchanges on the statistics communicator, histogram on the auxiliary one; HIAST_DIST_REHEARSAL=1, "
+                        "hiast_amd/utils/comm.py).  The only way to run torch's RCCL backend on a one-GPU box; the line it "
+                        "prints says 'dp1-rehearsal' and is not a bench result")
     p.add_argument("--cpu-threads", type=int, default=64, help="upper bound; the usable CPUs of the box decide")
     p.add_argument("--cpu-reps", type=int, default=3)
     p.add_argument("--amp-dtype", default=os.environ.get("HIAST_BENCH_AMP", "fp16"), choices=["bf16", "fp16"],
@@ -339,12 +344,13 @@ def step_fractions(groups, ms_per_step, serial_step_ms):
 
 
 class HotPath:
-    def __init__(self, cfg, device, rank, world, B):
+    def __init__(self, cfg, device, rank, world, B, multi=None):
         from hiast_amd.utils import utils
         from hiast_amd.utils.registry import register  # noqa: F401
         from torch.nn.parallel import DistributedDataParallel as DDP
         from hiast_amd.workflows.trainer.base_trainer import _Bare, autocast_dtype, make_grad_scaler
         self.cfg, self.device, self.rank, self.world, self.B = cfg, device, rank, world, B
+        self.multi = multi = (world > 1) if multi is None else multi      # the N > 1 code path (also: the one-rank rehearsal)
         utils.seed_everything(cfg.train.random_seed)
         model = utils.init_model(cfg).to(device)
         if os.environ.get("HIAST_BENCH_RAW_INIT", "0") != "1":      # =1: the plain random init — NaN weights from step 3 on
@@ -355,7 +361,7 @@ class HotPath:
         self.scaler = make_grad_scaler(self.amp)        # fp16: apex's dynamic loss scaling (2^16, halved on overflow)
         self.skipped = 0
         self.model = (DDP(model, device_ids=[device.index], gradient_as_bucket_view=True, bucket_cap_mb=32,
-                          broadcast_buffers=False) if world > 1 else _Bare(model))
+                          broadcast_buffers=False) if multi else _Bare(model))
         self.teacher = cfg.cst_training.is_enabled
         if self.teacher:
             self.ema = utils.init_model(cfg, student_model=self.model).to(device)
@@ -421,7 +427,7 @@ class HotPath:
         model.train(was)
 
     def _allreduce(self, t):
-        if self.world > 1:      # histogram / class sums of the pseudo-label pass: auxiliary communicator (utils/comm.py)
+        if self.multi:          # histogram / class sums of the pseudo-label pass: auxiliary communicator (utils/comm.py)
             from hiast_amd.utils import comm
             comm.all_reduce(t, "aux")
         return t
@@ -453,7 +459,7 @@ class HotPath:
             # that time every launch)
             logits = self._graphed(net, None)(self.weak, parts=None if self.use_side else 1, eager=not self.use_side)
             mp, am, hist = K.plabel_pass1(logits.contiguous(), H, W)
-            if self.world > 1 and getattr(self, "_pl_on_side", False):
+            if self.multi and getattr(self, "_pl_on_side", False):
                 # N > 1, pass on its own stream: the histogram all-reduce is ISSUED by plabel_finish(), after the student
                 # forward has issued its SyncBN all-reduces — a communicator executes its operations in issue order, and
                 # this one waits for the whole pseudo-label forward: issued here it would hold back every SyncBN
@@ -794,6 +800,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+    multi = world > 1
+    if args.rehearse_dist:
+        assert world == 1, "--rehearse-dist is the ONE-rank rehearsal of the N > 1 path"
+        multi = True
+        os.environ["HIAST_DIST_REHEARSAL"] = "1"        # (before anything of the package asks: utils/comm.py rehearsal())
+        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29541"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+            os.environ.setdefault(k, v)
     if args.global_batch:
         assert args.global_batch % world == 0, "--global-batch %d does not divide over %d ranks" % (args.global_batch, world)
         args.batch = args.global_batch // world
@@ -807,7 +820,7 @@ def main():
     device = torch.device("cuda", local)
     dog = Watchdog(args.watchdog_s, rank, world, json_out, args)
     from hiast_amd.utils import comm
-    if world > 1:
+    if multi:
         # (no device_id: communicators are then created lazily by ncclCommInitRank at the first collective of each group —
         # the oldest and most exercised path of torch's RCCL backend — instead of eagerly + ncclCommSplit for new groups)
         # timeout = HIAST_DIST_TIMEOUT_S (180 s): a collective one rank never joins raises instead of hanging for 10-30 minutes;
@@ -818,18 +831,18 @@ def main():
     cu_reserve = comm.apply_cu_reserve(world, device)
     torch.backends.cudnn.benchmark = bool(int(os.environ.get("HIAST_MIOPEN_FIND", "0")))
 
-    cfg = make_cfg(world, args.trainer, args.amp_dtype)
+    cfg = make_cfg(2 if args.rehearse_dist else world, args.trainer, args.amp_dtype)      # (gpu_num > 1 => SyncBN layers)
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):        # the package's progress prints ("%% freeze all BN layers" ...)
         from hiast_amd.utils import utils as _u
         _u.limit_cpu_threads()      # (N ranks per node: N OpenMP pools sized for the whole machine otherwise)
-        hp = HotPath(cfg, device, rank, world, args.batch)   # must not precede the ONE JSON line on stdout
+        hp = HotPath(cfg, device, rank, world, args.batch, multi)   # must not precede the ONE JSON line on stdout
     dog.beat("model built")
     timer = KernelTimer()
     timer.install()
 
     def sync():
-        if world > 1:
+        if multi:
             dist.barrier(device_ids=[local]) if args.backend == "nccl" else dist.barrier()
         torch.cuda.synchronize()
 
@@ -844,7 +857,7 @@ def main():
         hp.use_side = not serial
         HF.enable_wgrad_overlap(not serial)
         hp.step()
-        if world > 1 or it == 0:
+        if multi or it == 0:
             torch.cuda.synchronize()        # (the first step of a rank compiles nothing but loads ~200 code objects; at N > 1
         dog.beat("warm-up step %d of %d" % (it + 1, args.warmup))      # every warm-up step is a checkpoint of the watchdog)
     hp.use_side = True
@@ -897,7 +910,7 @@ def main():
     elapsed = time.perf_counter() - t0
     # collectives issued per step and communicator inside the timed region (host-side counters; the reducer's own bucket count)
     collectives = None
-    if world > 1:
+    if multi:
         collectives = {"syncbn_stat_all_reduces": (_comm.COUNTS["stat"] - coll_before["stat"]) / float(args.steps),
                        "pseudo_label_aux_all_reduces": (_comm.COUNTS["aux"] - coll_before["aux"]) / float(args.steps),
                        "gradient_buckets": None,
@@ -929,7 +942,7 @@ def main():
     # enqueues ahead of the device the two events complete back to back (~0); a host that arrives late shows as a gap.
     gaps = [marks[i][4].elapsed_time(marks[i + 1][0]) for i in range(1, len(marks) - 1)]      # (step 0 is the serial one)
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
+    if multi:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     # after the timed region: the last step's losses (mean over ranks) and, at N > 1, whether the replicas still agree —
@@ -938,7 +951,7 @@ def main():
     names = list(last_losses.keys())
     lv = torch.stack([torch.mean(last_losses[k]).double() for k in names])
     ranks_agree = None
-    if world > 1:
+    if multi:
         dist.all_reduce(lv)
         lv /= world
         chk = torch.cat([torch.from_numpy(hp.thr.view(np.int64).copy()).to(device),
@@ -975,7 +988,7 @@ def main():
                        "images_per_gpu_per_step": args.batch, "num_classes": C,
                        "batch_semantics": ("reference_bs%d: global batch split over the ranks + SyncBN (code/train.py:52-53)"
                                            % args.global_batch if args.global_batch else "per-GPU batch (weak scaling)"),
-                       "parallelism": "dp%d" % world if world > 1 else "single", "cu_reserve": cu_reserve},
+                       "parallelism": "dp1-rehearsal" if args.rehearse_dist else ("dp%d" % world if world > 1 else "single"), "cu_reserve": cu_reserve},
             "phases_ms": {"pseudo_label": 1e3 * t_pl / args.steps, "train_step": 1e3 * t_tr / args.steps,
                           "note": "of the first timed step, which runs every part in order on one stream (per-launch "
                                   "events); the other steps overlap the parts on four streams"},
@@ -1015,7 +1028,7 @@ def main():
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
     dog.stop()
-    if world > 1:
+    if multi:
         dist.barrier(device_ids=[local]) if args.backend == "nccl" else dist.barrier()
         dist.destroy_process_group()
 

@@ -175,9 +175,14 @@ def discriminator_input(logits_lr, size, entropy=False):
 
 
 def _sync_world(bn):
+    """number of ranks a BatchNorm layer's statistics are summed over: 1 = no exchange (plain BN, or no process group);
+    N > 1 = SyncBN over N ranks; 0 = SyncBN in the one-rank rehearsal (utils/comm.py: the exchange is issued, the count is
+    this rank's)"""
     import torch.distributed as dist
     if isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized():
-        return dist.get_world_size()
+        from hiast_amd.utils import comm
+        w = dist.get_world_size()
+        return 0 if (w == 1 and comm.rehearsal()) else w
     return 1
 
 
@@ -218,9 +223,9 @@ class _BnActFn(torch.autograd.Function):
             return y
         part = K.bn_stats(x)
         count = float(x.shape[0] * x.shape[2] * x.shape[3])
-        if world > 1:      # SyncBN: sum the per-plane partials across ranks in place (one collective, no extra kernels)
+        if world != 1:     # SyncBN: sum the per-plane partials across ranks in place (one collective, no extra kernels)
             _stat_all_reduce(part)
-            count *= world
+            count *= max(world, 1)
         y, sm, si = K.bn_act_apply(x, res, gamma, beta, running_mean, running_var, part, count, momentum, eps, relu)
         ctx.save_for_backward(x, y, gamma, sm, si)
         ctx.relu, ctx.has_res, ctx.world, ctx.count = relu, res is not None, world, count
@@ -235,7 +240,7 @@ class _BnActFn(torch.autograd.Function):
         if dy.dtype != x.dtype:
             dy = dy.to(x.dtype)
         part = K.bn_act_bwd_stats(dy, y, x, sm, si, ctx.relu)
-        if ctx.world > 1:
+        if ctx.world != 1:
             _stat_all_reduce(part)
         want_p = gamma is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3])
         dx, dres, dg, db = K.bn_act_bwd_apply(dy, y, x, gamma, sm, si, part, ctx.count, ctx.relu,
@@ -269,9 +274,9 @@ class _BnActNhwcFn(torch.autograd.Function):
                                           relu, want_mask)
         else:
             sums = K.bn_nhwc_stats_from_partial(partial) if partial is not None else K.bn_nhwc_stats(x)
-            if world > 1:      # SyncBN: one all-reduce of [C,2] double sums
+            if world != 1:     # SyncBN: one all-reduce of [C,2] double sums
                 _stat_all_reduce(sums)
-                count *= world
+                count *= max(world, 1)
             out = K.bn_nhwc_apply(x, res, gamma, beta, running_mean, running_var, sums, count, momentum, eps, relu,
                                   want_mask)
         y, sm, si = out[:3]
@@ -319,7 +324,7 @@ class _BnActNhwcFn(torch.autograd.Function):
                 sums = K.bn_nhwc_stats_from_partial(fused)
             else:
                 sums = K.bn_nhwc_bwd_stats(dy, y, x, gamma, beta, sm, si, ctx.gate)
-            if ctx.world > 1:
+            if ctx.world != 1:
                 _stat_all_reduce(sums)
         want_p = gamma is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3])
         handoff = ctx.box is not None and ctx.needs_input_grad[1]
@@ -415,7 +420,7 @@ class _ConvNhwcFn(torch.autograd.Function):
                 bx, sm, si, gamma, beta = ctx.in_bn["bn"]
                 dxv, bpartial = K.igemm_dgrad_bn_stats(dy.permute(0, 2, 3, 1), wpt, dil, bx.permute(0, 2, 3, 1), gamma, beta,
                                                        sm, si)
-                if ctx.in_bn.get("world", 1) > 1 and not _NO_ASYNC_STAT:
+                if ctx.in_bn.get("world", 1) != 1 and not _NO_ASYNC_STAT:
                     # SyncBN: reduce the per-block sums now and start their all-reduce; the weight gradient below (50 - 300 us,
                     # on the main stream under DDP) runs while the [C,2] exchange (a latency, ~30 us on 8 devices) is in
                     # flight — the BatchNorm's backward then finds the reduced sums instead of waiting for the exchange
@@ -429,7 +434,7 @@ class _ConvNhwcFn(torch.autograd.Function):
                 bx3, bmask, sm3, si3 = ctx.in_bn3["bn3"]
                 dxv, bpartial = K.xconv_dgrad_gated_bn_stats(dy.permute(0, 2, 3, 1), wpt, gated[0].permute(0, 2, 3, 1), gated[1],
                                                              bx3.permute(0, 2, 3, 1), bmask, sm3, si3)
-                if ctx.in_bn3.get("world", 1) > 1 and not _NO_ASYNC_STAT:
+                if ctx.in_bn3.get("world", 1) != 1 and not _NO_ASYNC_STAT:
                     bsums = K.bn_nhwc_stats_from_partial(bpartial)
                     ctx.in_bn3["bwd_sums"] = (bsums, _stat_all_reduce(bsums, async_op=True))
                 else:
@@ -814,8 +819,8 @@ def wgrad_side_stream(device):
     """the side stream weight gradients run on, or None (not enabled / DDP / HIAST_NO_WGRAD_STREAM=1)"""
     if not _wgrad_overlap[0] or os.environ.get("HIAST_NO_WGRAD_STREAM", "0") == "1":
         return None
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    from hiast_amd.utils import comm
+    if comm.multi():
         return None
     st = _wgrad_streams.get(device)
     if st is None:

@@ -26,9 +26,22 @@ import torch.distributed as dist
 _groups = {}
 
 
+def rehearsal():
+    """HIAST_DIST_REHEARSAL=1: a process group of ONE rank takes the N > 1 code path — SyncBN layers exchange their [C,2] sums
+    through the statistics communicator, the pseudo-label histogram goes through the auxiliary one, weight gradients stay on the
+    main stream under DDP.  A one-rank all-reduce is the identity, so results must match the single-process step; what the
+    rehearsal exercises is the BACKEND: `bench.py --rehearse-dist` is the only way to run torch's RCCL process group (its own
+    streams, event hand-offs, async work handles) on a one-GPU box (RCCL refuses two ranks on one device)."""
+    return os.environ.get("HIAST_DIST_REHEARSAL", "0") == "1"
+
+
+def multi():
+    """does this process run the N > 1 code path?  (more than one rank, or the one-rank rehearsal)"""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or rehearsal())
+
+
 def _enabled():
-    return (os.environ.get("HIAST_COMM_GROUPS", "1") != "0" and dist.is_available() and dist.is_initialized()
-            and dist.get_world_size() > 1)
+    return os.environ.get("HIAST_COMM_GROUPS", "1") != "0" and multi()
 
 
 def _get(name):

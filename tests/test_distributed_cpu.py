@@ -267,6 +267,37 @@ def test_stat_and_aux_groups_are_separate_communicators(tmp_path):
     assert bool(np.load(out)[0])
 
 
+def _rehearsal_worker(rank, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    from hiast_amd.utils import comm
+    from hiast_amd import functional as HF
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    sbn, bn = torch.nn.SyncBatchNorm(4), torch.nn.BatchNorm2d(4)
+    os.environ.pop("HIAST_DIST_REHEARSAL", None)
+    res = [comm.multi(), comm.stat_group() is None, HF._sync_world(sbn), HF._sync_world(bn)]
+    os.environ["HIAST_DIST_REHEARSAL"] = "1"
+    res += [comm.multi(), comm.stat_group() is not None and comm.stat_group() is not comm.aux_group(),
+            HF._sync_world(sbn), HF._sync_world(bn)]
+    before = comm.COUNTS["stat"]
+    t = torch.arange(6, dtype=torch.float64)
+    HF._stat_wait(HF._stat_all_reduce(t, async_op=True))
+    res += [bool(torch.equal(t, torch.arange(6, dtype=torch.float64))), comm.COUNTS["stat"] - before]
+    np.save(out, np.array([float(v) for v in res]))
+    dist.destroy_process_group()
+    comm.reset()
+
+
+def test_one_rank_rehearsal_takes_the_exchange_path(tmp_path):
+    """HIAST_DIST_REHEARSAL=1 (utils/comm.py, `bench.py --rehearse-dist`): with a ONE-rank process group the package takes the
+    N > 1 path — own communicators, SyncBN layers report world 0 (= exchange, count of this rank), plain BN stays 1 — and without
+    the switch a one-rank group is a single process"""
+    out = str(tmp_path / "r.npy")
+    mp.spawn(_rehearsal_worker, args=(_free_port(), out), nprocs=1, join=True)
+    assert np.load(out).tolist() == [0, 1, 1, 1, 1, 1, 0, 1, 1, 1]
+
+
 def test_usable_cpus_respects_affinity():
     from hiast_amd.utils import comm
     n = comm.usable_cpus()

@@ -94,6 +94,30 @@ def test_bench_two_ranks_through_spawn_ranks_rccl():
     assert "grad strides do not match bucket view" not in err
 
 
+def test_bench_rehearses_the_n_gt_1_path_on_one_rank_over_rccl():
+    """`bench.py --gpus 1 --rehearse-dist` (round 6): a ONE-rank process group on torch's RCCL backend ('nccl') takes the whole
+    N > 1 code path — DDP with bucket views, 208 SyncBN exchanges on the statistics communicator (the backward ones as async
+    work handles started ahead of the weight gradient), 3 auxiliary reduces, weight gradients on the main stream.  RCCL refuses
+    two ranks on one device, so this is what a one-GPU box can run of the backend the driver's N > 1 runs use: process-group
+    start-up, three communicators, RCCL's own streams and their event hand-offs to the four streams of the step.  A one-rank
+    all-reduce is the identity: the losses must match the single-process step (which runs other BatchNorm kernels — apply
+    straight from the per-block partials — hence the fp16 tolerance of the CU-reserve test)."""
+    out, err = _run_bench(["--rehearse-dist", "--batch", "2"], gpus=1)
+    assert out["n_gpus"] == 1 and out["config"]["parallelism"] == "dp1-rehearsal"
+    _check_collectives(out)
+    assert out["ranks_agree"] is True
+    fin = out["final_losses"]
+    assert all(v == v and abs(v) < 1e4 for v in fin.values()), fin
+    h = out["collectives_per_step"]["host_ms_per_step"]
+    assert h["stat"] > 0 and h["aux"] > 0
+    single = _run_bench(["--batch", "2"], gpus=1)[0]
+    assert single["config"]["parallelism"] == "single" and single["collectives_per_step"] is None
+    for k, v in fin.items():
+        assert abs(v - single["final_losses"][k]) <= 3e-2 * max(1.0, abs(v)), (k, v, single["final_losses"][k])
+    print("rehearsal: %.2f ms/step (single process %.2f); host ms per step inside the collectives: %s"
+          % (out["ms_per_step"], single["ms_per_step"], h))
+
+
 @pytest.mark.parametrize("no_async", ["0", "1"])
 def test_bench_four_ranks_reference_batch_semantics_gloo_same_device(no_async):
     """cfg4 in the reference's own semantics (code/train.py:52-53: a GLOBAL batch, here 4 = ONE image per rank, SyncBN
