@@ -8,6 +8,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from hiast_amd.utils import comm
+
 
 class ResultRecorder:
 
@@ -35,7 +37,7 @@ class ResultRecorder:
         if self.acc is None:
             return {}
         vec = self.acc / max(self.n, 1)
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if comm.multi():      # (N > 1, or the one-rank rehearsal: utils/comm.py)
             dist.all_reduce(vec)
             vec /= dist.get_world_size()
         vals = dict(zip(self.names, vec.cpu().tolist()))

@@ -91,7 +91,8 @@ def load_model(cfg, resume_from=None, student_model=None):
 def init_model(cfg, resume_from=None, student_model=None):
     """utils.py:92-112 — SyncBN when more than one GPU takes part, then the BN freeze."""
     model = load_model(cfg, resume_from=resume_from, student_model=student_model)
-    if cfg.train.gpu_num > 1:
+    from hiast_amd.utils import comm
+    if cfg.train.gpu_num > 1 or comm.rehearsal():      # (rehearsal: the one-rank run of the N > 1 path, utils/comm.py)
         model = nn.SyncBatchNorm.convert_sync_batchnorm(model)
         print("%% convert BN to SyncBN")
     if cfg.model.is_freeze_bn:

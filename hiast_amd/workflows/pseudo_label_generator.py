@@ -274,6 +274,7 @@ class BasePseudoGenerator:
         self.class_threshold = None
         self.rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.multi = self.world > 1 or comm.multi()      # (the one-rank rehearsal takes the exchange path too: utils/comm.py)
         self._io = ThreadPoolExecutor(max_workers=max(2, cfg.dataset.num_workers))
         self._pending = []
         comm.setup()
@@ -316,7 +317,7 @@ class BasePseudoGenerator:
             or self.rank != 0)
         if self.rank == 0:
             os.makedirs(self.pseudo_label_save_dir, exist_ok=True)
-        if self.world > 1:
+        if self.multi:
             dist.barrier()
 
     # -- artefacts ---------------------------------------------------------------------------
@@ -330,7 +331,7 @@ class BasePseudoGenerator:
         for f in self._pending:
             f.result()
         self._pending = []
-        if self.world > 1:   # per-image records live on their owner rank: gather them on rank 0
+        if self.multi:   # per-image records live on their owner rank: gather them on rank 0
             parts = [None] * self.world
             dist.all_gather_object(parts, (self.sample_stats, self.samples_class))
             self.sample_stats = [s for p in parts for s in p[0]]
@@ -356,7 +357,7 @@ class BasePseudoGenerator:
 
     # -- one batch ---------------------------------------------------------------------------
     def _allreduce(self, t):
-        if self.world > 1:      # histogram / class sums: on the auxiliary communicator (utils/comm.py)
+        if self.multi:      # histogram / class sums: on the auxiliary communicator (utils/comm.py)
             comm.all_reduce(t, "aux", op=dist.ReduceOp.SUM)
         return t
 
@@ -445,7 +446,7 @@ class BasePseudoGenerator:
         """rank 0 looks at the directory; every rank takes ITS decision (a rank that went on alone into the
         collectives of run() would wait for the others forever)"""
         done = self.rank == 0 and len(os.listdir(self.pseudo_label_save_dir)) >= len(self.t_dataset)
-        if self.world > 1:
+        if self.multi:
             box = [bool(done)]
             dist.broadcast_object_list(box, src=0)
             done = box[0]
@@ -507,7 +508,7 @@ class CBSTPseudoGenerator(ConstantThresholdPseudoGenerator):
         for imgs, _ in self._batches():
             full = self.engine.pass1(imgs)
             offset = None
-            if self.world > 1:          # class-c pixels of this global batch held by the lower ranks
+            if self.multi:          # class-c pixels of this global batch held by the lower ranks
                 mine = full.long().sum(1)
                 parts = [torch.zeros_like(mine) for _ in range(self.world)]
                 dist.all_gather(parts, mine, group=comm.aux_group())
@@ -539,7 +540,7 @@ class IASPseudoGenerator(BasePseudoGenerator):
         # writes; the device no longer idles while the host computes thresholds, reads the label maps back and hands them
         # to the PNG writers, and the host no longer waits through a forward it could have enqueued earlier.
         for paths, st in self._pipelined_states():
-            hist = self.engine.hist_host(st, self._allreduce if self.world > 1 else None)
+            hist = self.engine.hist_host(st, self._allreduce if self.multi else None)
             _, self.class_threshold = ias_math.ias_update(hist, self.class_threshold, ias.alpha, ias.beta, ias.gamma)
             self.select_and_save_confident_label(paths, st)
         self.save_data()

@@ -114,6 +114,9 @@ class BaseTrainer:
         if torch.cuda.is_available():
             utils.limit_cpu_threads()
         self.world = self.cfg.train.gpu_num
+        # the N > 1 code path: more than one rank — or HIAST_DIST_REHEARSAL=1, a ONE-rank process group that runs DDP, the SyncBN
+        # exchanges and the validation all-reduce through the real backend (RCCL on a one-GPU box; utils/comm.py rehearsal())
+        self.multi = self.world > 1 or comm.rehearsal()
         self.logger = None
         if self.gpu_index == 0:
             os.makedirs(self.cfg.work_dir, exist_ok=True)
@@ -121,7 +124,7 @@ class BaseTrainer:
             self.checkpoint_dir_path = os.path.join(self.cfg.work_dir, "checkpoints")
             os.makedirs(self.checkpoint_dir_path, exist_ok=True)
         use_cuda = torch.cuda.is_available()
-        if self.world > 1 and not dist.is_initialized():
+        if self.multi and not dist.is_initialized():
             # (timeout=comm.timeout(): a collective one rank never joins raises after HIAST_DIST_TIMEOUT_S instead of hanging)
             if "MASTER_ADDR" in os.environ and "RANK" in os.environ:
                 dist.init_process_group(backend="nccl" if use_cuda else "gloo", timeout=comm.timeout())
@@ -129,7 +132,7 @@ class BaseTrainer:
                 dist.init_process_group(backend="nccl" if use_cuda else "gloo",
                                         init_method="tcp://127.0.0.1:{}".format(self.cfg.train.port),
                                         world_size=self.world, rank=self.gpu_index, timeout=comm.timeout())
-        if self.world > 1:
+        if self.multi:
             comm.setup()        # communicators of the SyncBN sums and of the small exchanges, beside DDP's (utils/comm.py)
         if use_cuda:
             # HIAST_SAME_DEVICE=1 (functional tests of the N>1 path on a one-GPU box): every rank uses cuda:0
@@ -141,7 +144,7 @@ class BaseTrainer:
             raise RuntimeError("training runs on the HIP device; no GPU is visible and there is no CPU fallback")
 
     def _wrap(self, model):
-        if self.world > 1:
+        if self.multi:
             return DDP(model, device_ids=[self.device_index], gradient_as_bucket_view=True, bucket_cap_mb=32,
                        broadcast_buffers=False)
         return _Bare(model)
@@ -236,7 +239,7 @@ class BaseTrainer:
         self.validate(self.model, self.model_recorder, current_iter)
 
     def _sync_grads(self, optimizer):
-        if self.manual_allreduce and self.world > 1:
+        if self.manual_allreduce and self.multi:
             utils.all_reduce_grads([p for g in optimizer.param_groups for p in g["params"]], self.world)
 
     def update_model(self, g_optimizer, d_optimizer, losses):
@@ -310,7 +313,7 @@ class BaseTrainer:
             acc[0] += inter
             acc[1] += union
         model.train(was_training)    # the reference calls model.train() at the top of every iteration
-        if self.world > 1:
+        if self.multi:
             comm.all_reduce(acc, "aux")       # one 38-element all-reduce instead of two
         acc = acc.cpu().numpy().astype(np.float64)
         iou = acc[0] / (acc[1] + 1e-10)

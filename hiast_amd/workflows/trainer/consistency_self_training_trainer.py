@@ -207,6 +207,6 @@ class ConsistencySelfTrainingTrainer(BaseTrainer):
             # (HIAST_GRAPH_EVAL=1 replays the teacher forward from a graph of its own: a replay cannot be captured into another
             # graph, the iteration then stays eager)
             on = self._graph_train = (os.environ.get("HIAST_GRAPH_TRAIN", "1") == "1"
-                                      and os.environ.get("HIAST_GRAPH_EVAL", "0") != "1" and self.world == 1
+                                      and os.environ.get("HIAST_GRAPH_EVAL", "0") != "1" and not self.multi
                                       and self.amp_dtype is not None and not getattr(self, "manual_allreduce", False))
         return on

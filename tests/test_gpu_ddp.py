@@ -37,7 +37,7 @@ def _inputs():
     return weak, strong, np.concatenate([half, other])
 
 
-def _make_trainer(root, world, rank, apex_opt):
+def _make_trainer(root, world, rank, apex_opt, port=None):
     from hiast_amd.utils.registry import register  # noqa: F401
     from hiast_amd.utils.default_config import get_default_cfg
     from hiast_amd.workflows.trainer.consistency_self_training_trainer import ConsistencySelfTrainingTrainer
@@ -65,6 +65,8 @@ def _make_trainer(root, world, rank, apex_opt):
     c.train.apex_opt = apex_opt
     c.train.amp_dtype = "bf16"       # (O1 here = the 16-bit step WITHOUT loss scaling: _step() below calls backward() itself)
     c.train.gpu_num = world
+    if port is not None:
+        c.train.port = int(port)
     c.train.resume_from = os.path.join(root, "init.pth")
     c.work_dir = os.path.join(root, "work_w%d_%s" % (world, apex_opt))
     c.freeze()
@@ -120,6 +122,34 @@ def _worker(rank, world, port, root, apex_opt, out, backend="gloo"):
     res["stride_warnings"] = np.int64(sum("strides" in str(w.message) for w in wlist))
     np.savez(out % rank, **res)
     dist.barrier()
+    dist.destroy_process_group()
+
+
+def _rehearsal_worker(rank, port, root, apex_opt, out):
+    """ONE rank on torch's RCCL backend taking the trainer's N > 1 path (HIAST_DIST_REHEARSAL=1, utils/comm.py): the trainer
+    starts the process group itself (BaseTrainer.initialize: tcp://127.0.0.1:cfg.train.port, world_size 1)"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["HIAST_DIST_REHEARSAL"] = "1"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("MASTER_ADDR", "MASTER_PORT", "RANK", "WORLD_SIZE"):
+        os.environ.pop(k, None)
+    import warnings
+    from hiast_amd.utils import comm
+    torch.cuda.set_device(0)
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
+        tr = _make_trainer(root, 1, 0, apex_opt, port=port)
+        assert dist.is_initialized() and dist.get_backend() == "nccl" and dist.get_world_size() == 1
+        assert isinstance(tr.model, torch.nn.parallel.DistributedDataParallel)
+        n_sync = sum(isinstance(m, torch.nn.SyncBatchNorm) for m in tr.model.modules())
+        assert n_sync == 104
+        before = comm.COUNTS["stat"]
+        res = _step(tr, *_inputs())
+    res["stride_warnings"] = np.int64(sum("strides" in str(w.message) for w in wlist))
+    res["stat_reduces"] = np.int64(comm.COUNTS["stat"] - before)
+    np.savez(out, **res)
+    dist.barrier(device_ids=[0])
     dist.destroy_process_group()
 
 
@@ -205,3 +235,35 @@ def test_two_rank_step_equals_single_process(root, apex_opt, backend):
     for k in [k for k in one if k.startswith(("rm/", "rv/"))]:      # SyncBN: both ranks hold the GLOBAL running statistics
         for p in parts:
             assert np.allclose(p[k], one[k], rtol=1e-3 if fp32 else 3e-2, atol=1e-3 if fp32 else 1e-2), k
+
+
+@pytest.mark.parametrize("apex_opt", ["O0", "O1"])
+def test_one_rank_rehearsal_over_rccl_equals_single_process(root, apex_opt):
+    """the trainer's N > 1 path — process group started by BaseTrainer.initialize, SyncBN conversion, DDP with bucket views, the
+    SyncBN exchanges on the statistics communicator — through torch's RCCL backend on ONE rank (HIAST_DIST_REHEARSAL=1): a one-rank
+    all-reduce is the identity, so the step equals the single-process step on the same batch up to the summation order of the
+    BatchNorm sums (the SyncBN form reduces per-block partials to [C,2] in a launch of its own).  RCCL refuses two ranks on one
+    device; the two-rank form of this test runs on gloo here and on RCCL wherever two devices are visible."""
+    out = os.path.join(root, "rehearsal_" + apex_opt + ".npz")
+    mp.spawn(_rehearsal_worker, args=(_port(), root, apex_opt, out), nprocs=1, join=True)
+    got = dict(np.load(out))
+    tr = _make_trainer(root, 1, 0, apex_opt)
+    assert not isinstance(tr.model, torch.nn.parallel.DistributedDataParallel)
+    one = _step(tr, *_inputs())
+    assert int(got["stride_warnings"]) == 0, "DDP: grad strides do not match the bucket view"
+    # O1: 104 layers x (forward of the student + backward); the teacher / pseudo-label forwards run in eval mode.  O0 (fp32
+    # NCHW kernels) exchanges in the same places
+    assert int(got["stat_reduces"]) == 208, int(got["stat_reduces"])
+    fp32 = apex_opt == "O0"
+    for k in [k for k in one if k.startswith("loss/")]:
+        assert abs(got[k] - one[k]) <= (2e-4 if fp32 else 3e-2) * max(1.0, abs(one[k])), (k, got[k], one[k])
+    gkeys = [k for k in one if k.startswith("grad/")]
+    assert len(gkeys) == 112
+    rel = {k: (float(np.abs(got[k] - one[k]).max() / (np.abs(one[k]).max() + 1e-30)), _cos(got[k], one[k])) for k in gkeys}
+    worst = min(rel.items(), key=lambda kv: kv[1][1])
+    print("rehearsal %s: worst cosine %.6f (%s), worst max-rel %.2e" % (apex_opt, worst[1][1], worst[0][5:],
+                                                                        max(v[0] for v in rel.values())))
+    assert max(v[0] for v in rel.values()) <= 0.35, max(rel.items(), key=lambda kv: kv[1][0])
+    assert worst[1][1] >= (0.999 if fp32 else 0.995), worst
+    for k in [k for k in one if k.startswith(("rm/", "rv/"))]:
+        assert np.allclose(got[k], one[k], rtol=1e-3 if fp32 else 3e-2, atol=1e-3 if fp32 else 1e-2), k

@@ -425,6 +425,128 @@ def test_sharded_generation_on_hip_equals_single_process(world, tmp_path, backen
         assert np.array_equal(np.array(Image.open(os.path.join(d1, n))), np.array(Image.open(os.path.join(d2, n)))), n
 
 
+def _rehearsal_gen_worker(rank, port, cfg_dict, save_dir, policy, rehearse):
+    import sys
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    torch.cuda.set_device(0)
+    if rehearse:
+        os.environ["HIAST_DIST_REHEARSAL"] = "1"
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        from hiast_amd.utils import comm
+        comm.init_process_group("nccl", rank=0, world_size=1)
+    from hiast_amd.utils.registry import register  # noqa: F401
+    from hiast_amd.utils.registry.registries import PSEUDO_POLICY
+    from hiast_amd.utils.default_config import CfgNode
+    c = CfgNode(cfg_dict)
+    c.pseudo_policy.type = policy
+    c.pseudo_policy.batch_size = 2
+    c.pseudo_policy.save_dir = save_dir
+    gen = PSEUDO_POLICY[policy](c)
+    assert gen.multi == bool(rehearse)
+    gen.run()
+    if rehearse:
+        from hiast_amd.utils import comm
+        assert comm.COUNTS["aux"] > 0                # the exchanges were issued (on RCCL's auxiliary communicator)
+        dist.barrier(device_ids=[0])
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("policy", ["IAS", "CBST"])
+def test_generator_rehearsal_over_rccl_on_one_rank_equals_single_process(world, tmp_path, policy):
+    """the sharded generators' exchange path — histogram / class-sum all-reduce on the auxiliary communicator, CBST's all_gather
+    of class counts, `broadcast_object_list` of the resume decision, `all_gather_object` of the per-image records, barriers —
+    through torch's RCCL backend on ONE rank (HIAST_DIST_REHEARSAL=1, utils/comm.py): every artefact byte-equal to the plain
+    single process.  (RCCL refuses two ranks on one device; the 2- and 4-rank forms of this test run on gloo.)"""
+    import socket
+    import torch.multiprocessing as mp
+    from PIL import Image
+    from hiast_amd.tools import synth_data
+    cfg0, sd, _ = world
+    root = str(tmp_path)
+    cfg = synth_data.synthetic_cfg(root, n_train=6, n_val=1, h=H, w=W)
+    cfg.pseudo_policy.resume_from = cfg0.pseudo_policy.resume_from
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    d2 = os.path.join(root, "pseudo_rehearsal", "pseudo_labels")
+    mp.spawn(_rehearsal_gen_worker, args=(port, cfg.to_dict(), d2, policy, True), nprocs=1, join=True)
+    d1 = os.path.join(root, "pseudo_single", "pseudo_labels")
+    mp.spawn(_rehearsal_gen_worker, args=(port, cfg.to_dict(), d1, policy, False), nprocs=1, join=True)
+    for f in ("class_threshold.npy", "statics_class.npy", "class_mean_probabilities.npy"):
+        a, b = np.load(os.path.join(d1, "..", f)), np.load(os.path.join(d2, "..", f))
+        assert np.array_equal(a.view(np.uint64) if a.dtype == np.float64 else a,
+                              b.view(np.uint64) if b.dtype == np.float64 else b), f
+    for f in ("sample_class_stats.json", "samples_with_class.json"):
+        assert open(os.path.join(d1, "..", f)).read() == open(os.path.join(d2, "..", f)).read(), f
+    names = sorted(os.listdir(d1))
+    assert names == sorted(os.listdir(d2)) and len(names) == 6
+    for n in names:
+        assert np.array_equal(np.array(Image.open(os.path.join(d1, n))), np.array(Image.open(os.path.join(d2, n)))), n
+
+
+def _rehearsal_round_worker(rank, port, cfg_dict, out):
+    import sys
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ["HIAST_DIST_REHEARSAL"] = "1"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("MASTER_ADDR", "MASTER_PORT", "RANK", "WORLD_SIZE"):
+        os.environ.pop(k, None)
+    from hiast_amd.utils.registry import register  # noqa: F401
+    from hiast_amd.utils.registry.registries import TRAINER
+    from hiast_amd.utils.default_config import CfgNode
+    from hiast_amd.utils import comm
+    c = CfgNode(cfg_dict)
+    c.train.port = int(port)
+    c.freeze()
+    tr = TRAINER[c.trainer](c, 0)           # BaseTrainer.initialize starts the one-rank 'nccl' group itself
+    ok = dist.is_initialized() and dist.get_backend() == "nccl" and tr.multi
+    ok = ok and isinstance(tr.model, torch.nn.parallel.DistributedDataParallel)
+    tr.run()
+    fin = all(bool(torch.isfinite(p).all()) for p in tr.model.parameters())
+    json.dump({"ok": bool(ok), "finite": fin, "stat": comm.COUNTS["stat"], "aux": comm.COUNTS["aux"],
+               "tracked": int(tr.model.module.seg_model.backbone.bn1.num_batches_tracked)}, open(out, "w"))
+    dist.barrier(device_ids=[0])
+    dist.destroy_process_group()
+
+
+def test_config3_round_rehearsed_over_rccl_on_one_rank(world, tmp_path):
+    """the config-3 round of `test_config3_hiast_training_round` (CopyPaste + HIAST trainer, report every iteration, validation +
+    checkpoints at the end) with the trainer's N > 1 machinery on torch's RCCL backend, ONE rank (HIAST_DIST_REHEARSAL=1): DDP,
+    104 SyncBN layers exchanging on the statistics communicator, the recorder's packed loss all-reduce, the validation's
+    intersection / union all-reduce on the auxiliary communicator, rank-0 checkpoints with the reference's state-dict keys"""
+    import socket
+    import torch.multiprocessing as mp
+    cfg, sd, root = world
+    c = cfg.clone()
+    c.trainer = "ConsistencySelfTrainingTrainer"
+    c.dataset.target.pseudo_dir = cfg.pseudo_policy.save_dir
+    c.dataset.target.aug_type = ["PRS-%d-%d" % (H, W), "CCA"]
+    c.cst_training.is_enabled = True
+    c.cst_training.cst_loss.weight = 0.5
+    c.preprocessor.type = "CopyPaste"
+    c.train.gpu_num, c.train.batch_size, c.train.total_iter, c.train.iter_report, c.train.iter_val = 1, 2, 2, 1, 2
+    c.train.lr = 3e-6
+    c.work_dir = str(tmp_path / "work_rehearsal")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "r.json")
+    mp.spawn(_rehearsal_round_worker, args=(port, c.to_dict(), out), nprocs=1, join=True)
+    r = json.load(open(out))
+    assert r["ok"] and r["finite"] and r["tracked"] == 2, r
+    assert r["stat"] == 2 * 208 and r["aux"] >= 1, r           # two training iterations; the validation areas
+    ck = os.path.join(c.work_dir, "checkpoints")
+    assert {"model_last.pth", "ema_model_last.pth"} <= set(os.listdir(ck))
+    saved = torch.load(os.path.join(ck, "model_last.pth"), map_location="cpu")
+    assert list(saved.keys()) == list(sd.keys())          # reference state-dict keys: no 'module.' prefix, SyncBN = BN keys
+    assert "mIoU" in open(os.path.join(c.work_dir, "train.log")).read()
+
+
 def test_sharded_generation_four_ranks_equals_single_process(world, tmp_path):
     """the same at FOUR ranks (gloo, all on cuda:0; a GPU box allows six processes on its card): one image per rank and
     global batch — the reference-semantics split of cfg4 / cfg5 — against one process at batch 4 forwarded as four
