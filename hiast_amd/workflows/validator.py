@@ -46,8 +46,9 @@ class Validator:
         # on the HIP device the workers hand over uint8 frames and labels; ToTensor + Normalize run on the device
         # (hiast_normalize_u8: the same bits as the host transform) — as the trainers' loaders do since round 2.  A 2048 x 1024
         # frame is 6 + 2 MB through the worker pipes and PCIe instead of 25 + 17 MB of float32 / int64, and the workers no longer
-        # spend ~50 ms per frame on the float conversion: round 6 measured the stand-alone validator at 12 frames/s on such
-        # frames, the device idle 80 % of the time.  HIAST_HOST_TRANSFORM=1: the reference's float32 / int64 batches.
+        # spend their time on the float conversion (2048 x 1024, flip TTA, 8 workers: 47.9 -> 55.0 frames/s, 61.8 with the batched
+        # mirror image below; profiles/r06_validator_synth.txt).  Workers persist across run() calls (a trainer validates every
+        # iter_val iterations).  HIAST_HOST_TRANSFORM=1: the reference's float32 / int64 batches.
         ds.device_transform = self.device.type == "cuda" and os.environ.get("HIAST_HOST_TRANSFORM", "0") != "1"
         nw = self.cfg.dataset.num_workers
         self.v_loader = DataLoader(ds, self.cfg.validate.batch_size, num_workers=nw, pin_memory=self.device.type == "cuda",
