@@ -805,7 +805,12 @@ def main():
         assert world == 1, "--rehearse-dist is the ONE-rank rehearsal of the N > 1 path"
         multi = True
         os.environ["HIAST_DIST_REHEARSAL"] = "1"        # (before anything of the package asks: utils/comm.py rehearsal())
-        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29541"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+        if "MASTER_PORT" not in os.environ:             # a free port of this host (the group has one rank: nobody else needs it)
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("RANK", "0"), ("WORLD_SIZE", "1")):
             os.environ.setdefault(k, v)
     if args.global_batch:
         assert args.global_batch % world == 0, "--global-batch %d does not divide over %d ranks" % (args.global_batch, world)
